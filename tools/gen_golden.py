@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference).
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+The reference source never leaves /root/reference; only inputs / expected outputs are saved.
+Inputs that are cheap to regenerate are stored as seeds (tests/synth.py) instead of bytes.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_import  # noqa: E402
+import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+T = torch.from_numpy
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print("wrote %-38s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------------------------
+def functional_cases(M):
+    from architecture.modeling.aggregation.utils.block_cost import block_cost
+    from architecture.modeling.layers import inverse_warp_3d, project_to_3d
+    from architecture.modeling.prediction.soft_argmin import SOFTARGMIN
+    from architecture.modeling.prediction.argmin import ARGMIN
+    from architecture.modeling.aggregation.TemporalStereo.coarse import CoarseAggregation
+
+    seed = synth.SEED0
+    # K1a integer path ---------------------------------------------------------------------
+    for i, (B, C, H, W, D) in enumerate([(2, 16, 10, 14, 3), (1, 8, 8, 12, 5), (1, 8, 9, 13, 4)]):
+        L = synth.normal(seed + i, "bcL", (B, C, H, W))
+        R = synth.normal(seed + i, "bcR", (B, C, H, W))
+        out = block_cost(T(L), T(R), D, block_cost_scale=3)
+        save("block_cost_int_%d" % i, left=L, right=R, num_disp=D, scales=3, out=out)
+    # K1b sampled path ---------------------------------------------------------------------
+    for i, (B, C, H, W, D) in enumerate([(2, 16, 10, 14, 5), (1, 8, 8, 12, 3), (1, 8, 9, 13, 6)]):
+        L = synth.normal(seed + 10 + i, "bcL", (B, C, H, W))
+        R = synth.normal(seed + 10 + i, "bcR", (B, C, H, W))
+        disp = synth.uniform(seed + 10 + i, "bcD", (B, D, H, W), -3.0, W + 2.0)
+        disp[:, 0] = np.round(disp[:, 0])            # exact-integer candidates
+        disp[:, 1, :, : W // 2] = 0.0                # zero shift
+        out = block_cost(T(L), T(R), T(disp), block_cost_scale=3)
+        save("block_cost_sampled_%d" % i, left=L, right=R, disp=disp, scales=3, out=out)
+    # scale count 1 and 2
+    L = synth.normal(seed + 20, "bcL", (1, 8, 8, 12)); R = synth.normal(seed + 20, "bcR", (1, 8, 8, 12))
+    disp = synth.uniform(seed + 20, "bcD", (1, 4, 8, 12), 0.0, 6.0)
+    for sc in (1, 2):
+        save("block_cost_sampled_scale%d" % sc, left=L, right=R, disp=disp, scales=sc,
+             out=block_cost(T(L), T(R), T(disp), block_cost_scale=sc))
+        save("block_cost_int_scale%d" % sc, left=L, right=R, num_disp=4, scales=sc,
+             out=block_cost(T(L), T(R), 4, block_cost_scale=sc))
+    # the reference-authored 3x4 "value test" inputs (cat_fms.py:48-57 / dif_fms.py:56-65)
+    H, W = 3, 4
+    left = torch.linspace(1, H * W, H * W).reshape(1, 1, H, W)
+    right = torch.linspace(H * W + 1, H * W * 2, H * W).reshape(1, 1, H, W)
+    ds = torch.linspace(-2, 2, 5).repeat(1, H, W, 1).permute(0, 3, 1, 2).contiguous()
+    save("value_test_warp", left=left, right=right, disp=ds, warped=inverse_warp_3d(right, -ds, padding_mode='zeros'))
+    # K2a geometry --------------------------------------------------------------------------
+    B, C, H, W = 2, 3, 6, 8
+    depth = synth.uniform(seed + 30, "depth", (B, C, H, W), 1.0, 20.0)
+    K = synth.sceneflow_intrinsics(B, 48, 64)
+    K[:, 0] /= 8.0; K[:, 1] /= 8.0
+    Tm = synth.small_motion(seed + 30, B)
+    o = project_to_3d(T(depth), T(K), torch.inverse(T(K)), T(Tm))
+    save("project_to_3d", depth=depth, K=K, T=Tm, triangular_depth=o['triangular_depth'],
+         optical_flow=o['optical_flow'], flow_mask=o['flow_mask'], src_pixel_coord=o['src_pixel_coord'])
+    o3 = project_to_3d(T(depth), T(K[:, :3, :3].copy()), None, T(Tm))
+    save("project_to_3d_k3", depth=depth, K=K[:, :3, :3], T=Tm, triangular_depth=o3['triangular_depth'],
+         optical_flow=o3['optical_flow'])
+    # K4 regression -------------------------------------------------------------------------
+    B, D, H, W = 2, 14, 6, 9
+    cost = synth.normal(seed + 40, "cost", (B, D, H, W))
+    samp = np.sort(synth.uniform(seed + 40, "samp", (B, D, H, W), 0, 30), axis=1)
+    off = synth.uniform(seed + 40, "off", (B, D, H, W), -1, 1)
+    tiny = CoarseAggregation(in_planes=8, C=8, num_sample=2)
+    d, td, tc = tiny.predict_disp(T(cost), T(samp), T(off), k=2)
+    save("topk_softargmax", cost=cost, samp=samp, off=off, disp=d, topk_disp=td, topk_cost=tc)
+    d3, td3, tc3 = tiny.predict_disp(T(cost), T(samp), T(off), k=3)
+    save("topk_softargmax_k3", cost=cost, samp=samp, off=off, disp=d3, topk_disp=td3, topk_cost=tc3)
+    Dd = 48
+    cost = synth.normal(seed + 41, "cost", (1, Dd, 5, 7), 3.0)
+    samp = np.broadcast_to(np.arange(Dd, dtype=np.float32).reshape(1, Dd, 1, 1), (1, Dd, 5, 7)).copy()
+    save("soft_argmin", cost=cost, samp=samp,
+         disp=SOFTARGMIN(temperature=1.0, normalize=True)(T(cost), T(samp)),
+         disp_t2=SOFTARGMIN(temperature=2.0, normalize=True)(T(cost), T(samp)),
+         disp_argmin=ARGMIN(dim=1)(T(cost), T(samp)))
+
+
+# ----------------------------------------------------------------------------------------------
+def build_reference_aggregator(dims):
+    from architecture.modeling.aggregation.TemporalStereo.TemporalStereo import TEMPORALSTEREO
+    from architecture.modeling.aggregation.TemporalStereo.coarse import CoarseAggregation
+    from architecture.modeling.aggregation.TemporalStereo.fine import FineAggregation
+    from architecture.modeling.aggregation.TemporalStereo.precise import PreciseAggregation
+    c, f, p = dims['coarse'], dims['fine'], dims['precise']
+    net = TEMPORALSTEREO(
+        coarse=CoarseAggregation(in_planes=c['in_planes'], C=c['C'], num_sample=c['num_sample'], topk=2),
+        fine=FineAggregation(in_planes=f['in_planes'], C=f['C'], num_sample=5, topk=2),
+        precise=PreciseAggregation(in_planes=p['in_planes'], C=p['C'], num_sample=5, topk=2),
+    )
+    return net
+
+
+def load_synth_weights(net, seed):
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    import json
+    tag = "x".join(str(v.shape[0]) for k, v in net.state_dict().items() if k.endswith("init3d.0.conv.0.weight"))
+    with open(os.path.join(OUT, "state_shapes_%s.json" % tag), "w") as fh:
+        json.dump({k: list(v) for k, v in shapes.items()}, fh, indent=0, sort_keys=True)
+    vals = synth.state_values(shapes, seed)
+    net.load_state_dict({k: T(v) for k, v in vals.items()}, strict=True)
+    return shapes
+
+
+class Recorder:
+    """Records block_cost outputs and the permutations torch.sort produced inside the reference."""
+
+    def __init__(self):
+        self.raw, self.orders = [], []
+
+    def __enter__(self):
+        import architecture.modeling.aggregation.TemporalStereo.coarse as c
+        import architecture.modeling.aggregation.TemporalStereo.fine as f
+        import architecture.modeling.aggregation.TemporalStereo.precise as p
+        self.mods = (c, f, p)
+        self.orig_bc = c.block_cost
+        self.orig_sort = torch.sort
+
+        def bc(*a, **k):
+            out = self.orig_bc(*a, **k)
+            self.raw.append(out)
+            return out
+
+        def sort(x, *a, **k):
+            r = self.orig_sort(x, *a, **k)
+            self.orders.append(r[1])
+            return r
+        for m in self.mods:
+            m.block_cost = bc
+        torch.sort = sort
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.mods:
+            m.block_cost = self.orig_bc
+        torch.sort = self.orig_sort
+
+
+TINY = dict(coarse=dict(in_planes=32, C=8, num_sample=4), fine=dict(in_planes=16, C=8),
+            precise=dict(in_planes=8, C=8))
+SCENEFLOW = dict(coarse=dict(in_planes=256, C=32, num_sample=12), fine=dict(in_planes=128, C=16),
+                 precise=dict(in_planes=64, C=8))
+
+
+def synthetic_prev_info(seed, B, H, W, local_maps=2):
+    """A plausible temporal state at 1/8 resolution (what update_map would hand over)."""
+    h, w = H // 8, W // 8
+    base = synth.uniform(seed, "mem_base", (B, 1, h, w), 1.0, 6.0)
+    ds = np.concatenate([base + 0.3, base - 0.4], axis=1).astype(np.float32)
+    cv = synth.normal(seed, "mem_cost", (B, 2, h, w))
+    lm = np.concatenate([base * 1.02 + 0.1 * k for k in range(local_maps)], axis=1).astype(np.float32)
+    return ds, cv, lm
+
+
+def aggregator_case(name, dims, seed, B, H, W, temporal, store_inputs, training=False):
+    net = build_reference_aggregator(dims)
+    load_synth_weights(net, seed)
+    net.train(training)
+    chans = (dims['precise']['in_planes'], dims['fine']['in_planes'], dims['coarse']['in_planes'])
+    lf, rf = synth.feature_pyramid(seed, B, H, W, chans=chans)
+    il, ir = synth.images(seed, B, H, W)
+    prev = {}
+    extra = {}
+    if temporal:
+        ds, cv, lm = synthetic_prev_info(seed, B, H, W)
+        prev = {'cost_memory': {'disp_sample': T(ds), 'cost_volume': T(cv)}, 'use_past_cost': True,
+                'local_map': T(lm), 'local_map_size': lm.shape[1]}
+        extra.update(mem_disp_sample=ds, mem_cost_volume=cv, local_map=lm)
+    with torch.no_grad(), Recorder() as rec:
+        disps, costs, samples, offs, ranges, info = net([T(x) for x in lf], [T(x) for x in rf], T(il), T(ir), prev)
+    arrs = dict(seed=seed, B=B, H=H, W=W, temporal=int(temporal), training=int(training),
+                dims=np.array([dims['coarse']['in_planes'], dims['coarse']['C'], dims['coarse']['num_sample'],
+                               dims['fine']['in_planes'], dims['fine']['C'],
+                               dims['precise']['in_planes'], dims['precise']['C']]))
+    arrs.update(extra)
+    if store_inputs:     # cross-check that synth regenerates the same bytes on the test side
+        arrs.update(l16_probe=lf[2][:, :2], r16_probe=rf[2][:, :2])
+        for i, nm in enumerate(("full", "precise", "fine_up", "coarse_up")):
+            arrs["disp_" + nm] = disps[i]
+        for i, nm in enumerate(("precise", "fine", "coarse")):
+            arrs["cost_" + nm] = costs[i]
+            arrs["samp_" + nm] = samples[i]
+            arrs["off_" + nm] = offs[i]
+        arrs.update(coarse_raw_b0=rec.raw[0][:1], fine_raw_b0=rec.raw[1][:1],
+                    coarse_order=rec.orders[0].to(torch.int16), fine_order=rec.orders[1].to(torch.int16),
+                    range_fine_low=ranges[0]['low'], range_coarse_low=ranges[1]['low'])
+    else:                # big case: outputs only, full-res map sub-sampled
+        arrs.update(disp_full_sub4=disps[0][:, :, ::4, ::4], disp_precise=disps[1], disp_fine_up=disps[2],
+                    disp_coarse_up=disps[3], cost_coarse=costs[2], samp_fine=samples[1],
+                    disp_full_mean=disps[0].double().mean(), disp_full_absmean=disps[0].double().abs().mean())
+    arrs.update(prev_disp_sub=info['prev_disp'][:, :, ::4, ::4],
+                mem_out_disp_sample=info['cost_memory']['disp_sample'],
+                mem_out_cost_volume=info['cost_memory']['cost_volume'])
+    save(name, **arrs)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    M = ref_import.import_reference()
+    functional_cases(M)
+    aggregator_case("agg_tiny_single", TINY, synth.SEED0 + 100, 2, 96, 160, temporal=False, store_inputs=True)
+    aggregator_case("agg_tiny_temporal", TINY, synth.SEED0 + 101, 2, 96, 160, temporal=True, store_inputs=True)
+    aggregator_case("agg_tiny_train", TINY, synth.SEED0 + 102, 2, 96, 160, temporal=False, store_inputs=True,
+                    training=True)
+    c1 = dict(SCENEFLOW); c1['coarse'] = dict(SCENEFLOW['coarse'], num_sample=3)      # D=48 -> 48/16
+    aggregator_case("agg_config1_256x512", c1, synth.SEED0 + 1, 1, 256, 512, temporal=False, store_inputs=False)
+    with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as fh:
+        fh.write("Generated by tools/gen_golden.py from the reference at /root/reference (v1), torch %s CPU.\n"
+                 "Inputs come from tests/synth.py seeds; weights from synth.state_values().\n" % torch.__version__)
+
+
+if __name__ == "__main__":
+    main()

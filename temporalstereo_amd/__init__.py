@@ -1,0 +1,10 @@
+"""temporalstereo_amd -- MI355X-native (gfx950) cost-volume stereo hot path.
+
+Drop-in for the hot path of youmi-zym/TemporalStereo (cost-volume build, temporal cost warp,
+3-D aggregation pyramid, disparity regression): hand-written HIP kernels in libts_hip.so behind
+the C ABI of include/ts_hip.h, wrapped here as torch.autograd.Function ops and nn.Modules that
+mirror the reference's interfaces.  See DESIGN.md / INTEGRATION.md.
+"""
+__version__ = "0.1.0"
+
+from .functional import block_cost  # noqa: F401

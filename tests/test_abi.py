@@ -1,0 +1,59 @@
+"""CPU: libts_hip.so builds, loads, and exports every symbol include/ts_hip.h declares
+(no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ts_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from temporalstereo_amd import build
+    return build.build(verbose=False)
+
+
+def test_header_symbols_exported(built_lib):
+    handle = ctypes.CDLL(built_lib)
+    syms = declared_symbols()
+    assert len(syms) >= 8
+    for name in syms:
+        assert hasattr(handle, name), "libts_hip.so does not export %s" % name
+
+
+def test_python_signature_table_matches_header(built_lib):
+    from temporalstereo_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    assert _lib.lib().ts_version() >= 1
+    assert _lib.lib().ts_last_error_string() is not None
+
+
+def test_argument_errors_without_gpu(built_lib):
+    """Validation happens before any launch, so it is checkable on CPU."""
+    from temporalstereo_amd import _lib
+    L = _lib.lib()
+    assert L.ts_block_cost_workspace_bytes(1, 12, 8, 8, 3, 3) == 0          # C % 8 != 0
+    assert L.ts_block_cost_workspace_bytes(1, 16, 8, 8, 3, 3) > 0
+    rc = L.ts_block_cost_int_fwd(None, None, None, None, 1, 16, 8, 8, 3, 3, None)
+    assert rc == -1 and b"NULL" in L.ts_last_error_string()
+    rc = L.ts_block_cost_int_fwd(None, None, None, None, 1, 12, 8, 8, 3, 3, None)
+    assert rc == -2
+    rc = L.ts_block_cost_sampled_fwd(None, None, None, None, None, 1, 16, 8, 8, 1, 3, None)
+    assert rc == -3                                                          # D == 1 rejected
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "ts_block_cost_sampled_fwd")
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    import temporalstereo_amd as ts
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ts.block_cost(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4), 3)

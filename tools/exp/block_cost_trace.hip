@@ -1,0 +1,1045 @@
+// K1 -- cost-volume construction for gfx950 (MI355X).
+//
+// Replaces block_cost()  architecture/modeling/aggregation/utils/block_cost.py:16-83 of the
+// reference (int path :34-45, sampled path :47-58 through inverse_warp_3d.py:4-58, multi-scale
+// group correlation :66-81).  Where the reference materialises the shifted/warped right volume
+// twice, pools it three times and concatenates, this is ONE streaming pass:
+//
+//   kernel A  (block_cost_main):  workgroup = (4 feature rows) x (one group of 8 channels) x all
+//       candidates.  The 8x4 right-feature rows are staged once into LDS in a 4-way
+//       de-interleaved layout (element x lives at [x&3][x>>2]) so that a wavefront whose lanes
+//       own 4 consecutive pixels each gathers conflict-free; each lane owns a 4x4 pixel block of
+//       one candidate, emits the main channels and the scale-0 group correlation with 16-byte
+//       coalesced stores, and reduces the 2x2 / 4x4 pooled differences of its own block in
+//       registers (no cross-lane traffic) into two tiny pooled maps.
+//   kernel B  (block_cost_upsample): bilinear (align_corners) expansion of the pooled maps into
+//       the scale-1/2 channel blocks, again 16 bytes per lane.
+//
+// HBM-bound: algorithmic bytes = inputs once + output once; the only
+// extra traffic is the pooled maps (< 2 % of the output).  There is no inter-workgroup reuse, so
+// no XCD-aware block remap is needed here (cdna guide T1: 0 % on ops without shared panels).
+#include "../../temporalstereo_amd/csrc/ts_common.hpp"
+#include <cstdlib>
+extern "C" { unsigned long long* g_trace = nullptr; }
+
+namespace {
+
+constexpr int GRP = 8;  // channels per correlation group (block_cost.py:8)
+constexpr int TR = 4;   // feature rows per workgroup == pooling footprint of scale 2
+
+struct Shape {
+  int B, C, H, W, D, scales;
+  int G;          // C / 8
+  int mainC;      // C (int path) or 2C (sampled path)
+  int Ctot;       // mainC + scales * G
+  int H1, W1, H2, W2;
+  int nbx, nby;   // 4x4 pixel blocks
+  int nbxp;       // nbx padded so that a wavefront does not straddle candidates (when cheap)
+  int Wq, Wqp;    // quarter-row length and its padded LDS stride
+  float rh1, rw1, rh2, rw2;  // align_corners scales (in-1)/(out-1) of the two pooled maps
+  unsigned long long* trace;
+};
+
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float* __restrict__ row, int x, int W) {
+  if constexpr (VEC) {
+    return *reinterpret_cast<const float4*>(row + x);
+  } else {
+    float4 v;
+    v.x = (x + 0 < W) ? row[x + 0] : 0.f;
+    v.y = (x + 1 < W) ? row[x + 1] : 0.f;
+    v.z = (x + 2 < W) ? row[x + 2] : 0.f;
+    v.w = (x + 3 < W) ? row[x + 3] : 0.f;
+    return v;
+  }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void st4(float* __restrict__ row, int x, int W, float4 v) {
+  if constexpr (VEC) {
+    *reinterpret_cast<float4*>(row + x) = v;
+  } else {
+    if (x + 0 < W) row[x + 0] = v.x;
+    if (x + 1 < W) row[x + 1] = v.y;
+    if (x + 2 < W) row[x + 2] = v.z;
+    if (x + 3 < W) row[x + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ void unpack(const float4 v, float (&a)[4]) { a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+__device__ __forceinline__ float4 pack(const float (&a)[4]) { return make_float4(a[0], a[1], a[2], a[3]); }
+
+
+// Source taps of one output pixel: the two neighbouring right-feature columns (as LDS or row
+// offsets) and their weights (0 outside the row == zeros padding).
+template <bool SAMPLED, bool STAGE>
+__device__ __forceinline__ void tap(int x, int d, float dispv, int W, float Wm1, int Wqp,
+                                    int& o0, int& o1, float& w0, float& w1) {
+  int xi;
+  float f = 0.f;
+  if constexpr (SAMPLED) {
+    // same float sequence as the reference: normalise to [-1,1] (inverse_warp_3d.py:41-47)
+    // and back (grid_sampler align_corners), so the tap position rounds identically
+    const float xs = static_cast<float>(x) + (-dispv);
+    const float gx = (xs / Wm1 * 2.f) - 1.f;
+    float ix = ((gx + 1.f) / 2.f) * Wm1;
+    ix = fminf(fmaxf(ix, -2.f), static_cast<float>(W) + 1.f);   // keeps int conversion defined
+    const float fl = floorf(ix);
+    f = ix - fl;
+    xi = static_cast<int>(fl);
+  } else {
+    xi = x - d;
+  }
+  const bool v0 = (xi >= 0) & (xi < W);
+  const bool v1 = (xi + 1 >= 0) & (xi + 1 < W);
+  w0 = v0 ? (1.f - f) : 0.f;
+  w1 = v1 ? f : 0.f;
+  const int i0 = min(max(xi, 0), W - 1);
+  const int i1 = min(max(xi + 1, 0), W - 1);
+  if constexpr (STAGE) {
+    o0 = (i0 & 3) * Wqp + (i0 >> 2);
+    o1 = (i1 & 3) * Wqp + (i1 >> 2);
+  } else {
+    o0 = i0;
+    o1 = i1;
+  }
+}
+
+// cooperative copy of the 8x4 right-feature rows of this workgroup into LDS, de-interleaved
+// [c][r][x&3][x>>2]: a float4 read from global is scattered to the four quarter-rows
+template <bool VEC>
+__device__ __forceinline__ void stage_right_rows(float* lds, const float* __restrict__ Rg, int y0, int H, int W,
+                                                 size_t HW, int Wq, int Wqp) {
+  const int n = GRP * TR * Wq;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int j = i % Wq, cr = i / Wq;
+    const int y = y0 + (cr & (TR - 1));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < H) v = ld4<VEC>(Rg + static_cast<size_t>(cr >> 2) * HW + static_cast<size_t>(y) * W, 4 * j, W);
+    float* dst = lds + static_cast<size_t>(cr) * 4 * Wqp + j;
+    dst[0] = v.x;
+    dst[Wqp] = v.y;
+    dst[2 * Wqp] = v.z;
+    dst[3 * Wqp] = v.w;
+  }
+  __syncthreads();
+}
+
+// SAMPLED: per-pixel fractional candidates (block_cost.py:47-58); else integer shift d (:34-45).
+// VEC:     W % 4 == 0 and 16-byte aligned bases -> float4 traffic.
+// STAGE:   the workgroup's feature rows live in LDS: all 8x4 right rows (de-interleaved for the
+//          gather) and the left rows two at a time (linear, read back with ds_read_b128; rows 2-3
+//          are fetched into registers during the prologue and swapped in at half time).  After the
+//          prologue the only vector-memory traffic of a wave is its store stream plus one
+//          prefetched candidate row, so a wave never waits on its own stores (vmcnt is in-order and
+//          counts stores on CDNA4).  ~47 KiB at W=240 -> three workgroups per CU, so the 544
+//          workgroups of the 136x240 level are co-resident in a single round.
+//          Rows too wide for that (or needing more than one pass of items) read both maps
+//          through L1/L2 instead.
+// NP:      left float4 values each thread carries across the first half (STAGE only).
+template <bool SAMPLED, bool VEC, bool STAGE, int NP>
+__global__ void __launch_bounds__(512)
+block_cost_main(const float* __restrict__ L, const float* __restrict__ R,
+                const float* __restrict__ disp, float* __restrict__ out,
+                float* __restrict__ P1, float* __restrict__ P2, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int by = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int y0 = by * TR;
+  const int H = s.H, W = s.W, D = s.D, C = s.C;
+  const size_t HW = static_cast<size_t>(H) * W;
+  const float* Lg = L + (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const float* Rg = R + (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const int Wl = 4 * s.Wq;                                    // LDS row length of the left rows
+  float* ldsL = lds + static_cast<size_t>(GRP) * TR * 4 * s.Wqp;   // [c][r & 1][Wl]
+
+  float4 lpre[NP];   // left rows 2,3 in flight across the first half
+  if constexpr (STAGE) {
+    const int n = GRP * TR * s.Wq;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int j = i % s.Wq, cr = i / s.Wq;
+      const int r = cr & (TR - 1), c = cr >> 2;
+      const int y = y0 + r;
+      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), lv = rv;
+      if (y < H) {
+        const size_t off = static_cast<size_t>(c) * HW + static_cast<size_t>(y) * W;
+        rv = ld4<VEC>(Rg + off, 4 * j, W);
+        if (r < 2) lv = ld4<VEC>(Lg + off, 4 * j, W);
+      }
+      float* dst = lds + static_cast<size_t>(cr) * 4 * s.Wqp + j;
+      dst[0] = rv.x;
+      dst[s.Wqp] = rv.y;
+      dst[2 * s.Wqp] = rv.z;
+      dst[3 * s.Wqp] = rv.w;
+      if (r < 2) *reinterpret_cast<float4*>(ldsL + static_cast<size_t>(c * 2 + r) * Wl + 4 * j) = lv;
+    }
+    const int n2 = GRP * 2 * s.Wq;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int i = threadIdx.x + p * blockDim.x;
+      lpre[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n2) {
+        const int j = i % s.Wq, cr = i / s.Wq;          // cr = c*2 + (r-2)
+        const int y = y0 + 2 + (cr & 1);
+        if (y < H) lpre[p] = ld4<VEC>(Lg + static_cast<size_t>(cr >> 1) * HW + static_cast<size_t>(y) * W, 4 * j, W);
+      }
+    }
+    __syncthreads();
+  }
+
+  const float Wm1 = static_cast<float>(W - 1);
+  const int nitems = s.nbxp * D;
+  // STAGE runs exactly one item per thread (the host guarantees nitems <= blockDim) so that the
+  // half-time barrier is uniform; the fallback loops.
+  for (int item = threadIdx.x; item < (STAGE ? blockDim.x : nitems); item += blockDim.x) {
+    const int d = item / s.nbxp;
+    const int bx = item - d * s.nbxp;
+    const bool live = (item < nitems) && (bx < s.nbx);
+    if (!STAGE && !live) continue;
+    const int x4 = bx * 4;
+    float* plane0 = out + (static_cast<size_t>(b) * s.Ctot * D + (live ? d : 0)) * HW;  // channel 0, candidate d
+    const size_t cstride = static_cast<size_t>(D) * HW;                                 // one channel
+    const float* drow = SAMPLED ? disp + (static_cast<size_t>(b) * D + (live ? d : 0)) * HW : nullptr;
+
+    float s1[GRP][2];   // 2x2 pooled difference sums of the current row pair
+    float s2[GRP];      // 4x4 pooled difference sums
+#pragma unroll
+    for (int c = 0; c < GRP; ++c) s1[c][0] = s1[c][1] = s2[c] = 0.f;
+    const size_t pbase = ((static_cast<size_t>(b) * s.G + g) * D + d);
+
+    float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (SAMPLED) {
+      if (live) dnext = ld4<VEC>(drow + static_cast<size_t>(y0) * W, x4, W);
+    }
+
+#pragma unroll 1
+    for (int r = 0; r < TR; ++r) {
+      const int y = y0 + r;
+      if constexpr (STAGE) {
+        if (r == 2) {   // swap left rows 2,3 into the LDS slots of rows 0,1
+          __syncthreads();
+          const int n2 = GRP * 2 * s.Wq;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const int i = threadIdx.x + p * blockDim.x;
+            if (i < n2) {
+              const int j = i % s.Wq, cr = i / s.Wq;
+              *reinterpret_cast<float4*>(ldsL + static_cast<size_t>(cr) * Wl + 4 * j) = lpre[p];
+            }
+          }
+          __syncthreads();
+        }
+      }
+      if (y < H && live) {
+        float dv[4];
+        unpack(dnext, dv);
+        if constexpr (SAMPLED) {   // prefetch the next candidate row ahead of this row's stores
+          if (r + 1 < TR && y + 1 < H) dnext = ld4<VEC>(drow + static_cast<size_t>(y + 1) * W, x4, W);
+        }
+        int o0[4], o1[4];
+        float w0[4], w1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          tap<SAMPLED, STAGE>(x4 + k, d, dv[k], W, Wm1, s.Wqp, o0[k], o1[k], w0[k], w1[k]);
+        float g0[4] = {0.f, 0.f, 0.f, 0.f};
+        const size_t rowoff = static_cast<size_t>(y) * W;
+#pragma unroll
+        for (int c = 0; c < GRP; ++c) {
+          float4 lv4;
+          const float* src;
+          if constexpr (STAGE) {
+            lv4 = *reinterpret_cast<const float4*>(ldsL + static_cast<size_t>(c * 2 + (r & 1)) * Wl + x4);
+            src = lds + static_cast<size_t>(c * TR + r) * 4 * s.Wqp;
+          } else {
+            lv4 = ld4<VEC>(Lg + c * HW + rowoff, x4, W);
+            src = Rg + c * HW + rowoff;
+          }
+          float lv[4], tv[4], ev[4];
+          unpack(lv4, lv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float t = w0[k] * src[o0[k]];
+            if constexpr (SAMPLED) t += w1[k] * src[o1[k]];
+            tv[k] = t;
+            ev[k] = lv[k] - t;
+          }
+          float* pl = plane0 + static_cast<size_t>(g * GRP + c) * cstride + rowoff;
+          if constexpr (SAMPLED) {
+            st4<VEC>(pl, x4, W, lv4);                                              // reference half
+            st4<VEC>(pl + static_cast<size_t>(C) * cstride, x4, W, pack(tv));      // warped half
+          } else {
+            st4<VEC>(pl, x4, W, make_float4(-ev[0] * ev[0], -ev[1] * ev[1], -ev[2] * ev[2], -ev[3] * ev[3]));
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g0[k] += ev[k] * ev[k];
+          s1[c][0] += ev[0] + ev[1];
+          s1[c][1] += ev[2] + ev[3];
+        }
+        st4<VEC>(plane0 + static_cast<size_t>(s.mainC + g) * cstride + rowoff, x4, W,
+                 make_float4(-g0[0], -g0[1], -g0[2], -g0[3]));
+      }
+      if (r & 1) {   // a row pair is complete: emit its 2x2 cells, fold it into the 4x4 sums
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < GRP; ++c) {
+          const float a = s1[c][0] * 0.25f, e = s1[c][1] * 0.25f;
+          a0 += a * a;
+          a1 += e * e;
+          s2[c] += s1[c][0] + s1[c][1];
+          s1[c][0] = s1[c][1] = 0.f;
+        }
+        const int py = 2 * by + (r >> 1);
+        if (live && s.scales > 1 && py < s.H1) {
+          float* prow = P1 + (pbase * s.H1 + py) * s.W1;
+          if (2 * bx < s.W1) prow[2 * bx] = -a0;
+          if (2 * bx + 1 < s.W1) prow[2 * bx + 1] = -a1;
+        }
+      }
+    }
+    if (live && s.scales > 2 && by < s.H2 && bx < s.W2) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < GRP; ++c) {
+        const float m = s2[c] * 0.0625f;
+        acc += m * m;
+      }
+      P2[(pbase * s.H2 + by) * s.W2 + bx] = -acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fast path (all shipped configs): rows narrow enough for LDS staging, one item per thread.
+//
+// LDS layout
+//   R4  [half h][row r][x & 3][x >> 2] of float4 = the 4 channels 4h..4h+3 of one right pixel.
+//       One tap of one pixel is then TWO ds_read_b128 for all 8 channels (instead of 8 ds_read_b32),
+//       and lanes that own consecutive 4-pixel blocks read consecutive 16-byte slots (conflict-free).
+//   Lx  [channel c][row & 1][x] plain rows of the left map, read back as one float4 per channel;
+//       rows 2,3 ride in registers through the first half and are swapped in at half time, which
+//       keeps the workgroup at ~47 KiB (W=240) so that three of them share a CU.
+// Addressing: every output plane base is wave-uniform (SGPR); a lane carries ONE 32-bit element
+// offset (candidate, row, column) for all 17 planes it stores to.
+// ------------------------------------------------------------------------------------------------
+
+// ---- buffer (SRSRC) addressing: wave-uniform base in SGPRs + one 32-bit per-lane byte offset ----
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// 4 floats at element offset `eoff` (+ uniform element offset `uoff`); elements with x+k >= W are
+// skipped in the non-VEC form.
+template <bool VEC>
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned eoff, unsigned uoff, int x, int W, float4 v) {
+  if constexpr (VEC) {
+    u32x4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, eoff * 4u, uoff * 4u, 0);
+  } else {
+    if (x + 0 < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), r, eoff * 4u, uoff * 4u, 0);
+    if (x + 1 < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), r, eoff * 4u + 4u, uoff * 4u, 0);
+    if (x + 2 < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), r, eoff * 4u + 8u, uoff * 4u, 0);
+    if (x + 3 < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), r, eoff * 4u + 12u, uoff * 4u, 0);
+  }
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned eoff, int x, int W) {
+  if constexpr (VEC) {
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, eoff * 4u, 0, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+  } else {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x + 0 < W) v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, eoff * 4u, 0, 0));
+    if (x + 1 < W) v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, eoff * 4u + 4u, 0, 0));
+    if (x + 2 < W) v.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, eoff * 4u + 8u, 0, 0));
+    if (x + 3 < W) v.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, eoff * 4u + 12u, 0, 0));
+    return v;
+  }
+}
+
+// One output pixel's two source columns as float4-slot offsets inside an R4 row, packed 16+16 bits,
+// plus the fraction.  Columns outside the row map to the zero slot (index Wq of quarter-row 0), so
+// zeros padding needs no weight masking.
+template <bool SAMPLED>
+__device__ __forceinline__ void tap4(int x, int d, float dispv, int W, float Wm1, int Wq, int Wqp,
+                                     unsigned& packed, float& f) {
+  int xi;
+  f = 0.f;
+  if constexpr (SAMPLED) {
+    // same float sequence as the reference: normalise to [-1,1] (inverse_warp_3d.py:41-47)
+    // and back (grid_sampler align_corners), so the tap position rounds identically
+    const float xs = static_cast<float>(x) + (-dispv);
+    const float gx = (xs / Wm1 * 2.f) - 1.f;
+    float ix = ((gx + 1.f) / 2.f) * Wm1;
+    ix = fminf(fmaxf(ix, -2.f), static_cast<float>(W) + 1.f);   // keeps int conversion defined
+    const float fl = floorf(ix);
+    f = ix - fl;
+    xi = static_cast<int>(fl);
+  } else {
+    xi = x - d;
+  }
+  const unsigned a0 = (xi >= 0 && xi < W) ? static_cast<unsigned>((xi & 3) * Wqp + (xi >> 2)) : static_cast<unsigned>(Wq);
+  const int xj = xi + 1;
+  const unsigned a1 = (xj >= 0 && xj < W) ? static_cast<unsigned>((xj & 3) * Wqp + (xj >> 2)) : static_cast<unsigned>(Wq);
+  packed = a0 | (a1 << 16);
+}
+
+__device__ __forceinline__ float comp(const float4& v, int i) {
+  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+template <bool SAMPLED, bool VEC, int NP>
+__global__ void __launch_bounds__(512, 4)   // <= 128 VGPRs: three 5-wave workgroups per CU
+block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
+                const float* __restrict__ disp, float* __restrict__ out,
+                float* __restrict__ P1, float* __restrict__ P2, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int by = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int y0 = by * TR;
+  const int H = s.H, W = s.W, D = s.D, C = s.C;
+  const unsigned HW = static_cast<unsigned>(H) * W;
+  const float* Lg = L + (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const float* Rg = R + (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const int Wq = s.Wq, Wqp = s.Wqp, Wl = 4 * s.Wq;
+  float4* ldsR4 = reinterpret_cast<float4*>(lds);                       // [2][TR][4][Wqp]
+  float* ldsL = lds + static_cast<size_t>(2) * TR * 4 * Wqp * 4;        // [GRP][2][Wl]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  unsigned long long t0 = __builtin_readcyclecounter(), t1 = 0;
+  unsigned long long w0c = wall_clock64();
+
+  // ---- prologue: stage right rows (channel-packed), left rows 0,1; fetch left rows 2,3 ----------
+  for (int i = tid; i < 2 * TR * Wq; i += nthr) {
+    const int j = i % Wq, hr = i / Wq;            // hr = h*TR + r
+    const int r = hr & (TR - 1), h = hr >> 2;
+    const int y = y0 + r;
+    float v[4][4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y < H) t4 = ld4<VEC>(Rg + static_cast<size_t>(h * 4 + cc) * HW + static_cast<size_t>(y) * W, 4 * j, W);
+      unpack(t4, v[cc]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      ldsR4[(hr * 4 + k) * Wqp + j] = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
+  }
+  if (tid < 2 * TR) ldsR4[(tid * 4) * Wqp + Wq] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero slot of each row
+  const int n2 = GRP * 2 * Wq;
+  float4 lpre[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int i = tid + p * nthr;
+    lpre[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n2) {
+      const int j = i % Wq, cr = i / Wq;          // cr = c*2 + (row & 1)
+      const size_t off = static_cast<size_t>(cr >> 1) * HW;
+      const int ya = y0 + (cr & 1), yb = ya + 2;
+      float4 first = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ya < H) first = ld4<VEC>(Lg + off + static_cast<size_t>(ya) * W, 4 * j, W);
+      if (yb < H) lpre[p] = ld4<VEC>(Lg + off + static_cast<size_t>(yb) * W, 4 * j, W);
+      *reinterpret_cast<float4*>(ldsL + cr * Wl + 4 * j) = first;
+    }
+  }
+  __syncthreads();
+  t1 = __builtin_readcyclecounter();
+
+  // ---- one item (candidate d, 4x4 block bx) per thread ------------------------------------------
+  const int item = tid;
+  const int d = item / s.nbxp;
+  const int bx = item - d * s.nbxp;
+  const bool live = (d < D) && (bx < s.nbx);
+  const int x4 = bx * 4;
+  const float Wm1 = static_cast<float>(W - 1);
+  const unsigned dHW = static_cast<unsigned>(D) * HW;                         // one channel (uniform)
+  // the whole [Ctot, D, H, W] slab of this batch item behind one descriptor (host checks < 4 GiB)
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + static_cast<size_t>(b) * s.Ctot * dHW,
+                                                 static_cast<unsigned>(s.Ctot) * dHW * 4u);
+  const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(SAMPLED ? disp + static_cast<size_t>(b) * dHW : out, dHW * 4u);
+  unsigned loff = (live ? static_cast<unsigned>(d) : 0u) * HW + static_cast<unsigned>(y0) * W + x4;
+
+  float s1[GRP][2], s2[GRP];
+#pragma unroll
+  for (int c = 0; c < GRP; ++c) s1[c][0] = s1[c][1] = s2[c] = 0.f;
+  const size_t pbase = ((static_cast<size_t>(b) * s.G + g) * D + (live ? d : 0));
+
+  float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (SAMPLED) {
+    if (live) dnext = bld4<VEC>(drsrc, loff, x4, W);
+  }
+
+#pragma unroll 1
+  for (int r = 0; r < TR; ++r, loff += W) {
+    const int y = y0 + r;
+    if (r == 2) {   // swap left rows 2,3 into the LDS slots of rows 0,1
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int i = tid + p * nthr;
+        if (i < n2) *reinterpret_cast<float4*>(ldsL + (i / Wq) * Wl + 4 * (i % Wq)) = lpre[p];
+      }
+      __syncthreads();
+    }
+    if (y < H && live) {
+      float dv[4];
+      unpack(dnext, dv);
+      if constexpr (SAMPLED) {   // prefetch the next candidate row ahead of this row's stores
+        if (r + 1 < TR && y + 1 < H) dnext = bld4<VEC>(drsrc, loff + W, x4, W);
+      }
+      unsigned op[4];
+      float fr[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tap4<SAMPLED>(x4 + k, d, dv[k], W, Wm1, Wq, Wqp, op[k], fr[k]);
+      float g0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4* rrow = ldsR4 + (h * TR + r) * 4 * Wqp;
+        float4 ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ta[k] = rrow[op[k] & 0xffffu];
+          if constexpr (SAMPLED) tb[k] = rrow[op[k] >> 16];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = h * 4 + cc;
+          const float4 lv4 = *reinterpret_cast<const float4*>(ldsL + (c * 2 + (r & 1)) * Wl + x4);
+          float lv[4], tv[4], ev[4];
+          unpack(lv4, lv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float t = comp(ta[k], cc);
+            if constexpr (SAMPLED) t = (1.f - fr[k]) * t + fr[k] * comp(tb[k], cc);
+            tv[k] = t;
+            ev[k] = lv[k] - t;
+          }
+          const unsigned plane = static_cast<unsigned>(g * GRP + c) * dHW;        // uniform (SGPR)
+          if constexpr (SAMPLED) {
+            bst4<VEC>(orsrc, loff, plane, x4, W, lv4);                              // reference half
+            bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));   // warped half
+          } else {
+            bst4<VEC>(orsrc, loff, plane, x4, W,
+                      make_float4(-ev[0] * ev[0], -ev[1] * ev[1], -ev[2] * ev[2], -ev[3] * ev[3]));
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g0[k] += ev[k] * ev[k];
+          s1[c][0] += ev[0] + ev[1];
+          s1[c][1] += ev[2] + ev[3];
+        }
+      }
+      bst4<VEC>(orsrc, loff, static_cast<unsigned>(s.mainC + g) * dHW, x4, W,
+                make_float4(-g0[0], -g0[1], -g0[2], -g0[3]));
+    }
+    if (r & 1) {   // a row pair is complete: emit its 2x2 cells, fold it into the 4x4 sums
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < GRP; ++c) {
+        const float a = s1[c][0] * 0.25f, e = s1[c][1] * 0.25f;
+        a0 += a * a;
+        a1 += e * e;
+        s2[c] += s1[c][0] + s1[c][1];
+        s1[c][0] = s1[c][1] = 0.f;
+      }
+      const int py = 2 * by + (r >> 1);
+      if (live && s.scales > 1 && py < s.H1) {
+        float* prow = P1 + (pbase * s.H1 + py) * s.W1;
+        if (2 * bx < s.W1) prow[2 * bx] = -a0;
+        if (2 * bx + 1 < s.W1) prow[2 * bx + 1] = -a1;
+      }
+    }
+  }
+  if (live && s.scales > 2 && by < s.H2 && bx < s.W2) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < GRP; ++c) {
+      const float m = s2[c] * 0.0625f;
+      acc += m * m;
+    }
+    P2[(pbase * s.H2 + by) * s.W2 + bx] = -acc;
+  }
+  if (s.trace && threadIdx.x == 0) {
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const size_t wg = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    unsigned long long* rec = s.trace + wg * 8;
+    rec[0] = t0; rec[1] = t1; rec[2] = __builtin_readcyclecounter(); rec[3] = xcc; rec[4] = hwid; rec[5] = w0c; rec[6] = wall_clock64();
+  }
+}
+
+// trilinear(align_corners=True) expansion of the pooled maps (block_cost.py:74); the D axis maps
+// to itself, so it is a per-candidate bilinear interpolation, done separably: a workgroup owns a
+// band of RB output rows of one (b, g, d) plane, first interpolates the few pooled rows the band
+// touches along W into LDS (coalesced reads of the tiny pooled maps), then blends pairs of those
+// rows along H with ds_read_b128 and streams 16-byte stores.
+template <bool VEC, int RB>
+__global__ void __launch_bounds__(256)
+block_cost_upsample(const float* __restrict__ P1, const float* __restrict__ P2,
+                    float* __restrict__ out, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NR1 = RB / 2 + 2, NR2 = RB / 4 + 2;     // pooled rows a band can touch per level
+  const int Wl = 4 * s.nbx;
+  const int band = blockIdx.x, plane = blockIdx.y + blockIdx.z * gridDim.y;
+  if (plane >= s.B * s.G * s.D) return;
+  const int d = plane % s.D;
+  const int bg = plane / s.D;
+  const int g = bg % s.G, b = bg / s.G;
+  const int yfirst = band * RB;
+  const int ylast = min(yfirst + RB, s.H) - 1;
+  const size_t HW = static_cast<size_t>(s.H) * s.W;
+
+  int lo[3];
+#pragma unroll
+  for (int lvl = 1; lvl <= 2; ++lvl) {
+    if (lvl >= s.scales) break;
+    const float* P = (lvl == 1) ? P1 : P2;
+    const int Hs = (lvl == 1) ? s.H1 : s.H2, Ws = (lvl == 1) ? s.W1 : s.W2;
+    const float rh = (lvl == 1) ? s.rh1 : s.rh2, rw = (lvl == 1) ? s.rw1 : s.rw2;
+    const int nr = (lvl == 1) ? NR1 : NR2;
+    float* buf = lds + (lvl == 1 ? 0 : NR1 * Wl);
+    lo[lvl] = static_cast<int>(rh * static_cast<float>(yfirst));
+    const int hi = min(static_cast<int>(rh * static_cast<float>(ylast)) + 1, Hs - 1);
+    const float* Pp = P + static_cast<size_t>(plane) * Hs * Ws;
+    for (int i = threadIdx.x; i < nr * Wl; i += blockDim.x) {
+      const int rr = i / Wl, x = i - rr * Wl;
+      const int srow = lo[lvl] + rr;
+      float v = 0.f;
+      if (srow <= hi && x < s.W) {
+        const float wr = rw * static_cast<float>(x);
+        const int w1 = static_cast<int>(wr);
+        const int wp = (w1 < Ws - 1) ? 1 : 0;
+        const float wl = wr - static_cast<float>(w1);
+        const float* row = Pp + static_cast<size_t>(srow) * Ws;
+        v = (1.f - wl) * row[w1] + wl * row[w1 + wp];
+      }
+      buf[i] = v;
+    }
+  }
+  __syncthreads();
+
+  const int nrows = ylast - yfirst + 1;
+  for (int item = threadIdx.x; item < nrows * s.nbx; item += blockDim.x) {
+    const int r = item / s.nbx;
+    const int x4 = (item - r * s.nbx) * 4;
+    const int y = yfirst + r;
+#pragma unroll
+    for (int lvl = 1; lvl <= 2; ++lvl) {
+      if (lvl >= s.scales) break;
+      const int Hs = (lvl == 1) ? s.H1 : s.H2;
+      const float rh = (lvl == 1) ? s.rh1 : s.rh2;
+      const float* buf = lds + (lvl == 1 ? 0 : NR1 * Wl);
+      const float hr = rh * static_cast<float>(y);
+      const int h1 = static_cast<int>(hr);
+      const int hp = (h1 < Hs - 1) ? 1 : 0;
+      const float hl = hr - static_cast<float>(h1);
+      const float4 a = *reinterpret_cast<const float4*>(buf + (h1 - lo[lvl]) * Wl + x4);
+      const float4 c = *reinterpret_cast<const float4*>(buf + (h1 + hp - lo[lvl]) * Wl + x4);
+      const float4 v = make_float4((1.f - hl) * a.x + hl * c.x, (1.f - hl) * a.y + hl * c.y,
+                                   (1.f - hl) * a.z + hl * c.z, (1.f - hl) * a.w + hl * c.w);
+      float* pl = out + ((static_cast<size_t>(b) * s.Ctot + s.mainC + lvl * s.G + g) * s.D + d) * HW +
+                  static_cast<size_t>(y) * s.W;
+      st4<VEC>(pl, x4, s.W, v);
+    }
+  }
+}
+
+int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales) {
+  TS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, TS_ERR_SHAPE, "block_cost: non-positive size");
+  TS_REQUIRE(C % GRP == 0, TS_ERR_SHAPE, "block_cost: C=%d is not a multiple of 8 (block_cost.py:9)", C);
+  TS_REQUIRE(scales >= 1 && scales <= 3, TS_ERR_UNSUPPORTED, "block_cost: scales=%d outside 1..3", scales);
+  TS_REQUIRE(H >= 4 && W >= 4, TS_ERR_UNSUPPORTED, "block_cost: H,W must be >= 4 (got %dx%d)", H, W);
+  // D==1 divides by zero in the reference's coordinate normalisation (inverse_warp_3d.py:45)
+  TS_REQUIRE(!sampled || D >= 2, TS_ERR_UNSUPPORTED, "block_cost: sampled path needs D >= 2");
+  TS_REQUIRE(B <= 65535 && C / GRP <= 65535, TS_ERR_UNSUPPORTED, "block_cost: grid too large");
+  s.B = B; s.C = C; s.H = H; s.W = W; s.D = D; s.scales = scales;
+  s.G = C / GRP;
+  s.mainC = sampled ? 2 * C : C;
+  s.Ctot = s.mainC + scales * s.G;
+  s.H1 = H / 2; s.W1 = W / 2; s.H2 = H / 4; s.W2 = W / 4;
+  s.nbx = (W + 3) / 4; s.nby = (H + 3) / 4;
+  s.Wq = s.nbx; s.Wqp = (s.Wq + 1) | 1;    // >= Wq + 1: slot Wq of quarter-row 0 is the zero slot
+  // lanes of one wave should store into one plane: pad the per-candidate item count to a divisor
+  // (or multiple) of 64 when that idles at most 1/8 of the lanes
+  s.nbxp = s.nbx;
+  for (int q : {8, 16, 32, 64, 128, 192, 256, 320, 384, 448, 512}) {
+    if (q >= s.nbx) {
+      if ((q - s.nbx) * 8 <= q) s.nbxp = q;
+      break;
+    }
+  }
+  auto scale = [](int in, int outn) { return outn > 1 ? static_cast<float>(in - 1) / static_cast<float>(outn - 1) : 0.f; };
+  s.rh1 = scale(s.H1, H); s.rw1 = scale(s.W1, W);
+  s.rh2 = scale(s.H2, H); s.rw2 = scale(s.W2, W);
+  s.trace = g_trace;
+  return TS_OK;
+}
+
+size_t pooled_bytes(const Shape& s, int lvl) {
+  const size_t n = static_cast<size_t>(s.B) * s.G * s.D * (lvl == 1 ? s.H1 * s.W1 : s.H2 * s.W2);
+  return ts::round_up(n * sizeof(float), 256);
+}
+
+template <bool SAMPLED>
+int launch_fwd(const float* left, const float* right, const float* disp, float* out, void* workspace,
+               int B, int C, int H, int W, int D, int scales, void* stream) {
+  Shape s;
+  if (int rc = make_shape(s, SAMPLED, B, C, H, W, D, scales)) return rc;
+  TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(out);
+  if (SAMPLED) TS_REQUIRE_PTR(disp);
+  if (scales > 1) TS_REQUIRE_PTR(workspace);
+  float* P1 = reinterpret_cast<float*>(workspace);
+  float* P2 = scales > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pooled_bytes(s, 1)) : nullptr;
+
+  const bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(out) &&
+                   (!SAMPLED || ts::aligned16(disp));
+  const int nitems = s.nbxp * D;
+  // one pass when the row of items fits a workgroup, otherwise an even split over the fewest passes
+  const int passes = (nitems + 511) / 512;
+  int threads = static_cast<int>(ts::round_up(static_cast<size_t>((nitems + passes - 1) / passes), ts::kWave));
+  if (threads > 512) threads = 512;
+  // LDS: 4 right rows (de-interleaved, padded) + 2 left rows, per channel of the group
+  const size_t lds_bytes = static_cast<size_t>(GRP) * (TR * 4 * s.Wqp + 2 * 4 * s.Wq) * sizeof(float);   // R4 + Lx
+  const int np = (GRP * 2 * s.Wq + threads - 1) / threads;     // carried left float4s per thread
+  // the fast path addresses one batch item's output slab through a 32-bit buffer descriptor
+  const bool stage = lds_bytes <= 64 * 1024 && passes == 1 && np <= 8 &&
+                     static_cast<unsigned long long>(s.Ctot) * D * H * W * 4ull < (1ull << 32);
+  const dim3 grid(s.nby, s.G, B);
+  hipStream_t st = ts::as_stream(stream);
+
+#define TS_LAUNCH_FAST(V, N)                                                                     \
+  hipLaunchKernelGGL((block_cost_fast<SAMPLED, V, N>), grid, dim3(threads), lds_bytes, st,       \
+                     left, right, disp, out, P1, P2, s)
+#define TS_LAUNCH_WIDE(V)                                                                        \
+  hipLaunchKernelGGL((block_cost_main<SAMPLED, V, false, 1>), grid, dim3(threads), 0, st,        \
+                     left, right, disp, out, P1, P2, s)
+  if (stage) {
+    if (vec) { if (np <= 2) TS_LAUNCH_FAST(true, 2); else if (np == 3) TS_LAUNCH_FAST(true, 3); else if (np == 4) TS_LAUNCH_FAST(true, 4); else TS_LAUNCH_FAST(true, 8); }
+    else { if (np <= 2) TS_LAUNCH_FAST(false, 2); else if (np <= 4) TS_LAUNCH_FAST(false, 4); else TS_LAUNCH_FAST(false, 8); }
+  } else {
+    if (vec) TS_LAUNCH_WIDE(true);
+    else TS_LAUNCH_WIDE(false);
+  }
+#undef TS_LAUNCH_FAST
+#undef TS_LAUNCH_WIDE
+  if (int rc = ts::launched("block_cost_main")) return rc;
+
+  if (scales > 1) {
+    const int nplanes = B * s.G * D;
+    const int gy = nplanes < 32768 ? nplanes : 32768;
+    const int gz = (nplanes + gy - 1) / gy;
+    const int Wl = 4 * s.nbx;
+    // largest row band whose separable intermediate fits 64 KiB of LDS
+    int rb = 16;
+    while (rb > 4 && static_cast<size_t>(rb / 2 + 2 + rb / 4 + 2) * Wl * sizeof(float) > 64 * 1024) rb /= 2;
+    const size_t ulds = static_cast<size_t>(rb / 2 + 2 + rb / 4 + 2) * Wl * sizeof(float);
+    TS_REQUIRE(ulds <= 64 * 1024, TS_ERR_UNSUPPORTED, "block_cost: W=%d too wide for the upsample stage", W);
+    const dim3 ugrid((H + rb - 1) / rb, gy, gz);
+#define TS_LAUNCH_UP(V, RBV) \
+  hipLaunchKernelGGL((block_cost_upsample<V, RBV>), ugrid, dim3(256), ulds, st, P1, P2, out, s)
+    if (vec) { if (rb == 16) TS_LAUNCH_UP(true, 16); else if (rb == 8) TS_LAUNCH_UP(true, 8); else TS_LAUNCH_UP(true, 4); }
+    else { if (rb == 16) TS_LAUNCH_UP(false, 16); else if (rb == 8) TS_LAUNCH_UP(false, 8); else TS_LAUNCH_UP(false, 4); }
+#undef TS_LAUNCH_UP
+    if (int rc = ts::launched("block_cost_upsample")) return rc;
+  }
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward.
+//   step 1  block_cost_upsample_adjoint: dP_l = U_l^T dOut(scale-l block)   (gather, deterministic)
+//   step 2  block_cost_bwd_main: same decomposition as the forward; each lane owns a 4x4 block of
+//           one candidate, recomputes the differences e = L - t, and pushes
+//             ge = dLoss/de = -2 e dG0 - 2 mean2x2(e) dP1/4 - 2 mean4x4(e) dP2/16  (- 2 e dCost, int path)
+//             gL += ge (+ dOut_L);  gt = -ge (+ dOut_T);  gR[x0], gR[x0+1] += w gt;
+//             gDisp -= gt (R[x0+1] - R[x0])            (zeros padding: out-of-row taps read as 0)
+//           with fp32 hardware atomics; gL/gR/gDisp are zero-filled by the host entry first.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+block_cost_upsample_adjoint(const float* __restrict__ dout, float* __restrict__ dP1, float* __restrict__ dP2,
+                            const Shape s) {
+  const long long n1 = static_cast<long long>(s.B) * s.G * s.D * s.H1 * s.W1;
+  const long long n2 = (s.scales > 2) ? static_cast<long long>(s.B) * s.G * s.D * s.H2 * s.W2 : 0;
+  const size_t HW = static_cast<size_t>(s.H) * s.W;
+  for (long long idx = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < n1 + n2;
+       idx += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int lvl = (idx < n1) ? 1 : 2;
+    long long t = (lvl == 1) ? idx : idx - n1;
+    const int Hs = (lvl == 1) ? s.H1 : s.H2, Ws = (lvl == 1) ? s.W1 : s.W2;
+    const float rh = (lvl == 1) ? s.rh1 : s.rh2, rw = (lvl == 1) ? s.rw1 : s.rw2;
+    const int px = static_cast<int>(t % Ws); t /= Ws;
+    const int py = static_cast<int>(t % Hs); t /= Hs;
+    const int d = static_cast<int>(t % s.D);
+    const long long bg = t / s.D;
+    const int g = static_cast<int>(bg % s.G), b = static_cast<int>(bg / s.G);
+    const float* plane = dout + ((static_cast<size_t>(b) * s.Ctot + s.mainC + lvl * s.G + g) * s.D + d) * HW;
+    int ylo = 0, yhi = s.H - 1, xlo = 0, xhi = s.W - 1;
+    if (rh > 0.f) {
+      ylo = max(0, static_cast<int>(floorf((py - 1) / rh)) - 1);
+      yhi = min(s.H - 1, static_cast<int>(ceilf((py + 1) / rh)) + 1);
+    }
+    if (rw > 0.f) {
+      xlo = max(0, static_cast<int>(floorf((px - 1) / rw)) - 1);
+      xhi = min(s.W - 1, static_cast<int>(ceilf((px + 1) / rw)) + 1);
+    }
+    float acc = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+      const float hr = rh * static_cast<float>(y);
+      const int h1 = static_cast<int>(hr);
+      const int hp = (h1 < Hs - 1) ? 1 : 0;
+      const float hl = hr - static_cast<float>(h1);
+      const float wy = (h1 == py ? 1.f - hl : 0.f) + (h1 + hp == py ? hl : 0.f);
+      if (wy == 0.f) continue;
+      float racc = 0.f;
+      for (int x = xlo; x <= xhi; ++x) {
+        const float wr = rw * static_cast<float>(x);
+        const int w1 = static_cast<int>(wr);
+        const int wp = (w1 < Ws - 1) ? 1 : 0;
+        const float wl = wr - static_cast<float>(w1);
+        const float wx = (w1 == px ? 1.f - wl : 0.f) + (w1 + wp == px ? wl : 0.f);
+        racc += wx * plane[static_cast<size_t>(y) * s.W + x];
+      }
+      acc += wy * racc;
+    }
+    if (lvl == 1) dP1[idx] = acc;
+    else dP2[idx - n1] = acc;
+  }
+}
+
+// source column (clamped to [-2, W+1]) and fraction of one output pixel
+template <bool SAMPLED>
+__device__ __forceinline__ void source_column(int x, int d, float dispv, int W, float Wm1, int& xi, float& f) {
+  if constexpr (SAMPLED) {
+    const float xs = static_cast<float>(x) + (-dispv);
+    const float gx = (xs / Wm1 * 2.f) - 1.f;
+    float ix = ((gx + 1.f) / 2.f) * Wm1;
+    ix = fminf(fmaxf(ix, -2.f), static_cast<float>(W) + 1.f);
+    const float fl = floorf(ix);
+    f = ix - fl;
+    xi = static_cast<int>(fl);
+  } else {
+    xi = x - d;
+    f = 0.f;
+  }
+}
+
+template <bool SAMPLED, bool VEC, bool STAGE>
+__global__ void __launch_bounds__(256)
+block_cost_bwd_main(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
+                    const float* __restrict__ dout, const float* __restrict__ dP1, const float* __restrict__ dP2,
+                    float* __restrict__ gL, float* __restrict__ gR, float* __restrict__ gD, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int by = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int y0 = by * TR;
+  const int H = s.H, W = s.W, D = s.D, C = s.C;
+  const size_t HW = static_cast<size_t>(H) * W;
+  const size_t goff = (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const float* Lg = L + goff;
+  const float* Rg = R + goff;
+  if constexpr (STAGE) stage_right_rows<VEC>(lds, Rg, y0, H, W, HW, s.Wq, s.Wqp);
+
+  const float Wm1 = static_cast<float>(W - 1);
+  const int nitems = s.nbx * D;
+  for (int item = threadIdx.x; item < nitems; item += blockDim.x) {
+    const int d = item / s.nbx;
+    const int bx = item - d * s.nbx;
+    const int x4 = bx * 4;
+    const float* dplane0 = dout + (static_cast<size_t>(b) * s.Ctot * D + d) * HW;
+    const size_t cstride = static_cast<size_t>(D) * HW;
+    const size_t pbase = ((static_cast<size_t>(b) * s.G + g) * D + d);
+
+    int xi[TR][4];
+    float fr[TR][4], dg0[TR][4], gdacc[TR][4];
+    float dp1[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float dp2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+      const int y = min(y0 + r, H - 1);
+      float dv[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (SAMPLED)
+        unpack(ld4<VEC>(disp + (static_cast<size_t>(b) * D + d) * HW + static_cast<size_t>(y) * W, x4, W), dv);
+      unpack(ld4<VEC>(dplane0 + static_cast<size_t>(s.mainC + g) * cstride + static_cast<size_t>(y) * W, x4, W), dg0[r]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        source_column<SAMPLED>(x4 + k, d, dv[k], W, Wm1, xi[r][k], fr[r][k]);
+        gdacc[r][k] = 0.f;
+      }
+    }
+    if (s.scales > 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int py = 2 * by + i, px = 2 * bx + j;
+          if (py < s.H1 && px < s.W1) dp1[i][j] = dP1[(pbase * s.H1 + py) * s.W1 + px];
+        }
+      if (s.scales > 2 && by < s.H2 && bx < s.W2) dp2 = dP2[(pbase * s.H2 + by) * s.W2 + bx];
+    }
+
+#pragma unroll 1
+    for (int c = 0; c < GRP; ++c) {
+      float e[TR][4], slope[TR][4];
+      float m1[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int r = 0; r < TR; ++r) {
+        const int y = y0 + r;
+        const bool rowok = y < H;
+        const size_t rowoff = static_cast<size_t>(min(y, H - 1)) * W;
+        float lv[4];
+        unpack(ld4<VEC>(Lg + c * HW + rowoff, x4, W), lv);
+        const float* src;
+        if constexpr (STAGE) src = lds + static_cast<size_t>(c * TR + r) * 4 * s.Wqp;
+        else src = Rg + c * HW + rowoff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int a = xi[r][k];
+          const int i0 = min(max(a, 0), W - 1), i1 = min(max(a + 1, 0), W - 1);
+          const int q0 = STAGE ? (i0 & 3) * s.Wqp + (i0 >> 2) : i0;
+          const int q1 = STAGE ? (i1 & 3) * s.Wqp + (i1 >> 2) : i1;
+          const float r0 = (a >= 0 && a < W) ? src[q0] : 0.f;
+          const float r1 = (SAMPLED && a + 1 >= 0 && a + 1 < W) ? src[q1] : 0.f;
+          const float t = (1.f - fr[r][k]) * r0 + fr[r][k] * r1;
+          const bool ok = rowok && (x4 + k < W);
+          e[r][k] = ok ? (lv[k] - t) : 0.f;
+          slope[r][k] = r1 - r0;
+        }
+        m1[r >> 1][0] += e[r][0] + e[r][1];
+        m1[r >> 1][1] += e[r][2] + e[r][3];
+      }
+      const float m2 = (m1[0][0] + m1[0][1] + m1[1][0] + m1[1][1]) * 0.0625f;
+      const size_t chan = static_cast<size_t>(g * GRP + c);
+#pragma unroll
+      for (int r = 0; r < TR; ++r) {
+        const int y = y0 + r;
+        if (y < H) {
+          const size_t rowoff = static_cast<size_t>(y) * W;
+          float dmain[4], dwarp[4] = {0.f, 0.f, 0.f, 0.f};
+          unpack(ld4<VEC>(dplane0 + chan * cstride + rowoff, x4, W), dmain);
+          if constexpr (SAMPLED) unpack(ld4<VEC>(dplane0 + (chan + C) * cstride + rowoff, x4, W), dwarp);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int x = x4 + k;
+            if (x < W) {
+              float ge = -2.f * e[r][k] * dg0[r][k];
+              ge -= 0.125f * m1[r >> 1][k >> 1] * dp1[r >> 1][k >> 1];   // 2 * (sum/4) / 4
+              ge -= 0.125f * m2 * dp2;                                    // 2 * mean / 16
+              float gl, gt;
+              if constexpr (SAMPLED) {
+                gl = ge + dmain[k];
+                gt = dwarp[k] - ge;
+              } else {
+                ge -= 2.f * e[r][k] * dmain[k];
+                gl = ge;
+                gt = -ge;
+              }
+              float* grow = gR + goff + c * HW + rowoff;
+              if (gL) unsafeAtomicAdd(gL + goff + c * HW + rowoff + x, gl);
+              const int a = xi[r][k];
+              if (gR) {
+                if (a >= 0 && a < W) unsafeAtomicAdd(grow + a, (1.f - fr[r][k]) * gt);
+                if (SAMPLED && a + 1 >= 0 && a + 1 < W) unsafeAtomicAdd(grow + a + 1, fr[r][k] * gt);
+              }
+              if constexpr (SAMPLED) gdacc[r][k] -= gt * slope[r][k];
+            }
+          }
+        }
+      }
+    }
+    if constexpr (SAMPLED) {
+      if (gD) {
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (y0 + r < H && x4 + k < W)
+              unsafeAtomicAdd(gD + (static_cast<size_t>(b) * D + d) * HW + static_cast<size_t>(y0 + r) * W + x4 + k,
+                              gdacc[r][k]);
+      }
+    }
+  }
+}
+
+template <bool SAMPLED>
+int launch_bwd(const float* left, const float* right, const float* disp, const float* grad_out,
+               float* grad_left, float* grad_right, float* grad_disp, void* workspace,
+               int B, int C, int H, int W, int D, int scales, void* stream) {
+  Shape s;
+  if (int rc = make_shape(s, SAMPLED, B, C, H, W, D, scales)) return rc;
+  TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(grad_out);
+  if (SAMPLED) TS_REQUIRE_PTR(disp);
+  if (scales > 1) TS_REQUIRE_PTR(workspace);
+  hipStream_t st = ts::as_stream(stream);
+  const size_t nfeat = static_cast<size_t>(B) * C * H * W * sizeof(float);
+  if (grad_left) if (hipError_t e = hipMemsetAsync(grad_left, 0, nfeat, st)) return ts::fail(e, "memset grad_left");
+  if (grad_right) if (hipError_t e = hipMemsetAsync(grad_right, 0, nfeat, st)) return ts::fail(e, "memset grad_right");
+  if (SAMPLED && grad_disp)
+    if (hipError_t e = hipMemsetAsync(grad_disp, 0, static_cast<size_t>(B) * D * H * W * sizeof(float), st))
+      return ts::fail(e, "memset grad_disp");
+
+  float* dP1 = reinterpret_cast<float*>(workspace);
+  float* dP2 = scales > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pooled_bytes(s, 1)) : nullptr;
+  if (scales > 1) {
+    const long long total = static_cast<long long>(B) * s.G * D * (static_cast<long long>(s.H1) * s.W1 + (scales > 2 ? s.H2 * s.W2 : 0));
+    long long blocks = (total + 255) / 256;
+    if (blocks > ts::kNumCU * 16) blocks = ts::kNumCU * 16;
+    hipLaunchKernelGGL(block_cost_upsample_adjoint, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
+                       grad_out, dP1, dP2, s);
+    if (int rc = ts::launched("block_cost_upsample_adjoint")) return rc;
+  }
+  const bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(grad_out) &&
+                   (!SAMPLED || ts::aligned16(disp));
+  const size_t lds_bytes = static_cast<size_t>(GRP) * TR * 4 * s.Wqp * sizeof(float);
+  const bool stage = lds_bytes <= 64 * 1024;
+  const int nitems = s.nbx * D;
+  const int passes = (nitems + 255) / 256;
+  int threads = static_cast<int>(ts::round_up(static_cast<size_t>((nitems + passes - 1) / passes), ts::kWave));
+  if (threads > 256) threads = 256;
+  const dim3 grid(s.nby, s.G, B);
+#define TS_LAUNCH_BWD(V, S)                                                                          \
+  hipLaunchKernelGGL((block_cost_bwd_main<SAMPLED, V, S>), grid, dim3(threads), (S) ? lds_bytes : 0, st, \
+                     left, right, disp, grad_out, dP1, dP2, grad_left, grad_right, grad_disp, s)
+  if (vec && stage) TS_LAUNCH_BWD(true, true);
+  else if (vec) TS_LAUNCH_BWD(true, false);
+  else if (stage) TS_LAUNCH_BWD(false, true);
+  else TS_LAUNCH_BWD(false, false);
+#undef TS_LAUNCH_BWD
+  return ts::launched("block_cost_bwd_main");
+}
+
+}  // namespace
+
+extern "C" size_t ts_block_cost_workspace_bytes(int B, int C, int H, int W, int D, int scales) {
+  Shape s;
+  if (make_shape(s, false, B, C, H, W, D, scales) != TS_OK) return 0;
+  if (scales < 2) return 256;
+  return pooled_bytes(s, 1) + pooled_bytes(s, 2);
+}
+
+extern "C" int ts_block_cost_int_fwd(const float* left, const float* right, float* out, void* workspace,
+                                     int B, int C, int H, int W, int D, int scales, void* stream) {
+  return launch_fwd<false>(left, right, nullptr, out, workspace, B, C, H, W, D, scales, stream);
+}
+
+extern "C" int ts_block_cost_sampled_fwd(const float* left, const float* right, const float* disp, float* out,
+                                         void* workspace, int B, int C, int H, int W, int D, int scales,
+                                         void* stream) {
+  return launch_fwd<true>(left, right, disp, out, workspace, B, C, H, W, D, scales, stream);
+}
+
+extern "C" size_t ts_block_cost_bwd_workspace_bytes(int B, int C, int H, int W, int D, int scales) {
+  return ts_block_cost_workspace_bytes(B, C, H, W, D, scales);
+}
+
+extern "C" int ts_block_cost_int_bwd(const float* left, const float* right, const float* grad_out,
+                                     float* grad_left, float* grad_right, void* workspace,
+                                     int B, int C, int H, int W, int D, int scales, void* stream) {
+  return launch_bwd<false>(left, right, nullptr, grad_out, grad_left, grad_right, nullptr, workspace,
+                           B, C, H, W, D, scales, stream);
+}
+
+extern "C" int ts_block_cost_sampled_bwd(const float* left, const float* right, const float* disp,
+                                         const float* grad_out, float* grad_left, float* grad_right,
+                                         float* grad_disp, void* workspace,
+                                         int B, int C, int H, int W, int D, int scales, void* stream) {
+  return launch_bwd<true>(left, right, disp, grad_out, grad_left, grad_right, grad_disp, workspace,
+                          B, C, H, W, D, scales, stream);
+}

@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Kernel-level timing of the hot-path ops at BASELINE config-2 sizes (GPU box only).
+
+usage: python tools/microbench.py [--iters N] [--batch B]
+Prints one line per op: mean time, algorithmic bytes, achieved GB/s, fraction of 8.0 / 6.29 TB/s.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import temporalstereo_amd as ts  # noqa: E402
+
+LEVELS = {  # name: (C, H, W, D, sampled)   -- SURVEY.md section 8(a) K1a/K1b, config 2
+    "coarse": (256, 34, 60, 12, False),
+    "fine": (128, 68, 120, 5, True),
+    "precise": (128, 136, 240, 5, True),
+}
+
+
+def alg_bytes(B, C, H, W, D, sampled):
+    # inputs once + output once, fp32
+    if sampled:
+        return 4 * B * H * W * (2 * C + D + (2 * C + 3 * C // 8) * D)
+    return 4 * B * H * W * (2 * C + (C + 3 * C // 8) * D)
+
+
+def time_op(fn, iters, warmup=20):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(iters):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / iters * 1e-3
+
+
+def calibrate(dev, nbytes, iters):
+    from temporalstereo_amd import _lib
+    L = _lib.lib()
+    a = torch.empty(nbytes // 4, device=dev); b = torch.ones(nbytes // 4, device=dev)
+    st = _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for kind, name, mult in ((0, "fill ", 1), (1, "copy ", 2), (2, "read ", 1)):
+        tsec = time_op(lambda: _lib.check(L.ts_calib_stream(kind, _lib.ptr(a), _lib.ptr(b), nbytes, st), "calib"), iters)
+        print("calib[%s] %7.1f MB  %8.1f us  %7.1f GB/s" % (name, nbytes / 1e6, tsec * 1e6, mult * nbytes / tsec / 1e9), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=1)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B = a.batch
+    tot_b, tot_t = 0, 0.0
+    for mb in (64, 200, 1024, 4096):
+        calibrate(dev, mb * 1000 * 1000 // 16 * 16, 50)
+    for name, (C, H, W, D, sampled) in LEVELS.items():
+        torch.manual_seed(0)
+        L = torch.randn(B, C, H, W, device=dev)
+        R = torch.randn(B, C, H, W, device=dev)
+        if sampled:   # piecewise-smooth candidates like the pyramid produces (base +- range), not white noise
+            yy = torch.linspace(0, 1, H, device=dev).view(1, 1, H, 1)
+            xx = torch.linspace(0, 1, W, device=dev).view(1, 1, 1, W)
+            base = 4.0 + 0.15 * W * (0.3 + 0.7 * yy) * (0.8 + 0.2 * torch.sin(6.28 * xx))
+            steps = torch.tensor([0., 3., 4., 5., 8.], device=dev)[:D].view(1, D, 1, 1)
+            disp = (base - 4.0 + steps + 0.05 * torch.rand(B, D, H, W, device=dev)).contiguous()
+        else:
+            disp = D
+        tsec = time_op(lambda: ts.block_cost(L, R, disp, 3), a.iters)
+        nb = alg_bytes(B, C, H, W, D, sampled)
+        tot_b += nb
+        tot_t += tsec
+        print("block_cost[%-7s] B=%d  %8.1f us  %7.1f MB  %7.1f GB/s  %.3f of 8.0TB/s  %.3f of 6.29TB/s" % (
+            name, B, tsec * 1e6, nb / 1e6, nb / tsec / 1e9, nb / tsec / 8.0e12, nb / tsec / 6.29e12), flush=True)
+    print("block_cost[total  ] B=%d  %8.1f us  %7.1f MB  %7.1f GB/s  %.3f of 8.0TB/s" % (
+        B, tot_t * 1e6, tot_b / 1e6, tot_b / tot_t / 1e9, tot_b / tot_t / 8.0e12))
+
+
+if __name__ == "__main__":
+    main()

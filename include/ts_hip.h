@@ -67,6 +67,59 @@ int ts_block_cost_sampled_bwd(const float* left, const float* right, const float
                               int B, int C, int H, int W, int D, int scales, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K4  disparity regression.  cost / sample / offset are [B,D,H,W].
+ * ts_topk_softargmax_*: predict_disp()  .../aggregation/TemporalStereo/coarse.py:69-75
+ *   (== fine.py:70-76, precise.py:61-67): top-k (1 <= k <= 8, ties: lowest index first) ->
+ *   softmax -> gather(sample+offset) -> weighted sum.  disp [B,1,H,W]; topk_* [B,k,H,W];
+ *   topk_index (int32, may be NULL in fwd) is what the backward needs.  Backward overwrites
+ *   grad_cost and grad_sample ([B,D,H,W]; grad of offset == grad of sample); any grad_* input may be NULL.
+ * ts_softargmin_*: SOFTARGMIN.forward  architecture/modeling/prediction/soft_argmin.py:38-59
+ * ts_argmax_select_fwd: ARGMIN.forward  architecture/modeling/prediction/argmin.py:35-46
+ * ---------------------------------------------------------------------------------------- */
+int ts_topk_softargmax_fwd(const float* cost, const float* sample, const float* offset, float* disp,
+                           float* topk_disp, float* topk_cost, int* topk_index,
+                           int B, int D, int H, int W, int k, void* stream);
+
+int ts_topk_softargmax_bwd(const float* topk_disp, const float* topk_cost, const int* topk_index,
+                           const float* disp, const float* grad_disp, const float* grad_topk_disp,
+                           const float* grad_topk_cost, float* grad_cost, float* grad_sample,
+                           int B, int D, int H, int W, int k, void* stream);
+
+int ts_softargmin_fwd(const float* cost, const float* sample, float* disp, float temperature,
+                      int normalize, int B, int D, int H, int W, void* stream);
+
+int ts_softargmin_bwd(const float* cost, const float* sample, const float* disp, const float* grad_disp,
+                      float* grad_cost, float* grad_sample, float temperature, int normalize,
+                      int B, int D, int H, int W, void* stream);
+
+int ts_argmax_select_fwd(const float* cost, const float* sample, float* disp, int* index,
+                         int B, int D, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  temporal cost warp.
+ * ts_softsplat_sum_*: the three kernels of architecture/modeling/layers/softsplat.py:8-177
+ *   (updateOutput :14-52, updateGradInput :63-105, updateGradFlow :116-176); input/output [B,C,H,W],
+ *   flow [B,2,H,W] (x then y).  fwd zero-fills `output` itself.  fp32 atomics: order not deterministic.
+ * ts_softsplat_softmax_fwd: FunctionSoftsplat(..., 'softmax')  softsplat.py:334-360 fused for the
+ *   detached use in update_map (projects/TemporalStereo/TemporalStereo.py:415-419): metric [B,1,H,W].
+ * ts_project_to_3d_fwd: project_to_3d()  architecture/modeling/layers/inverse_warp.py:92-178;
+ *   depth [B,C,H,W], K [B,k,k] (k = 3|4), inv_K [B,ik,ik], T [B,4,4] -> triangular_depth [B,C,H,W],
+ *   optical_flow [B,2C,H,W], flow_mask [B,C,H,W] (uint8); any output may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+int ts_softsplat_sum_fwd(const float* input, const float* flow, float* output,
+                         int B, int C, int H, int W, void* stream);
+int ts_softsplat_sum_bwd_input(const float* flow, const float* grad_output, float* grad_input,
+                               int B, int C, int H, int W, void* stream);
+int ts_softsplat_sum_bwd_flow(const float* input, const float* flow, const float* grad_output,
+                              float* grad_flow, int B, int C, int H, int W, void* stream);
+size_t ts_softsplat_softmax_workspace_bytes(int B, int C, int H, int W);
+int ts_softsplat_softmax_fwd(const float* input, const float* flow, const float* metric, float* output,
+                             void* workspace, int B, int C, int H, int W, void* stream);
+int ts_project_to_3d_fwd(const float* depth, const float* K, const float* inv_K, const float* T,
+                         float* triangular_depth, float* optical_flow, unsigned char* flow_mask,
+                         int B, int C, int H, int W, int k_dim, int inv_k_dim, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement support (no reference counterpart): float4 streams used by bench.py to calibrate
  * what this box sustains.  kind 0 = fill dst (write-only), 1 = copy src->dst, 2 = read src
  * (dst = 4-byte sink).  nbytes % 16 == 0.

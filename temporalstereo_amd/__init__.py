@@ -7,4 +7,5 @@ mirror the reference's interfaces.  See DESIGN.md / INTEGRATION.md.
 """
 __version__ = "0.1.0"
 
-from .functional import block_cost  # noqa: F401
+from .functional import (block_cost, topk_softargmax, soft_argmin, argmin_select,  # noqa: F401
+                         FunctionSoftsplat, project_to_3d)

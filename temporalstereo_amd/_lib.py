@@ -30,6 +30,17 @@ SIGNATURES = {
     "ts_block_cost_int_bwd": (c_int, [c_f32p] * 5 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_bwd": (c_int, [c_f32p] * 7 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_calib_stream": (c_int, [c_int, c_ptr, c_ptr, c_size, c_ptr]),
+    "ts_topk_softargmax_fwd": (c_int, [c_f32p] * 7 + [c_int] * 5 + [c_ptr]),
+    "ts_topk_softargmax_bwd": (c_int, [c_f32p] * 9 + [c_int] * 5 + [c_ptr]),
+    "ts_softargmin_fwd": (c_int, [c_f32p] * 3 + [c_float, c_int] + [c_int] * 4 + [c_ptr]),
+    "ts_softargmin_bwd": (c_int, [c_f32p] * 6 + [c_float, c_int] + [c_int] * 4 + [c_ptr]),
+    "ts_argmax_select_fwd": (c_int, [c_f32p] * 4 + [c_int] * 4 + [c_ptr]),
+    "ts_softsplat_sum_fwd": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_ptr]),
+    "ts_softsplat_sum_bwd_input": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_ptr]),
+    "ts_softsplat_sum_bwd_flow": (c_int, [c_f32p] * 4 + [c_int] * 4 + [c_ptr]),
+    "ts_softsplat_softmax_workspace_bytes": (c_size, [c_int] * 4),
+    "ts_softsplat_softmax_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 4 + [c_ptr]),
+    "ts_project_to_3d_fwd": (c_int, [c_f32p] * 7 + [c_int] * 6 + [c_float, c_ptr]),
 }
 
 

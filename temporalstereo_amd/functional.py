@@ -96,3 +96,204 @@ def block_cost(reference_fm, target_fm, disp_sample, block_cost_scale=3):
     if isinstance(disp_sample, int):
         return _BlockCost.apply(reference_fm, target_fm, None, disp_sample, scales)
     return _BlockCost.apply(reference_fm, target_fm, disp_sample, 0, scales)
+
+
+# --------------------------------------------------------------------------------------------- K4
+class _TopkSoftArgmax(torch.autograd.Function):
+    """K4a.  ts_topk_softargmax_{fwd,bwd}; returns (disp, topk_disp, topk_cost)."""
+
+    @staticmethod
+    def forward(ctx, cost, sample, offset, k):
+        _require_gpu(cost, sample, offset)
+        if cost.dim() != 4 or cost.shape != sample.shape or cost.shape != offset.shape:
+            raise ValueError("cost, disp_sample and off must be [B,D,H,W] of equal shape")
+        cost, sample, offset = cost.contiguous(), sample.contiguous(), offset.contiguous()
+        B, D, H, W = cost.shape
+        disp = torch.empty((B, 1, H, W), device=cost.device, dtype=torch.float32)
+        tdisp = torch.empty((B, k, H, W), device=cost.device, dtype=torch.float32)
+        tcost = torch.empty_like(tdisp)
+        tidx = torch.empty((B, k, H, W), device=cost.device, dtype=torch.int32)
+        rc = _lib.lib().ts_topk_softargmax_fwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(offset), _lib.ptr(disp),
+                                               _lib.ptr(tdisp), _lib.ptr(tcost), _lib.ptr(tidx), B, D, H, W, int(k),
+                                               _stream())
+        _lib.check(rc, "ts_topk_softargmax_fwd")
+        ctx.save_for_backward(tdisp, tcost, tidx, disp)
+        ctx.meta = (B, D, H, W, int(k))
+        return disp, tdisp, tcost
+
+    @staticmethod
+    def backward(ctx, g_disp, g_tdisp, g_tcost):
+        tdisp, tcost, tidx, disp = ctx.saved_tensors
+        B, D, H, W, k = ctx.meta
+        need_cost = ctx.needs_input_grad[0]
+        need_samp = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gcost = torch.empty((B, D, H, W), device=disp.device, dtype=torch.float32) if need_cost else None
+        gsamp = torch.empty((B, D, H, W), device=disp.device, dtype=torch.float32) if need_samp else None
+        c = lambda t: None if t is None else t.contiguous()
+        rc = _lib.lib().ts_topk_softargmax_bwd(_lib.ptr(tdisp), _lib.ptr(tcost), _lib.ptr(tidx), _lib.ptr(disp),
+                                               _lib.ptr(c(g_disp)), _lib.ptr(c(g_tdisp)), _lib.ptr(c(g_tcost)),
+                                               _lib.ptr(gcost), _lib.ptr(gsamp), B, D, H, W, k, _stream())
+        _lib.check(rc, "ts_topk_softargmax_bwd")
+        return (gcost, gsamp if ctx.needs_input_grad[1] else None,
+                gsamp if ctx.needs_input_grad[2] else None, None)
+
+
+def topk_softargmax(cost, disp_sample, off, k=2):
+    """predict_disp() of the reference levels (coarse.py:69-75): (disp_map, topk_disp, topk_cost)."""
+    return _TopkSoftArgmax.apply(cost, disp_sample, off, int(k))
+
+
+class _SoftArgmin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, sample, temperature, normalize):
+        _require_gpu(cost, sample)
+        cost, sample = cost.contiguous(), sample.contiguous()
+        B, D, H, W = cost.shape
+        disp = torch.empty((B, 1, H, W), device=cost.device, dtype=torch.float32)
+        rc = _lib.lib().ts_softargmin_fwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(disp), float(temperature),
+                                          int(bool(normalize)), B, D, H, W, _stream())
+        _lib.check(rc, "ts_softargmin_fwd")
+        ctx.save_for_backward(cost, sample, disp)
+        ctx.meta = (B, D, H, W, float(temperature), int(bool(normalize)))
+        return disp
+
+    @staticmethod
+    def backward(ctx, g):
+        cost, sample, disp = ctx.saved_tensors
+        B, D, H, W, temperature, normalize = ctx.meta
+        gc = torch.empty_like(cost) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(sample) if ctx.needs_input_grad[1] else None
+        rc = _lib.lib().ts_softargmin_bwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(disp), _lib.ptr(g.contiguous()),
+                                          _lib.ptr(gc), _lib.ptr(gs), temperature, normalize, B, D, H, W, _stream())
+        _lib.check(rc, "ts_softargmin_bwd")
+        return gc, gs, None, None
+
+
+def soft_argmin(cost_volume, disp_sample, temperature=1.0, normalize=True):
+    """SOFTARGMIN.forward (prediction/soft_argmin.py:38-59)."""
+    if cost_volume.dim() != 4:
+        raise ValueError('expected 4D input (got {}D input)'.format(cost_volume.dim()))
+    if cost_volume.shape != disp_sample.shape:
+        raise ValueError('The shape of disparity samples and cost volume should be consistent!')
+    return _SoftArgmin.apply(cost_volume, disp_sample, temperature, normalize)
+
+
+class _ArgmaxSelect(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, sample):
+        _require_gpu(cost, sample)
+        cost, sample = cost.contiguous(), sample.contiguous()
+        B, D, H, W = cost.shape
+        disp = torch.empty((B, 1, H, W), device=cost.device, dtype=torch.float32)
+        idx = torch.empty((B, 1, H, W), device=cost.device, dtype=torch.int32)
+        rc = _lib.lib().ts_argmax_select_fwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(disp), _lib.ptr(idx),
+                                             B, D, H, W, _stream())
+        _lib.check(rc, "ts_argmax_select_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = sample.shape
+        return disp
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gs = torch.zeros(ctx.shape, device=g.device, dtype=g.dtype)
+        gs.scatter_(1, idx.long(), g)          # index plumbing only; one element per pixel
+        return None, gs
+
+
+def argmin_select(cost_volume, disp_sample):
+    """ARGMIN.forward (prediction/argmin.py:35-46): gather the sample of the best (max) cost."""
+    if cost_volume.shape != disp_sample.shape:
+        raise ValueError("{}, {}".format(cost_volume.shape, disp_sample.shape))
+    return _ArgmaxSelect.apply(cost_volume, disp_sample)
+
+
+# --------------------------------------------------------------------------------------------- K2
+class _SplatSum(torch.autograd.Function):
+    """_FunctionSoftsplat of the reference (softsplat.py:239-332) on ts_softsplat_sum_*."""
+
+    @staticmethod
+    def forward(ctx, inp, flow):
+        _require_gpu(inp, flow)
+        if flow.shape[1] != 2 or inp.shape[0] != flow.shape[0] or inp.shape[2:] != flow.shape[2:]:
+            raise ValueError("flow must be [B,2,H,W] matching the input")
+        inp, flow = inp.contiguous(), flow.contiguous()
+        B, C, H, W = inp.shape
+        out = torch.empty_like(inp)
+        _lib.check(_lib.lib().ts_softsplat_sum_fwd(_lib.ptr(inp), _lib.ptr(flow), _lib.ptr(out), B, C, H, W, _stream()),
+                   "ts_softsplat_sum_fwd")
+        ctx.save_for_backward(inp, flow)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        inp, flow = ctx.saved_tensors
+        B, C, H, W = inp.shape
+        g = g.contiguous()
+        gi = gf = None
+        if ctx.needs_input_grad[0]:
+            gi = torch.empty_like(inp)
+            _lib.check(_lib.lib().ts_softsplat_sum_bwd_input(_lib.ptr(flow), _lib.ptr(g), _lib.ptr(gi), B, C, H, W,
+                                                             _stream()), "ts_softsplat_sum_bwd_input")
+        if ctx.needs_input_grad[1]:
+            gf = torch.empty_like(flow)
+            _lib.check(_lib.lib().ts_softsplat_sum_bwd_flow(_lib.ptr(inp), _lib.ptr(flow), _lib.ptr(g), _lib.ptr(gf),
+                                                            B, C, H, W, _stream()), "ts_softsplat_sum_bwd_flow")
+        return gi, gf
+
+
+def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
+    """Forward splatting, same signature as the reference's FunctionSoftsplat (softsplat.py:334-360).
+
+    'softmax' on inputs that do not require grad (the only use in update_map) runs the fused kernel
+    ts_softsplat_softmax_fwd; every other case composes the summation splat (with HIP backward)."""
+    if tenMetric is not None and tenMetric.shape[1] != 1:
+        raise ValueError("tenMetric must have one channel")
+    if strType not in ('summation', 'average', 'linear', 'softmax'):
+        raise ValueError("unknown splatting type %r" % (strType,))
+    grad_needed = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (tenInput, tenFlow, tenMetric))
+    if strType == 'softmax' and not grad_needed:
+        _require_gpu(tenInput, tenFlow, tenMetric)
+        inp, flow, met = tenInput.contiguous(), tenFlow.contiguous(), tenMetric.contiguous()
+        B, C, H, W = inp.shape
+        L = _lib.lib()
+        out = torch.empty_like(inp)
+        ws = torch.empty(int(L.ts_softsplat_softmax_workspace_bytes(B, C, H, W)), device=inp.device, dtype=torch.uint8)
+        _lib.check(L.ts_softsplat_softmax_fwd(_lib.ptr(inp), _lib.ptr(flow), _lib.ptr(met), _lib.ptr(out), _lib.ptr(ws),
+                                              B, C, H, W, _stream()), "ts_softsplat_softmax_fwd")
+        return out
+    x = tenInput
+    if strType == 'average':
+        x = torch.cat([x, x.new_ones(x.shape[0], 1, x.shape[2], x.shape[3])], 1)
+    elif strType == 'linear':
+        x = torch.cat([x * tenMetric, tenMetric], 1)
+    elif strType == 'softmax':
+        e = tenMetric.exp()
+        x = torch.cat([x * e, e], 1)
+    out = _SplatSum.apply(x, tenFlow)
+    if strType != 'summation':
+        out = out[:, :-1, :, :] / (out[:, -1:, :, :] + 1e-22)
+    return out
+
+
+def project_to_3d(depth, K, inv_K=None, T_target_to_source=None, eps=1e-7):
+    """project_to_3d of the reference (layers/inverse_warp.py:92-178), forward only (the project
+    calls it on detached tensors).  Returns triangular_depth / optical_flow / flow_mask /
+    src_pixel_coord; homo_points_3d is not produced (no caller on the hot path reads it)."""
+    if T_target_to_source is None:
+        raise NotImplementedError("the hot path always passes T_target_to_source")
+    _require_gpu(depth, K, T_target_to_source)
+    if inv_K is None:
+        inv_K = torch.inverse(K[:, :3, :3])
+    depth = depth.contiguous()
+    K, inv_K, T = K.contiguous(), inv_K.contiguous(), T_target_to_source.contiguous()
+    B, C, H, W = depth.shape
+    tri = torch.empty_like(depth)
+    flow = torch.empty((B, 2 * C, H, W), device=depth.device, dtype=torch.float32)
+    mask = torch.empty((B, C, H, W), device=depth.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().ts_project_to_3d_fwd(_lib.ptr(depth), _lib.ptr(K), _lib.ptr(inv_K), _lib.ptr(T), _lib.ptr(tri),
+                                               _lib.ptr(flow), _lib.ptr(mask), B, C, H, W, K.shape[-1], inv_K.shape[-1],
+                                               float(eps), _stream()), "ts_project_to_3d_fwd")
+    out = {'triangular_depth': tri, 'optical_flow': flow, 'flow_mask': mask.bool()}
+    return out

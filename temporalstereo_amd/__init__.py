@@ -9,3 +9,8 @@ __version__ = "0.1.0"
 
 from .functional import (block_cost, topk_softargmax, soft_argmin, argmin_select,  # noqa: F401
                          FunctionSoftsplat, project_to_3d)
+from .registry import (AGGREGATION_REGISTRY, PREDICTION_REGISTRY, build_aggregation, build_prediction,  # noqa: F401
+                       CfgView, register_into)
+from .aggregation import (TEMPORALSTEREO, CoarseAggregation, FineAggregation, PreciseAggregation)  # noqa: F401
+from .prediction import SOFTARGMIN, ARGMIN  # noqa: F401
+from . import temporal  # noqa: F401

@@ -1,0 +1,124 @@
+"""conv -> norm -> activation wrappers with the reference's constructor contract and state-dict
+names (architecture/modeling/layers/basic_layers.py:10-103,151-235,289-388): `Conv3d(*conv_args,
+norm=(name, channels) | module | None, activation=str | (str, coeff) | module | None)`; parameters
+live at `<name>.weight/.bias` and `<name>.norm.*`.
+
+Training keeps torch's convolution + BatchNorm (batch statistics / SyncBN collectives cannot be
+folded).  The eval-mode HIP execution of these layers happens one level up, in
+aggregation.engine, which folds the BatchNorm and fuses the activation into the conv kernels.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_NORMS = {
+    "BN1d": nn.BatchNorm1d, "BN": nn.BatchNorm2d, "BN3d": nn.BatchNorm3d,
+    "IN1d": nn.InstanceNorm1d, "IN": nn.InstanceNorm2d, "IN3d": nn.InstanceNorm3d,
+    "SyncBN": nn.SyncBatchNorm, "nnSyncBN": nn.SyncBatchNorm,
+    "GN": lambda c: nn.GroupNorm(32, c),
+}
+_ACTS = {
+    "ReLU": lambda a: nn.ReLU(inplace=True),
+    "LeakyReLU": lambda a: nn.LeakyReLU(negative_slope=0.1 if a is None else a, inplace=True),
+    "ELU": lambda a: nn.ELU(alpha=1.0 if a is None else a, inplace=True),
+    "SELU": lambda a: nn.SELU(inplace=True),
+    "SiLU": lambda a: nn.SiLU(inplace=True),
+    "Hardswish": lambda a: nn.Hardswish(inplace=True),
+    "Mish": lambda a: nn.Mish(inplace=True),
+}
+
+
+def get_norm(norm, out_channels):
+    """basic_layers.py:10-39."""
+    if norm is None or (isinstance(norm, str) and not norm):
+        return None
+    if isinstance(norm, str):
+        if norm not in _NORMS:
+            raise KeyError("unknown norm '%s'" % norm)
+        return _NORMS[norm](out_channels)
+    return norm(out_channels)
+
+
+def get_activation(activation, coeff=None):
+    """basic_layers.py:42-73."""
+    if activation is None or (isinstance(activation, str) and not activation):
+        return None
+    if isinstance(activation, str):
+        if activation not in _ACTS:
+            raise KeyError("unknown activation '%s'" % activation)
+        return _ACTS[activation](coeff)
+    return activation
+
+
+def _split_kwargs(kwargs):
+    """basic_layers.py:76-103: pops `norm` / `activation` and builds the modules."""
+    norm = kwargs.pop("norm", None)
+    if isinstance(norm, (tuple, list)):
+        if len(norm) != 2:
+            raise ValueError("norm must be (name, channels)")
+        norm = get_norm(*norm)
+    act = kwargs.pop("activation", None)
+    if isinstance(act, (tuple, list)):
+        if len(act) not in (1, 2):
+            raise ValueError("activation must be name | (name,) | (name, coeff)")
+        act = get_activation(act[0], act[1] if len(act) == 2 else None)
+    elif isinstance(act, str):
+        act = get_activation(act)
+    return norm, act, kwargs
+
+
+class _NormAct:
+    def _finish(self, x):
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+class Conv2d(nn.Conv2d, _NormAct):
+    def __init__(self, *args, **kwargs):
+        norm, act, kwargs = _split_kwargs(kwargs)
+        super().__init__(*args, **kwargs)
+        self.norm, self.activation = norm, act
+
+    def forward(self, x):
+        return self._finish(F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups))
+
+
+class Conv3d(nn.Conv3d, _NormAct):
+    def __init__(self, *args, **kwargs):
+        norm, act, kwargs = _split_kwargs(kwargs)
+        super().__init__(*args, **kwargs)
+        self.norm, self.activation = norm, act
+
+    def forward(self, x):
+        return self._finish(F.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups))
+
+
+class ConvTranspose2d(nn.ConvTranspose2d, _NormAct):
+    def __init__(self, *args, **kwargs):
+        norm, act, kwargs = _split_kwargs(kwargs)
+        super().__init__(*args, **kwargs)
+        self.norm, self.activation = norm, act
+
+    def forward(self, x, output_size=None):
+        if self.padding_mode != 'zeros':
+            raise ValueError('Only `zeros` padding mode is supported for ConvTranspose2d')
+        op = self._output_padding(x, output_size, self.stride, self.padding, self.kernel_size, 2, self.dilation)
+        return self._finish(F.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, op,
+                                               self.groups, self.dilation))
+
+
+class ConvTranspose3d(nn.ConvTranspose3d, _NormAct):
+    def __init__(self, *args, **kwargs):
+        norm, act, kwargs = _split_kwargs(kwargs)
+        super().__init__(*args, **kwargs)
+        self.norm, self.activation = norm, act
+
+    def forward(self, x, output_size=None):
+        if self.padding_mode != 'zeros':
+            raise ValueError('Only `zeros` padding mode is supported for ConvTranspose3d')
+        op = self._output_padding(x, output_size, self.stride, self.padding, self.kernel_size, 3, self.dilation)
+        return self._finish(F.conv_transpose3d(x, self.weight, self.bias, self.stride, self.padding, op,
+                                               self.groups, self.dilation))

@@ -33,8 +33,14 @@ def shapes_tag(dims):
     return "%dx%dx%d" % (dims['coarse']['C'], dims['fine']['C'], dims['precise']['C'])
 
 
-def synth_state(dims, seed, device="cpu"):
+def synth_state(dims, seed, device="cpu", golden=None):
+    """Synthetic weights; BatchNorm running statistics come from the fixture when it carries the
+    calibrated ones (keys 'bn::<name>', see tools/gen_golden.py)."""
     vals = synth.state_values(state_shapes(shapes_tag(dims)), seed)
+    if golden is not None:
+        for k, v in golden.items():
+            if k.startswith("bn::"):
+                vals[k[4:]] = v
     return {k: t(v, device) for k, v in vals.items()}
 
 

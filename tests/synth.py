@@ -2,8 +2,8 @@
 and the tests / bench (product side).  Pure numpy `RandomState` (frozen legacy stream) so the
 same seed gives the same bytes on every machine; nothing is read from /root/reference.
 
-Shapes follow SURVEY.md section 8(d): features ~ N(0,1) at 1/4, 1/8, 1/16 of the run
-resolution, images ~ N(0,1), weights by the reference initialiser's distribution
+Shapes follow SURVEY.md section 8(d): unit-variance, spatially smooth features at 1/4, 1/8, 1/16 of
+the run resolution (low-passed N(0,1), see `smooth`), images likewise, weights by the reference initialiser's distribution
 (normal(0, sqrt(2/(k*Cout))), coarse.py:52-67) and BatchNorm buffers randomised so that
 folding is exercised.
 """
@@ -26,6 +26,23 @@ def uniform(seed, tag, shape, lo=0.0, hi=1.0):
     return _rs(seed, tag).uniform(lo, hi, size=shape).astype(np.float32)
 
 
+def smooth(a, passes=2):
+    """Separable binomial [1,4,6,4,1]/16 low-pass along the last two axes (edge-replicated), applied
+    `passes` times and rescaled to unit variance: CNN feature maps are spatially smooth; white noise
+    would make every sub-pixel resampling maximally ill-conditioned (d feature / d disparity ~ 1.4)."""
+    k = np.array([1, 4, 6, 4, 1], dtype=np.float64) / 16.0
+    x = a.astype(np.float64)
+    for _ in range(passes):
+        for ax in (-2, -1):
+            pad = [(0, 0)] * x.ndim
+            pad[ax] = (2, 2)
+            xp = np.pad(x, pad, mode="edge")
+            n = x.shape[ax]
+            x = sum(k[i] * np.take(xp, np.arange(i, i + n), axis=ax) for i in range(5))
+    x = x / x.std()
+    return x.astype(np.float32)
+
+
 def feature_pyramid(seed, B, H, W, chans=(64, 128, 256), correlated=True, max_shift=6.0):
     """[f4, f8, f16] left and right pyramids for a run resolution H x W (both multiples of 16).
 
@@ -35,7 +52,7 @@ def feature_pyramid(seed, B, H, W, chans=(64, 128, 256), correlated=True, max_sh
     lefts, rights = [], []
     for lvl, (c, s) in enumerate(zip(chans, (4, 8, 16))):
         h, w = H // s, W // s
-        L = normal(seed, "L%d" % lvl, (B, c, h, w))
+        L = smooth(normal(seed, "L%d" % lvl, (B, c, h, w)))
         if correlated:
             ys = np.linspace(0, 1, h, dtype=np.float32).reshape(1, 1, h, 1)
             xs = np.arange(w, dtype=np.float32).reshape(1, 1, 1, w)
@@ -47,16 +64,16 @@ def feature_pyramid(seed, B, H, W, chans=(64, 128, 256), correlated=True, max_sh
             x0b = np.broadcast_to(x0c, L.shape)
             x1b = np.broadcast_to(x1c, L.shape)
             R = (1 - fr) * np.take_along_axis(L, x0b, axis=3) + fr * np.take_along_axis(L, x1b, axis=3)
-            R = (R + 0.1 * normal(seed, "Rn%d" % lvl, L.shape)).astype(np.float32)
+            R = (R + 0.1 * smooth(normal(seed, "Rn%d" % lvl, L.shape))).astype(np.float32)
         else:
-            R = normal(seed, "R%d" % lvl, (B, c, h, w))
+            R = smooth(normal(seed, "R%d" % lvl, (B, c, h, w)))
         lefts.append(L)
         rights.append(R)
     return lefts, rights
 
 
 def images(seed, B, H, W):
-    return normal(seed, "imgL", (B, 3, H, W)), normal(seed, "imgR", (B, 3, H, W))
+    return smooth(normal(seed, "imgL", (B, 3, H, W)), 3), smooth(normal(seed, "imgR", (B, 3, H, W)), 3)
 
 
 def state_values(shapes, seed):

@@ -178,7 +178,6 @@ def synthetic_prev_info(seed, B, H, W, local_maps=2):
 def aggregator_case(name, dims, seed, B, H, W, temporal, store_inputs, training=False):
     net = build_reference_aggregator(dims)
     load_synth_weights(net, seed)
-    net.train(training)
     chans = (dims['precise']['in_planes'], dims['fine']['in_planes'], dims['coarse']['in_planes'])
     lf, rf = synth.feature_pyramid(seed, B, H, W, chans=chans)
     il, ir = synth.images(seed, B, H, W)
@@ -189,6 +188,21 @@ def aggregator_case(name, dims, seed, B, H, W, temporal, store_inputs, training=
         prev = {'cost_memory': {'disp_sample': T(ds), 'cost_volume': T(cv)}, 'use_past_cost': True,
                 'local_map': T(lm), 'local_map_size': lm.shape[1]}
         extra.update(mem_disp_sample=ds, mem_cost_volume=cv, local_map=lm)
+    bn_stats = {}
+    if not training:
+        # give the synthetic network BatchNorm statistics that match its activations (as a trained
+        # network has): one calibration pass in train mode with momentum 1, then eval.
+        bns = [m for m in net.modules() if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))]
+        for m in bns:
+            m.momentum = 1.0
+        net.train(True)
+        with torch.no_grad():
+            net([T(x) for x in lf], [T(x) for x in rf], T(il), T(ir), dict(prev))
+        for m in bns:
+            m.momentum = 0.1
+        bn_stats = {"bn::" + k: v.clone() for k, v in net.state_dict().items()
+                    if k.endswith("running_mean") or k.endswith("running_var")}
+    net.train(training)
     with torch.no_grad(), Recorder() as rec:
         disps, costs, samples, offs, ranges, info = net([T(x) for x in lf], [T(x) for x in rf], T(il), T(ir), prev)
     arrs = dict(seed=seed, B=B, H=H, W=W, temporal=int(temporal), training=int(training),
@@ -196,6 +210,7 @@ def aggregator_case(name, dims, seed, B, H, W, temporal, store_inputs, training=
                                dims['fine']['in_planes'], dims['fine']['C'],
                                dims['precise']['in_planes'], dims['precise']['C']]))
     arrs.update(extra)
+    arrs.update(bn_stats)
     if store_inputs:     # cross-check that synth regenerates the same bytes on the test side
         arrs.update(l16_probe=lf[2][:, :2], r16_probe=rf[2][:, :2])
         for i, nm in enumerate(("full", "precise", "fine_up", "coarse_up")):

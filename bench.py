@@ -1,0 +1,304 @@
+#!/usr/bin/env python
+"""Headline benchmark: stereo pairs/s of the cost-volume aggregation hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode module|engine]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (coarse -> fine -> precise aggregation: cost-volume build,
+3-D aggregation pyramid, top-k soft-argmax regression, upsamplers) over one batch of synthetic
+FlyingThings3D-shaped inputs already resident in HBM: BASELINE.json configs[1] = 540x960 run at
+544x960 (as the reference does, sceneflow.yaml:84-85), D=192 (COARSE.NUM_SAMPLE=12), single frame,
+batch 1 per GPU, fp32, eval mode.  Ranks are independent replicas (stereo pairs shard with no
+data-path collective): value = pairs all ranks processed / max-over-ranks time ("weak" scaling).
+
+Prints ONE JSON line (rank 0) with the extra objects
+  roofline     cost-volume build at the 1/4 level (the dominant K1 launch): algorithmic bytes
+                / its mean duration measured with HIP events on the launch
+               stream inside the timed region, against the 8.0 TB/s HBM peak
+  cpu_baseline the CPU oracle (oracle/, a port of the reference's torch CPU path) timed on this
+               box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import synth  # noqa: E402  (deterministic synthetic inputs, shared with the tests)
+
+RUN_H, RUN_W = 544, 960            # 540x960 resized to a multiple of 16 (datasets/base.py:176-185)
+MAX_DISP = 192
+HBM_PEAK = 8.0e12                  # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+DIMS = dict(coarse=dict(in_planes=256, C=32, num_sample=MAX_DISP // 16), fine=dict(in_planes=128, C=16),
+            precise=dict(in_planes=64, C=8))
+
+
+def k1_algorithmic_bytes(B, C, H, W, D, sampled):
+    """inputs once + output once, fp32."""
+    if sampled:
+        return 4 * B * H * W * (2 * C + D + (2 * C + 3 * C // 8) * D)
+    return 4 * B * H * W * (2 * C + (C + 3 * C // 8) * D)
+
+
+def build_model(dev, seed):
+    import temporalstereo_amd as ts
+    net = ts.TEMPORALSTEREO(
+        coarse=ts.CoarseAggregation(DIMS['coarse']['in_planes'], DIMS['coarse']['C'], DIMS['coarse']['num_sample']),
+        fine=ts.FineAggregation(DIMS['fine']['in_planes'], DIMS['fine']['C'], 5),
+        precise=ts.PreciseAggregation(DIMS['precise']['in_planes'], DIMS['precise']['C'], 5))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    vals = synth.state_values(shapes, seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()}, strict=True)
+    return net.to(dev)
+
+
+def make_inputs(dev, seed, B):
+    chans = (DIMS['precise']['in_planes'], DIMS['fine']['in_planes'], DIMS['coarse']['in_planes'])
+    lf, rf = synth.feature_pyramid(seed, B, RUN_H, RUN_W, chans=chans)
+    il, ir = synth.images(seed, B, RUN_H, RUN_W)
+    to = lambda a: torch.from_numpy(a).to(dev)
+    return [to(x) for x in lf], [to(x) for x in rf], to(il), to(ir)
+
+
+def calibrate_batchnorm(net, inputs):
+    """One train-mode pass with momentum 1: running statistics := this input's batch statistics, so
+    the random-weight network is conditioned like a trained one (same protocol as tools/gen_golden.py)."""
+    bns = [m for m in net.modules() if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))]
+    for m in bns:
+        m.momentum = 1.0
+    net.train(True)
+    with torch.no_grad():
+        net(*inputs, {})
+    for m in bns:
+        m.momentum = 0.1
+    net.train(False)
+
+
+class K1Probe:
+    """HIP events (torch.cuda.Event on the launch stream) bracketing exactly the K1 C-ABI call.
+
+    Capture phase: during the timed steps it only remembers the arguments of each distinct K1 call.
+    Measure phase: after the timed steps the same calls are replayed back-to-back (the queue stays
+    full, so the events see kernel time, not host launch gaps) with one event pair per call."""
+
+    def __init__(self):
+        from temporalstereo_amd import functional as TF
+        self.TF = TF
+        self.calls = {}            # key -> (left, right, disp_or_int, scales)
+        self.records = []
+        self.timing = False
+
+    def __enter__(self):
+        self.TF._k1_probe = self._probe
+        self._orig = self.TF.block_cost
+
+        def remember(reference_fm, target_fm, disp_sample, block_cost_scale=3):
+            B, C, H, W = reference_fm.shape
+            sampled = not isinstance(disp_sample, int)
+            key = (B, C, H, W, disp_sample.shape[1] if sampled else disp_sample, sampled)
+            if key not in self.calls:
+                self.calls[key] = (reference_fm.detach(), target_fm.detach(),
+                                   disp_sample.detach() if sampled else disp_sample, block_cost_scale)
+            return self._orig(reference_fm, target_fm, disp_sample, block_cost_scale)
+        from temporalstereo_amd.aggregation import levels
+        self._levels = levels
+        levels.TF.block_cost = remember
+        return self
+
+    def __exit__(self, *exc):
+        self.TF._k1_probe = None
+        self._levels.TF.block_cost = self._orig
+
+    def _probe(self, key, launch):
+        if not self.timing:
+            return launch()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = launch()
+        e.record()
+        self.records.append((key, s, e))
+        return rc
+
+    def measure(self, iters):
+        self.timing = True
+        with torch.no_grad():
+            for key, (l, r, d, sc) in self.calls.items():
+                for _ in range(3):
+                    self._orig(l, r, d, sc)
+                self.records = [rec for rec in self.records if rec[0] != key]
+                for _ in range(iters):
+                    self._orig(l, r, d, sc)
+        torch.cuda.synchronize()
+        self.timing = False
+        per = {}
+        for key, s, e in self.records:
+            per.setdefault(key, []).append(s.elapsed_time(e) * 1e-3)
+        return {k: float(np.mean(v)) for k, v in per.items()}
+
+
+def cpu_baseline(seed, budget_s=20.0):
+    """The oracle aggregation (torch CPU ops, all host cores) on the same config-2 inputs."""
+    from oracle import aggregation as oagg
+    import temporalstereo_amd as ts
+    net = ts.TEMPORALSTEREO(
+        coarse=ts.CoarseAggregation(DIMS['coarse']['in_planes'], DIMS['coarse']['C'], DIMS['coarse']['num_sample']),
+        fine=ts.FineAggregation(DIMS['fine']['in_planes'], DIMS['fine']['C'], 5),
+        precise=ts.PreciseAggregation(DIMS['precise']['in_planes'], DIMS['precise']['C'], 5))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_values(shapes, seed).items()}
+    # more threads than ~16 only adds oversubscription on these small tensors (256-thread runs of this
+    # workload measured 76 s/pass on the GPU box's host); the count used is reported as `cores`
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    lf, rf, il, ir = make_inputs(torch.device("cpu"), seed, 1)
+    cfg = dict(coarse=dict(num_sample=DIMS['coarse']['num_sample']))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out = oagg.aggregate(sd, lf, rf, il, ir, {}, cfg=cfg)        # warm-up (also the parity reference)
+        first = time.perf_counter() - t0
+        n, t_acc = 0, 0.0
+        while t_acc < budget_s and n < 10:
+            t0 = time.perf_counter()
+            oagg.aggregate(sd, lf, rf, il, ir, {}, cfg=cfg)
+            t_acc += time.perf_counter() - t0
+            n += 1
+    return dict(value=n / t_acc, unit="pairs/s", cores=cores, kind="port",
+                sample="%d forward passes of the config-2 aggregation (544x960, D=192, B=1) through oracle/ "
+                       "(torch %s CPU kernels, %d threads; first pass %.2fs excluded)" % (n, torch.__version__, cores, first)), out, sd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (config 2: 1)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "module", "engine"],
+                    help="module: nn.Module forward; engine: fused HIP inference engine (+hipGraph)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    seed = synth.SEED0 + 2                      # config index 2
+    net = build_model(dev, seed)
+    inputs = make_inputs(dev, seed + rank, a.batch)
+    calibrate_batchnorm(net, inputs)
+
+    runner, mode = None, a.mode
+    if mode in ("auto", "engine"):
+        try:
+            from temporalstereo_amd.aggregation.engine import InferenceEngine
+            runner = InferenceEngine(net)
+            mode = "engine"
+        except ImportError:
+            if mode == "engine":
+                raise
+            mode = "module"
+
+    def step():
+        with torch.no_grad():
+            if runner is not None:
+                return runner(*inputs, {})
+            return net(*inputs, {})
+
+    with K1Probe() as k1:
+        for _ in range(a.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        k1_times = k1.measure(max(a.steps, 20)) if rank == 0 else {}
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    result = None
+    if rank == 0:
+        pairs = world * a.batch * a.steps
+        # dominant cost-volume launch: the 1/4-resolution (precise) sampled build
+        pkey = (a.batch, 2 * DIMS['precise']['in_planes'], RUN_H // 4, RUN_W // 4, 5, True)
+        roofline = None
+        if pkey in k1_times:
+            nbytes = k1_algorithmic_bytes(*pkey)
+            ach = nbytes / k1_times[pkey]
+            all_b = sum(k1_algorithmic_bytes(*k) for k in k1_times)
+            all_t = sum(k1_times.values())
+            roofline = dict(bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
+                            traffic=None,
+                            measured="HIP events on the launch stream around the C-ABI call, %d back-to-back "
+                                     "launches on the pipeline's own tensors right after the timed steps" % max(a.steps, 20),
+                            kernel="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample) on "
+                                   "[%d,%d,%d,%d] x %d candidates" % pkey[:5],
+                            algorithmic_bytes=nbytes, mean_us=k1_times[pkey] * 1e6,
+                            frac_of_measured_copy_ceiling=ach / 6.29e12,
+                            all_levels=dict(algorithmic_bytes=all_b, mean_us=all_t * 1e6,
+                                            achieved=all_b / all_t / 1e9, frac=all_b / all_t / HBM_PEAK))
+        result = dict(metric="stereo pairs/sec, FlyingThings3D 540x960 D=192 (aggregation hot path)",
+                      value=pairs / elapsed, unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                      ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling="weak",
+                      vs_baseline=None, dtype="f32", data="synthetic",
+                      config=dict(workload="BASELINE configs[1]: FlyingThings3D 540x960 (run 544x960) D=192 "
+                                           "single-frame aggregation, batch %d/GPU, eval" % a.batch,
+                                  run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
+                                  parallelism="replicas x%d" % world, exec_mode=mode),
+                      roofline=roofline)
+        if world == 1 and not a.no_cpu_baseline:
+            base, ref_out, _ = cpu_baseline(seed)
+            # parity on the very same inputs: needs the calibrated BN statistics on the oracle side too
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            from oracle import aggregation as oagg
+            lf, rf, il, ir = make_inputs(torch.device("cpu"), seed, a.batch)
+            with torch.no_grad():
+                ref = oagg.aggregate(sd, lf, rf, il, ir, {}, cfg=dict(coarse=dict(num_sample=DIMS['coarse']['num_sample'])))
+            full, rfull = out[0][0].detach().cpu().double(), ref[0][0].double()
+            # no ground truth exists for synthetic inputs: gt* = reference output + N(0,1) clipped to
+            # (0, MAX_DISP); EPE = mean |d - gt| (data/evaluation/pixel_error.py:33-63)
+            gen = torch.Generator().manual_seed(seed)
+            gt = (rfull + torch.randn(rfull.shape, generator=gen, dtype=torch.float64)).clamp(0, MAX_DISP)
+            result["cpu_baseline"] = base
+            result["parity"] = dict(delta_epe_px=abs(float((full - gt).abs().mean()) - float((rfull - gt).abs().mean())),
+                                    mean_abs_diff_px=float((full - rfull).abs().mean()),
+                                    max_abs_diff_px=float((full - rfull).abs().max()),
+                                    frac_pixels_off_by_0p01=float(((full - rfull).abs() > 0.01).double().mean()),
+                                    tolerance_px=1e-3, reference="oracle/ (CPU port pinned to the reference's golden vectors)")
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

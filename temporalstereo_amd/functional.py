@@ -13,6 +13,11 @@ def _stream():
     return _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Measurement hook (bench.py): when set, called as probe(key, launch) around the K1 C-ABI call so
+# that HIP events can bracket exactly the library's launches on the launch stream.
+_k1_probe = None
+
+
 def _require_gpu(*tensors):
     for t in tensors:
         if t is None:
@@ -51,12 +56,13 @@ class _BlockCost(torch.autograd.Function):
         out = torch.empty((B, ctot, D, H, W), device=left.device, dtype=torch.float32)
         ws = torch.empty(max(int(L.ts_block_cost_workspace_bytes(B, C, H, W, D, scales)), 256),
                          device=left.device, dtype=torch.uint8)
-        if sampled:
-            rc = L.ts_block_cost_sampled_fwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(disp), _lib.ptr(out),
-                                             _lib.ptr(ws), B, C, H, W, D, scales, _stream())
-        else:
-            rc = L.ts_block_cost_int_fwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(out), _lib.ptr(ws),
-                                         B, C, H, W, D, scales, _stream())
+        def launch():
+            if sampled:
+                return L.ts_block_cost_sampled_fwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(disp), _lib.ptr(out),
+                                                   _lib.ptr(ws), B, C, H, W, D, scales, _stream())
+            return L.ts_block_cost_int_fwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(out), _lib.ptr(ws),
+                                           B, C, H, W, D, scales, _stream())
+        rc = launch() if _k1_probe is None else _k1_probe((B, C, H, W, D, sampled), launch)
         _lib.check(rc, "ts_block_cost_%s_fwd" % ("sampled" if sampled else "int"))
         ctx.save_for_backward(left, right, disp if sampled else None)
         ctx.meta = (B, C, H, W, D, scales, sampled)

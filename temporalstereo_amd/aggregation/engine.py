@@ -1,0 +1,93 @@
+"""Inference engine of the aggregation hot path: one hipGraph per input signature.
+
+The reference runs its forward eagerly (~300 framework ops per pair, SURVEY.md section 7 "tiny
+problem sizes": launch gaps dominate at batch 1).  Here the whole coarse -> fine -> precise pass is
+captured ONCE into a HIP graph (torch.cuda.CUDAGraph is hipGraph on ROCm; our C-ABI launches go to
+the capturing stream like any other kernel) and replayed per frame: no Python, no allocator, no
+per-op launch latency on the critical path.  BatchNorm is in eval mode, so the captured kernels are
+the folded/fused inference variants.
+
+Static-buffer contract: inputs are copied into graph-owned buffers, outputs are graph-owned
+tensors that the next call overwrites (clone what must outlive the next frame).  The temporal state
+`prev_info` is part of the signature: a graph is built per (shapes, which state entries exist).
+"""
+import torch
+
+
+def _sig_of(obj):
+    if torch.is_tensor(obj):
+        return ("T",) + tuple(obj.shape)
+    if isinstance(obj, dict):
+        return ("D",) + tuple((k, _sig_of(obj[k])) for k in sorted(obj, key=str))
+    if isinstance(obj, (list, tuple)):
+        return ("L",) + tuple(_sig_of(o) for o in obj)
+    return ("V", obj)
+
+
+def _clone_static(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().clone().contiguous()
+    if isinstance(obj, dict):
+        return {k: _clone_static(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_clone_static(o) for o in obj)
+    return obj
+
+
+def _copy_into(dst, src):
+    if torch.is_tensor(dst):
+        if dst.data_ptr() != src.data_ptr():
+            dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_into(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s in zip(dst, src):
+            _copy_into(d, s)
+
+
+class _Captured:
+    def __init__(self, graph, static_in, static_out):
+        self.graph, self.static_in, self.static_out = graph, static_in, static_out
+
+
+class InferenceEngine:
+    """`engine(left_feats, right_feats, left_image, right_image, prev_info)` -> same tuple as
+    TEMPORALSTEREO.forward, executed as a hipGraph replay."""
+
+    def __init__(self, net, warmup=3):
+        if any(p.device.type != "cuda" for p in net.parameters()):
+            raise RuntimeError("InferenceEngine needs the module on the GPU (there is no CPU path)")
+        self.net = net.eval()
+        self.warmup = warmup
+        self._graphs = {}
+
+    def _capture(self, args):
+        static_in = _clone_static(args)
+        # eager warm-up on a side stream: MIOpen solver selection, lazy inits, allocator growth
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):
+                self.net(static_in[0], static_in[1], static_in[2], static_in[3], dict(static_in[4]))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            out = self.net(static_in[0], static_in[1], static_in[2], static_in[3], dict(static_in[4]))
+        return _Captured(graph, static_in, out)
+
+    def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):
+        state = {k: v for k, v in prev_info.items()
+                 if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}
+        args = (list(left_feats), list(right_feats), left_image, right_image, state)
+        sig = _sig_of(args)
+        cap = self._graphs.get(sig)
+        if cap is None:
+            cap = self._graphs[sig] = self._capture(args)
+        _copy_into(cap.static_in, args)
+        cap.graph.replay()
+        disps, costs, samples, offs, ranges, info = cap.static_out
+        out_info = dict(prev_info)
+        out_info.update(info)
+        return disps, costs, samples, offs, ranges, out_info

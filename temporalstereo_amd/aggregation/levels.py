@@ -46,9 +46,10 @@ def _init3d(cost_planes, C, norm, activation):
 
 def _candidates_in_range(low, high):
     """fine.py:82-87 / precise.py:73-78: five candidates at {0,3,4,5,8}/8 of the search range."""
-    steps = torch.tensor([0., 3., 4., 5., 8.], device=low.device, dtype=low.dtype)
-    steps = (steps / steps.max()).view(1, 5, 1, 1)
-    return torch.abs(high - low) * steps + torch.min(low, high)
+    span, base = torch.abs(high - low), torch.min(low, high)
+    # {0,3,4,5,8}/8 are exact in fp32, so span * s + base equals the reference's broadcast form; no
+    # host-built tensor is involved (keeps the pass capturable into a hipGraph)
+    return torch.cat([span * s + base for s in (0.0, 0.375, 0.5, 0.625, 1.0)], dim=1)
 
 
 class _Level(nn.Module):

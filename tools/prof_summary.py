@@ -1,21 +1,37 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 results .db (kernel trace) as a per-kernel table (name, calls, avg/min/max us)."""
+"""Summarise a rocprofv3 results .db (kernel trace) as a per-kernel table.
+
+usage: prof_summary.py results.db [top] [--window-ms A B]   (window relative to the LAST kernel end,
+       e.g. --window-ms 60 20 keeps kernels that started between 60 and 20 ms before the end)
+"""
 import sqlite3
 import sys
 
 
-def main(path, top=25):
+def main(path, top=25, window=None):
     db = sqlite3.connect(path)
+    where = ""
+    if window:
+        tend = db.execute("select max(end) from kernels").fetchone()[0]
+        where = " where start >= %d and start <= %d" % (tend - int(window[0] * 1e6), tend - int(window[1] * 1e6))
     rows = list(db.execute(
         "select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start), "
-        "max(vgpr_count), max(lds_size), max(workgroup_x), max(grid_x) from kernels group by name "
-        "order by sum(end-start) desc limit %d" % top))
+        "max(vgpr_count), max(lds_size), max(workgroup_x), max(grid_x) from kernels" + where + " group by name "
+        "order by sum(end-start) desc"))
     tot = sum(r[5] for r in rows) or 1
+    span = db.execute("select min(start), max(end), count(*) from kernels" + where).fetchone()
+    print("kernels: %d dispatches, %d distinct, busy %.3f ms over a %.3f ms span" % (span[2], len(rows), tot / 1e6, (span[1] - span[0]) / 1e6))
     print("%-72s %6s %9s %9s %9s %6s %5s %7s %5s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct", "vgpr", "lds", "wg"))
-    for r in rows:
+    for r in rows[:top]:
         print("%-72s %6d %9.1f %9.1f %9.1f %6.1f %5d %7d %5d" % (r[0][:72], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3,
                                                              100.0 * r[5] / tot, r[6], r[7], r[8]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 25)
+    args = sys.argv[1:]
+    window = None
+    if "--window-ms" in args:
+        i = args.index("--window-ms")
+        window = (float(args[i + 1]), float(args[i + 2]))
+        args = args[:i] + args[i + 3:]
+    main(args[0], int(args[1]) if len(args) > 1 else 25, window)

@@ -120,6 +120,58 @@ int ts_project_to_3d_fwd(const float* depth, const float* K, const float* inv_K,
                          int B, int C, int H, int W, int k_dim, int inv_k_dim, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K3  3-D aggregation pyramid, inference form (BatchNorm folded into per-channel scale/shift,
+ * activation fused: act 0 none, 1 SiLU, 2 ReLU, 3 tanh(x/100).clamp(-1,1)*act_param).
+ * Tensors may be channel slices of larger buffers: *_bstride / *_cstride are element strides of
+ * the batch and channel axes.  Weights are pre-laid out by the host with the output channel
+ * contiguous and zero-padded to ts_conv_cout_pad(Cout): [Cin][taps][CoutPad]; scale/shift [CoutPad].
+ * ts_conv3d_hw_fwd: Conv3d (1,3,3) / ConvTranspose3d (1,3,3) of DepthwiseConv3D /
+ *   DepthwiseConvTranspose3D (.../TemporalStereo/module.py:111-184) through the Conv3d wrappers
+ *   (layers/basic_layers.py:194-235,340-388); also every 3x3 Conv2d (D = 1).
+ * ts_conv3d_d_fwd: the (k,1,1) halves, Conv3d(5,1,1) of PyramidFusion (:408), Conv3d(3,1,1) of
+ *   PredictionHeads (:369-378), 1x1 convolutions (k = 1).
+ * ---------------------------------------------------------------------------------------- */
+int ts_conv_cout_pad(int cout);
+int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                     int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
+                     int transposed, int act, float act_param,
+                     long long in_bstride, long long in_cstride, long long out_bstride,
+                     long long out_cstride, void* stream);
+int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                    int B, int Cin, int Cout, int Din, int H, int W, int k, int stride, int dilation,
+                    int padding, int transposed, int act, float act_param,
+                    long long in_bstride, long long in_cstride, long long out_bstride,
+                    long long out_cstride, void* stream);
+/* ResidualBlock3D up-steps: out = act(trilinear_align_corners(a -> (D,H,W)) + add)  module.py:285-295 */
+int ts_resize3d_add_act_fwd(const float* a, const float* add, float* out, int B, int C, int Da, int Ha, int Wa,
+                            int D, int H, int W, int act, long long a_bstride, long long a_cstride,
+                            long long add_bstride, long long add_cstride, long long out_bstride,
+                            long long out_cstride, void* stream);
+/* PyramidFusion pooling branch: avg_pool3d + max_pool3d, kernel 5, stride 1, padding 2  module.py:415-417 */
+int ts_pool3d5_avgmax_fwd(const float* x, float* out_avg, float* out_max, int B, int C, int D, int H, int W,
+                          long long x_bstride, long long x_cstride, long long avg_bstride, long long avg_cstride,
+                          long long max_bstride, long long max_cstride, void* stream);
+/* temporal merge: past_conv(1->C)+BN+SiLU on the K memory costs, cat along D, stable sort of the
+ * D0+K candidates, gather of the volume  coarse.py:84-105 / fine.py:105-122.  sample NULL = 0..D0-1;
+ * mem_sample / mem_cost NULL = zeros. */
+int ts_merge_candidates_fwd(const float* volume, const float* sample, const float* mem_sample, const float* mem_cost,
+                            const float* past_w, const float* past_scale, const float* past_shift,
+                            float* out_sample, float* out_volume, int B, int C, int D0, int K, int H, int W,
+                            long long vol_bstride, long long vol_cstride, long long out_bstride,
+                            long long out_cstride, void* stream);
+/* K5 upsamplers: ConvexUpsample.forward module.py:336-353 (mask [B,9*f*f,H,W]); UNet.upsample :468-482
+ * (mask [B,9,Ho,Wo]); ConvTranspose2d(4, stride 2, padding 1) of UNet :453-457 (w_t [Cin][4][4][CoutPad],
+ * CoutPad = 16 or 32); bilinear align_corners resize with a value scale. */
+int ts_convex_upsample_fwd(const float* mask, const float* disp, float* out, int B, int H, int W, int factor,
+                           float disp_scale, void* stream);
+int ts_unet_upsample_fwd(const float* mask, const float* disp, float* out, int B, int h, int w, int Ho, int Wo,
+                         void* stream);
+int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                         int B, int Cin, int Cout, int H, int W, int act, long long out_bstride, void* stream);
+int ts_resize_bilinear_fwd(const float* x, float* out, int BC, int h, int w, int Ho, int Wo, float value_scale,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement support (no reference counterpart): float4 streams used by bench.py to calibrate
  * what this box sustains.  kind 0 = fill dst (write-only), 1 = copy src->dst, 2 = read src
  * (dst = 4-byte sink).  nbytes % 16 == 0.

@@ -40,6 +40,16 @@ SIGNATURES = {
     "ts_softsplat_sum_bwd_flow": (c_int, [c_f32p] * 4 + [c_int] * 4 + [c_ptr]),
     "ts_softsplat_softmax_workspace_bytes": (c_size, [c_int] * 4),
     "ts_softsplat_softmax_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 4 + [c_ptr]),
+    "ts_conv_cout_pad": (c_int, [c_int]),
+    "ts_conv3d_hw_fwd": (c_int, [c_f32p] * 5 + [c_int] * 10 + [c_float] + [ctypes.c_longlong] * 4 + [c_ptr]),
+    "ts_conv3d_d_fwd": (c_int, [c_f32p] * 5 + [c_int] * 12 + [c_float] + [ctypes.c_longlong] * 4 + [c_ptr]),
+    "ts_resize3d_add_act_fwd": (c_int, [c_f32p] * 3 + [c_int] * 9 + [ctypes.c_longlong] * 6 + [c_ptr]),
+    "ts_pool3d5_avgmax_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [ctypes.c_longlong] * 6 + [c_ptr]),
+    "ts_merge_candidates_fwd": (c_int, [c_f32p] * 9 + [c_int] * 6 + [ctypes.c_longlong] * 4 + [c_ptr]),
+    "ts_convex_upsample_fwd": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_float, c_ptr]),
+    "ts_unet_upsample_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [c_ptr]),
+    "ts_deconv2d_k4s2_fwd": (c_int, [c_f32p] * 5 + [c_int] * 6 + [ctypes.c_longlong, c_ptr]),
+    "ts_resize_bilinear_fwd": (c_int, [c_f32p] * 2 + [c_int] * 5 + [c_float, c_ptr]),
     "ts_project_to_3d_fwd": (c_int, [c_f32p] * 7 + [c_int] * 6 + [c_float, c_ptr]),
 }
 

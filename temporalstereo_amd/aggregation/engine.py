@@ -55,10 +55,21 @@ class InferenceEngine:
     """`engine(left_feats, right_feats, left_image, right_image, prev_info)` -> same tuple as
     TEMPORALSTEREO.forward, executed as a hipGraph replay."""
 
-    def __init__(self, net, warmup=3):
+    def __init__(self, net, warmup=3, backend="native", graph=True):
+        """backend 'native': every stage on libts_hip.so kernels (aggregation.native);
+        backend 'module': the nn.Module forward (torch/MIOpen convolutions + HIP K1/K4).
+        graph=False runs the backend directly (no hipGraph)."""
         if any(p.device.type != "cuda" for p in net.parameters()):
             raise RuntimeError("InferenceEngine needs the module on the GPU (there is no CPU path)")
-        self.net = net.eval()
+        net = net.eval()
+        if backend == "native":
+            from .native import NativeAggregator
+            self.net = NativeAggregator(net)
+        elif backend == "module":
+            self.net = net
+        else:
+            raise ValueError("backend must be 'native' or 'module'")
+        self.backend, self.use_graph = backend, graph
         self.warmup = warmup
         self._graphs = {}
 
@@ -81,6 +92,9 @@ class InferenceEngine:
         state = {k: v for k, v in prev_info.items()
                  if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}
         args = (list(left_feats), list(right_feats), left_image, right_image, state)
+        if not self.use_graph:
+            with torch.no_grad():
+                return self.net(args[0], args[1], args[2], args[3], dict(prev_info))
         sig = _sig_of(args)
         cap = self._graphs.get(sig)
         if cap is None:

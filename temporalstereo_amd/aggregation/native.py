@@ -1,0 +1,386 @@
+"""Native inference path of the aggregation pyramid: every stage on the HIP kernels of libts_hip.so.
+
+`NativeAggregator(net)` takes a TEMPORALSTEREO module (eval mode), folds each conv's BatchNorm and
+bias into a per-channel (scale, shift), re-lays the weights out for the kernels ([Cin][taps][Cout],
+output channel contiguous so one scalar load feeds a whole tap) and then runs the same graph as
+aggregation/levels.py with NO framework op on the data path:
+
+  cost volume      ts_block_cost_*                (K1)
+  separable convs  ts_conv3d_hw_fwd / ts_conv3d_d_fwd (+ transposed), BN + activation fused   (K3a/b)
+  hourglass skips  ts_resize3d_add_act_fwd        (trilinear resize + add + SiLU)            (K3b)
+  temporal merge   ts_merge_candidates_fwd        (past_conv + cat + stable sort + gather)   (K3c)
+  pyramid fusion   ts_pool3d5_avgmax_fwd + channel-sliced outputs instead of torch.cat       (K3d)
+  heads            conv kernels with the tanh-offset epilogue                               (K3e)
+  regression       ts_topk_softargmax_fwd         (K4a)
+  upsamplers       ts_convex_upsample_fwd / ts_unet_upsample_fwd / ts_deconv2d_k4s2_fwd      (K5)
+
+Semantics are those of the reference modules in eval mode (citations in levels.py / blocks.py).
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .. import functional as TF
+
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_TANH_OFFSET = 0, 1, 2, 3
+
+
+def _stream():
+    return _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _act_code(mod):
+    if mod is None:
+        return ACT_NONE
+    if isinstance(mod, nn.SiLU):
+        return ACT_SILU
+    if isinstance(mod, nn.ReLU):
+        return ACT_RELU
+    raise NotImplementedError("activation %r has no fused kernel epilogue" % (mod,))
+
+
+class Folded:
+    """Kernel-ready form of one conv (+BatchNorm (+activation))."""
+
+    def __init__(self, weight, bias, bn, act, transposed, kind):
+        w = weight.detach().float()
+        if transposed:                      # ConvTranspose: [Cin, Cout, ...] -> [Cout, Cin, ...]
+            w = w.transpose(0, 1)
+        cout, cin = w.shape[0], w.shape[1]
+        taps = w.shape[2:].numel()
+        self.cin, self.cout, self.kind, self.act = cin, cout, kind, act
+        self.kshape = tuple(w.shape[2:])
+        pad = 16 if (kind == "deconv2d" and cout <= 16) else (32 if kind == "deconv2d" else int(_lib.lib().ts_conv_cout_pad(cout)))
+        if pad < cout:
+            raise NotImplementedError("Cout=%d has no kernel bucket" % cout)
+        wt = torch.zeros(cin, taps, pad, device=w.device, dtype=torch.float32)
+        wt[:, :, :cout] = w.reshape(cout, cin, taps).permute(1, 2, 0)
+        self.w = wt.contiguous()
+        scale = torch.ones(pad, device=w.device)
+        shift = torch.zeros(pad, device=w.device)
+        b = bias.detach().float() if bias is not None else torch.zeros(cout, device=w.device)
+        if bn is not None:
+            if not isinstance(bn, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                raise NotImplementedError("only BatchNorm can be folded, got %r" % (bn,))
+            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            scale[:cout] = s
+            shift[:cout] = bn.bias.detach().float() + (b - bn.running_mean.detach().float()) * s
+        else:
+            shift[:cout] = b
+        self.scale, self.shift = scale.contiguous(), shift.contiguous()
+
+
+def fold_wrapper(m, kind, transposed=False):
+    """Conv3d / Conv2d / ConvTranspose wrappers of layers.py (conv -> .norm -> .activation)."""
+    return Folded(m.weight, m.bias, getattr(m, "norm", None), _act_code(getattr(m, "activation", None)), transposed, kind)
+
+
+# ------------------------------------------------------------------------------------------- ops
+def _strides5(t):
+    if t.stride(4) != 1 or t.stride(3) != t.shape[4] or t.stride(2) != t.shape[3] * t.shape[4]:
+        raise ValueError("tensor planes must be dense (channel-sliced views of contiguous buffers are fine)")
+    return t.stride(0), t.stride(1)
+
+
+def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0):
+    """x [B,Cin,D,H,W] -> [B,Cout,D,Ho,Wo]."""
+    B, Cin, D, H, W = x.shape
+    assert Cin == f.cin, (Cin, f.cin)
+    if transposed:
+        Ho, Wo = 2 * H, 2 * W
+    else:
+        Ho = (H + 2 * dilation - 2 * dilation - 1) // stride + 1
+        Wo = (W + 2 * dilation - 2 * dilation - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, f.cout, D, Ho, Wo), device=x.device, dtype=torch.float32)
+    ib, ic = _strides5(x)
+    ob, oc = _strides5(out)
+    rc = _lib.lib().ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
+                                     B, Cin, f.cout, D, H, W, stride, dilation, int(transposed),
+                                     f.act if act is None else act, float(act_param), ib, ic, ob, oc, _stream())
+    _lib.check(rc, "ts_conv3d_hw_fwd")
+    return out
+
+
+def conv_d(x, f, k, stride=1, dilation=1, padding=0, transposed=False, out=None, act=None, act_param=0.0):
+    """x [B,Cin,Din,H,W] -> [B,Cout,Dout,H,W]."""
+    B, Cin, Din, H, W = x.shape
+    assert Cin == f.cin, (Cin, f.cin)
+    Dout = 2 * Din if transposed else (Din + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, f.cout, Dout, H, W), device=x.device, dtype=torch.float32)
+    ib, ic = _strides5(x)
+    ob, oc = _strides5(out)
+    rc = _lib.lib().ts_conv3d_d_fwd(_lib.ptr(x), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
+                                    B, Cin, f.cout, Din, H, W, k, stride, dilation, padding, int(transposed),
+                                    f.act if act is None else act, float(act_param), ib, ic, ob, oc, _stream())
+    _lib.check(rc, "ts_conv3d_d_fwd")
+    return out
+
+
+def resize_add_act(a, add, size, act=ACT_SILU):
+    B, C, Da, Ha, Wa = a.shape
+    D, H, W = size
+    out = torch.empty((B, C, D, H, W), device=a.device, dtype=torch.float32)
+    ab, ac = _strides5(a)
+    bb, bc = _strides5(add) if add is not None else (0, 0)
+    ob, oc = _strides5(out)
+    rc = _lib.lib().ts_resize3d_add_act_fwd(_lib.ptr(a), _lib.ptr(add), _lib.ptr(out), B, C, Da, Ha, Wa, D, H, W, act,
+                                            ab, ac, bb, bc, ob, oc, _stream())
+    _lib.check(rc, "ts_resize3d_add_act_fwd")
+    return out
+
+
+def pool5(x, out_avg, out_max):
+    B, C, D, H, W = x.shape
+    xb, xc = _strides5(x); ab, ac = _strides5(out_avg); mb, mc = _strides5(out_max)
+    rc = _lib.lib().ts_pool3d5_avgmax_fwd(_lib.ptr(x), _lib.ptr(out_avg), _lib.ptr(out_max), B, C, D, H, W,
+                                          xb, xc, ab, ac, mb, mc, _stream())
+    _lib.check(rc, "ts_pool3d5_avgmax_fwd")
+
+
+def resize_bilinear(x, size, value_scale=1.0):
+    B, C, h, w = x.shape
+    out = torch.empty((B, C, size[0], size[1]), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().ts_resize_bilinear_fwd(_lib.ptr(x.contiguous()), _lib.ptr(out), B * C, h, w, size[0], size[1],
+                                           float(value_scale), _stream())
+    _lib.check(rc, "ts_resize_bilinear_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- blocks
+class SepConv:
+    """DepthwiseConv3D / DepthwiseConvTranspose3D (blocks.py) in kernel-ready form."""
+
+    def __init__(self, mod, transposed=False):
+        c0, c1 = mod.conv[0], mod.conv[1]
+        self.transposed = transposed
+        self.f0 = fold_wrapper(c0, "hw", transposed)
+        self.f1 = fold_wrapper(c1, "d", transposed)
+        self.k = c1.kernel_size[0]
+        self.stride, self.dil = c0.stride[1], c0.dilation[1]
+        self.pad_d = c1.padding[0]
+        if c0.kernel_size != (1, 3, 3) or c0.padding[1] != self.dil or c1.stride[0] != self.stride:
+            raise NotImplementedError("separable conv outside the (1,3,3)+(k,1,1) family: %r" % (mod,))
+
+    def __call__(self, x, out=None):
+        y = conv_hw(x, self.f0, self.stride, self.dil, self.transposed)
+        return conv_d(y, self.f1, self.k, self.stride, self.dil, self.pad_d, self.transposed, out=out)
+
+
+class Hourglass:
+    """ResidualBlock3D.forward (module.py:272-297)."""
+
+    def __init__(self, mod):
+        self.c1, self.c2, self.c3, self.c4 = (SepConv(getattr(mod, n)) for n in ("conv1", "conv2", "conv3", "conv4"))
+        self.c5, self.c6 = SepConv(mod.conv5, True), SepConv(mod.conv6, True)
+        self.s5, self.s6 = SepConv(mod.shortcut5), SepConv(mod.shortcut6)
+        # conv4 has no activation of its own; the SiLU that follows it (:281) is fused into its last kernel
+        self.c4.f1.act = ACT_SILU
+
+    def __call__(self, x):
+        pre = self.c2(self.c1(x))
+        out = self.c4(self.c3(pre))
+        out = resize_add_act(self.c5(out), self.s5(pre), pre.shape[-3:])
+        return resize_add_act(self.c6(out), self.s6(x), x.shape[-3:])
+
+
+class Heads:
+    """PredictionHeads (module.py:356-398): (cost, off) [B,D,H,W]."""
+
+    def __init__(self, mod):
+        self.delta = float(mod.delta)
+        self.c0, self.c1 = fold_wrapper(mod.cost_head[0], "d"), fold_wrapper(mod.cost_head[1], "hw")
+        self.o0, self.o1 = fold_wrapper(mod.off_head[0], "d"), fold_wrapper(mod.off_head[1], "hw")
+
+    def __call__(self, x):
+        cost = conv_hw(conv_d(x, self.c0, 3, 1, 1, 1), self.c1)
+        off = conv_hw(conv_d(x, self.o0, 3, 1, 1, 1), self.o1, act=ACT_TANH_OFFSET, act_param=self.delta)
+        return cost.squeeze(1), off.squeeze(1)
+
+
+class ConvexUp:
+    """ConvexUpsample (module.py:300-353) with mask.0+mask.1 (conv+BN) folded."""
+
+    def __init__(self, mod):
+        self.r, self.k = mod.upscale_factor, mod.window_size
+        if self.k != 3:
+            raise NotImplementedError("window_size != 3")
+        self.m0 = Folded(mod.mask[0].weight.unsqueeze(2), mod.mask[0].bias, mod.mask[1], ACT_SILU, False, "hw")
+        w3 = mod.mask[3].weight
+        self.m3 = Folded(w3.reshape(w3.shape[0], w3.shape[1], 1, 1, 1), mod.mask[3].bias, None, ACT_NONE, False, "d")
+
+    def __call__(self, feat, disp):
+        B, _, H, W = disp.shape
+        m = conv_hw(feat.unsqueeze(2), self.m0)
+        m = conv_d(m, self.m3, 1)
+        out = torch.empty((B, 1, H * self.r, W * self.r), device=disp.device, dtype=torch.float32)
+        rc = _lib.lib().ts_convex_upsample_fwd(_lib.ptr(m), _lib.ptr(disp.contiguous()), _lib.ptr(out), B, H, W, self.r,
+                                               float(self.r), _stream())
+        _lib.check(rc, "ts_convex_upsample_fwd")
+        return out
+
+
+class _LevelBase:
+    def __init__(self, mod):
+        self.mod = mod
+        self.C, self.topk, self.scales = mod.C, mod.topk, mod.block_cost_scale
+        self.init0, self.hg, self.init2 = SepConv(mod.init3d[0]), Hourglass(mod.init3d[1]), SepConv(mod.init3d[2])
+        self.heads = Heads(mod.pred_heads)
+
+    def init3d(self, raw):
+        return self.init2(self.hg(self.init0(raw)))
+
+
+class _MergingLevel(_LevelBase):
+    def __init__(self, mod):
+        super().__init__(mod)
+        pc = mod.past_conv
+        f = fold_wrapper(pc, "d")                   # 1 -> C, 1x1x1, BN, SiLU: evaluated inside the merge kernel
+        self.past_w = f.w.reshape(-1)[:self.C].contiguous()
+        self.past_scale, self.past_shift = f.scale[:self.C].contiguous(), f.shift[:self.C].contiguous()
+        self.fusion = mod.spatial_fusion
+        if self.fusion:
+            self.conv5 = fold_wrapper(mod.fuse.conv_5x5, "d")
+            self.fuse = SepConv(mod.fuse.conv_fuse)
+        self.up = ConvexUp(mod.convex_upsample)
+
+    def merge_fuse_predict(self, vol, samples, prev_info, feat, resize_memory):
+        B, C, D0, H, W = vol.shape
+        K = self.topk
+        memory = prev_info.get('cost_memory', None)
+        mem_s = mem_c = None
+        if memory is not None and prev_info.get('use_past_cost', False):
+            mem_s, mem_c = memory['disp_sample'], memory['cost_volume']
+            if resize_memory:                                           # coarse.py:91-96
+                mem_s = resize_bilinear(mem_s, (H, W), W / mem_s.shape[-1])
+                mem_c = resize_bilinear(mem_c, (H, W), 1.0)
+            mem_s, mem_c = mem_s.contiguous(), mem_c.contiguous()
+        Dm = D0 + K
+        nch = 4 * C if self.fusion else C
+        cat4 = torch.empty((B, nch, Dm, H, W), device=vol.device, dtype=torch.float32)
+        samp = torch.empty((B, Dm, H, W), device=vol.device, dtype=torch.float32)
+        x0 = cat4[:, :C]
+        vb, vc = _strides5(vol); ob, oc = _strides5(x0)
+        rc = _lib.lib().ts_merge_candidates_fwd(_lib.ptr(vol), _lib.ptr(samples), _lib.ptr(mem_s), _lib.ptr(mem_c),
+                                                _lib.ptr(self.past_w), _lib.ptr(self.past_scale), _lib.ptr(self.past_shift),
+                                                _lib.ptr(samp), _lib.ptr(x0), B, C, D0, K, H, W, vb, vc, ob, oc, _stream())
+        _lib.check(rc, "ts_merge_candidates_fwd")
+        if self.fusion:                                                 # PyramidFusion, module.py:412-421
+            conv_d(x0, self.conv5, 5, 1, 1, 2, out=cat4[:, C:2 * C])
+            pool5(x0, cat4[:, 2 * C:3 * C], cat4[:, 3 * C:])
+            y = self.fuse(cat4)
+        else:
+            y = x0
+        cost, off = self.heads(y)
+        disp, _, _ = TF.topk_softargmax(cost, samp, off, k=self.topk)
+        return self.up(feat, disp), cost, off, samp
+
+
+class NativeCoarse(_MergingLevel):
+    def __call__(self, left, right, prev_info):
+        raw = TF.block_cost(left, right, int(self.mod.num_sample), self.scales)
+        return self.merge_fuse_predict(self.init3d(raw), None, prev_info, left, resize_memory=True)
+
+
+def _candidates(low, high):
+    span, base = torch.abs(high - low), torch.min(low, high)
+    return torch.cat([span * s + base for s in (0.0, 0.375, 0.5, 0.625, 1.0)], dim=1)
+
+
+class NativeFine(_MergingLevel):
+    def __call__(self, left, right, low, high, prev_info):
+        ds = _candidates(low, high)
+        lm = prev_info.get('local_map', None)
+        if lm is not None and prev_info.get('local_map_size', 0) > 0:
+            H, W = low.shape[-2:]
+            ds = torch.cat([resize_bilinear(lm, (H, W), W / lm.shape[-1]), ds], dim=1)
+        ds = ds.contiguous()
+        raw = TF.block_cost(left, right, ds, self.scales)
+        return self.merge_fuse_predict(self.init3d(raw), ds, prev_info, left, resize_memory=False)
+
+
+class NativePrecise(_LevelBase):
+    def __init__(self, mod):
+        super().__init__(mod)
+        u = mod.refinement
+        self.enc = [fold_wrapper(m, "hw") for m in (u.conv2[0], u.conv2[1], u.conv4[0], u.conv4[1])]
+        self.enc_stride = [u.conv2[0].stride[0], u.conv2[1].stride[0], u.conv4[0].stride[0], u.conv4[1].stride[0]]
+        self.fuse = [fold_wrapper(u.fuse[0], "hw"), fold_wrapper(u.fuse[1], "hw")]
+        self.deconv4 = Folded(u.deconv4.weight, u.deconv4.bias, u.deconv4.norm, _act_code(u.deconv4.activation), True, "deconv2d")
+        self.concat = fold_wrapper(u.concat, "hw")
+        self.deconv2 = Folded(u.deconv2.weight, u.deconv2.bias, None, ACT_NONE, True, "deconv2d")
+        self.in_planes = mod.in_planes
+
+    @staticmethod
+    def _c2d(x, f, stride, out=None):
+        return conv_hw(x, f, stride, 1, out=out)
+
+    def encode(self, img, cat4):
+        """UNet.encoder for one image; the 1/4 feature goes straight into its slice of `cat4`."""
+        x = self._c2d(img.unsqueeze(2), self.enc[0], self.enc_stride[0])
+        s2 = self._c2d(x, self.enc[1], self.enc_stride[1])
+        x = self._c2d(s2, self.enc[2], self.enc_stride[2])
+        self._c2d(x, self.enc[3], self.enc_stride[3], out=cat4[:, self.in_planes:].unsqueeze(2))
+        return s2
+
+    def _deconv(self, x, f, out, out_bstride):
+        B, Cin, H, W = x.shape
+        rc = _lib.lib().ts_deconv2d_k4s2_fwd(_lib.ptr(x), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
+                                             B, Cin, f.cout, H, W, f.act, out_bstride, _stream())
+        _lib.check(rc, "ts_deconv2d_k4s2_fwd")
+
+    def __call__(self, left, right, low, high, left_image, right_image, prev_info):
+        B, Cf, H, W = left.shape
+        lcat = torch.empty((B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)
+        rcat = torch.empty_like(lcat)
+        lcat[:, :Cf].copy_(left); rcat[:, :Cf].copy_(right)
+        s2l = self.encode(left_image, lcat)
+        self.encode(right_image, rcat)
+        ds = _candidates(low, high).contiguous()
+        raw = TF.block_cost(lcat, rcat, ds, self.scales)
+        cost, off = self.heads(self.init3d(raw))
+        disp, mem_s, mem_c = TF.topk_softargmax(cost, ds, off, k=self.topk)
+        # UNet.decoder (module.py:484-492)
+        f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)
+        C32 = self.deconv4.cout
+        cat2 = torch.empty((B, C32 + s2l.shape[1], 2 * H, 2 * W), device=left.device, dtype=torch.float32)
+        self._deconv(f.contiguous(), self.deconv4, cat2, cat2.stride(0))
+        cat2[:, C32:].copy_(s2l.squeeze(2))
+        g = self._c2d(cat2.unsqueeze(2), self.concat, 1).squeeze(2).contiguous()
+        mask = torch.empty((B, 9, 4 * H, 4 * W), device=left.device, dtype=torch.float32)
+        self._deconv(g, self.deconv2, mask, mask.stride(0))
+        full = torch.empty((B, 1, 4 * H, 4 * W), device=left.device, dtype=torch.float32)
+        rc = _lib.lib().ts_unet_upsample_fwd(_lib.ptr(mask), _lib.ptr(disp), _lib.ptr(full), B, H, W, 4 * H, 4 * W, _stream())
+        _lib.check(rc, "ts_unet_upsample_fwd")
+        prev_info['prev_disp'] = full
+        prev_info['cost_memory'] = {'disp_sample': resize_bilinear(mem_s, (H // 2, W // 2), 0.5),      # precise.py:100-103
+                                    'cost_volume': resize_bilinear(mem_c, (H // 2, W // 2), 1.0)}
+        return full, disp, cost, off, ds
+
+
+class NativeAggregator:
+    """Callable with the signature and outputs of TEMPORALSTEREO.forward, eval mode, HIP kernels only."""
+
+    def __init__(self, net):
+        if net.training:
+            raise RuntimeError("NativeAggregator folds BatchNorm: put the module in eval() first")
+        if any(p.device.type != "cuda" for p in net.parameters()):
+            raise RuntimeError("NativeAggregator needs the module on the GPU (there is no CPU path)")
+        self.coarse, self.fine, self.precise = NativeCoarse(net.coarse), NativeFine(net.fine), NativePrecise(net.precise)
+
+    @torch.no_grad()
+    def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):
+        rng = 4
+        l4, l8, l16 = left_feats
+        r4, r8, r16 = right_feats
+        disps, costs, offs, samples, ranges = [], [], [], [], []
+        d, c, o, s = self.coarse(l16.contiguous(), r16.contiguous(), prev_info)
+        low, high = d - rng, d + rng
+        disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
+        d, c, o, s = self.fine(l8.contiguous(), r8.contiguous(), low, high, prev_info)
+        low, high = d - rng, d + rng
+        disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
+        full, d, c, o, s = self.precise(l4, r4, low, high, left_image.contiguous(), right_image.contiguous(), prev_info)
+        disps += [d, full]; costs.append(c); offs.append(o); samples.append(s)
+        return disps[::-1], costs[::-1], samples[::-1], offs[::-1], ranges[::-1], prev_info

@@ -1,0 +1,422 @@
+// K3/K5 -- the non-convolution stages of the aggregation pyramid for gfx950 (MI355X), inference form.
+//
+//   resize_add_act   F.interpolate(trilinear, align_corners) to the skip's size + add + SiLU
+//                    (ResidualBlock3D.forward, module.py:285-295)
+//   pool5_avgmax     avg_pool3d / max_pool3d 5^3, stride 1, padding 2 (PyramidFusion, module.py:415-417)
+//   merge_candidates past_conv + cat + sort + gather along D (coarse.py:84-105, fine.py:105-122)
+//   convex_upsample  softmax-over-9 weighted x2 upsampling (ConvexUpsample.forward, module.py:336-353)
+//   unet_upsample    softmax-over-9 weighted x4 upsampling (UNet.upsample, module.py:468-482)
+//   deconv2d_k4s2    ConvTranspose2d(kernel 4, stride 2, padding 1) (UNet.deconv4/deconv2, module.py:453-457)
+//   resize_bilinear  F.interpolate(bilinear, align_corners) with a value scale (memory resizes,
+//                    coarse.py:91-96, precise.py:100-103, projects/TemporalStereo/TemporalStereo.py:305-309)
+//
+// All are bandwidth/latency-bound element kernels: W is the contiguous axis, consecutive lanes own
+// consecutive pixels, every tensor is read once and written once (the 5^3 pooling goes through an
+// LDS plane tile and a 5-deep register ring along D instead of 125 global taps per output).
+#include "ts_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
+
+unsigned grid_for(long long n, int threads) {
+  long long blocks = (n + threads - 1) / threads;
+  const long long cap = static_cast<long long>(ts::kNumCU) * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>(blocks);
+}
+
+// source index / weight of torch's align_corners=True linear interpolation
+__device__ __forceinline__ void lin_src(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+  const float s = scale * static_cast<float>(dst);
+  i0 = static_cast<int>(s);
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - static_cast<float>(i0);
+}
+
+inline float ac_scale(int in_size, int out_size) {
+  return out_size > 1 ? static_cast<float>(in_size - 1) / static_cast<float>(out_size - 1) : 0.f;
+}
+
+// ------------------------------------------------------------------------------- resize + add + act
+struct Resize3 {
+  int C, Da, Ha, Wa, D, H, W;
+  float sd, sh, sw;
+  int act;   // 0 none, 1 SiLU
+  long long a_bstride, a_cstride, b_bstride, b_cstride, o_bstride, o_cstride;
+};
+
+__global__ void __launch_bounds__(256)
+resize_add_act_kernel(const float* __restrict__ a, const float* __restrict__ bsrc, float* __restrict__ out, const Resize3 p) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int n = p.D * p.H * p.W;
+  const float* ap = a + static_cast<size_t>(b) * p.a_bstride + static_cast<size_t>(c) * p.a_cstride;
+  const float* bp = bsrc ? bsrc + static_cast<size_t>(b) * p.b_bstride + static_cast<size_t>(c) * p.b_cstride : nullptr;
+  float* op = out + static_cast<size_t>(b) * p.o_bstride + static_cast<size_t>(c) * p.o_cstride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int x = i % p.W;
+    const int t = i / p.W;
+    const int y = t % p.H, d = t / p.H;
+    int d0, d1, y0, y1, x0, x1;
+    float ld, ly, lx;
+    lin_src(p.sd, d, p.Da, d0, d1, ld);
+    lin_src(p.sh, y, p.Ha, y0, y1, ly);
+    lin_src(p.sw, x, p.Wa, x0, x1, lx);
+    const size_t HWa = static_cast<size_t>(p.Ha) * p.Wa;
+    const float* p0 = ap + d0 * HWa;
+    const float* p1 = ap + d1 * HWa;
+    const float v00 = (1.f - lx) * p0[y0 * p.Wa + x0] + lx * p0[y0 * p.Wa + x1];
+    const float v01 = (1.f - lx) * p0[y1 * p.Wa + x0] + lx * p0[y1 * p.Wa + x1];
+    const float v10 = (1.f - lx) * p1[y0 * p.Wa + x0] + lx * p1[y0 * p.Wa + x1];
+    const float v11 = (1.f - lx) * p1[y1 * p.Wa + x0] + lx * p1[y1 * p.Wa + x1];
+    float v = (1.f - ld) * ((1.f - ly) * v00 + ly * v01) + ld * ((1.f - ly) * v10 + ly * v11);
+    if (bp) v += bp[i];
+    op[i] = p.act == 1 ? silu(v) : v;
+  }
+}
+
+// ------------------------------------------------------------------------------- 5^3 avg + max pool
+constexpr int PT_Y = 8, PT_X = 32;
+struct Pool5 {
+  int C, D, H, W;
+  long long x_bstride, x_cstride, avg_bstride, avg_cstride, max_bstride, max_cstride;
+};
+
+__global__ void __launch_bounds__(256)
+pool5_avgmax_kernel(const float* __restrict__ x, float* __restrict__ oavg, float* __restrict__ omax, const Pool5 p) {
+  __shared__ float tile[PT_Y + 4][PT_X + 4 + 1];
+  const int tiles_x = (p.W + PT_X - 1) / PT_X;
+  const int ty0 = (blockIdx.x / tiles_x) * PT_Y, tx0 = (blockIdx.x % tiles_x) * PT_X;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int tx = threadIdx.x & (PT_X - 1), ty = threadIdx.x / PT_X;
+  const int y = ty0 + ty, xx = tx0 + tx;
+  const size_t HW = static_cast<size_t>(p.H) * p.W;
+  const float* xp = x + static_cast<size_t>(b) * p.x_bstride + static_cast<size_t>(c) * p.x_cstride;
+  float* ap = oavg + static_cast<size_t>(b) * p.avg_bstride + static_cast<size_t>(c) * p.avg_cstride;
+  float* mp = omax + static_cast<size_t>(b) * p.max_bstride + static_cast<size_t>(c) * p.max_cstride;
+  float rs[5], rm[5];       // 2-D pooled planes d-4 .. d (ring kept in order by shifting)
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { rs[i] = 0.f; rm[i] = -INFINITY; }
+  for (int d = 0; d < p.D + 2; ++d) {
+    float s2 = 0.f, m2 = -INFINITY;
+    if (d < p.D) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < (PT_Y + 4) * (PT_X + 4); i += blockDim.x) {
+        const int cx = i % (PT_X + 4), cy = i / (PT_X + 4);
+        const int gy = ty0 + cy - 2, gx = tx0 + cx - 2;
+        // zero for the average (count_include_pad), handled as -inf for the max via the flag below
+        tile[cy][cx] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? xp[d * HW + static_cast<size_t>(gy) * p.W + gx] : NAN;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const float v = tile[ty + ky][tx + kx];
+          const bool pad = v != v;             // NaN marks padding
+          s2 += pad ? 0.f : v;
+          m2 = pad ? m2 : fmaxf(m2, v);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rs[i] = rs[i + 1]; rm[i] = rm[i + 1]; }
+    rs[4] = s2; rm[4] = m2;                     // planes beyond D contribute 0 / -inf
+    const int od = d - 2;
+    if (od >= 0 && y < p.H && xx < p.W) {
+      const float s = rs[0] + rs[1] + rs[2] + rs[3] + rs[4];
+      const float m = fmaxf(fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3])), rm[4]);
+      const size_t o = od * HW + static_cast<size_t>(y) * p.W + xx;
+      ap[o] = s * (1.f / 125.f);
+      mp[o] = m;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- merge candidates
+constexpr int MERGE_DMAX = 20;
+struct Merge {
+  int B, C, D0, K, HW;            // D0 computed candidates + K memory candidates
+  int implicit_samples;            // 1: candidate i has disparity i (coarse level)
+  long long vol_bstride, vol_cstride, out_bstride, out_cstride;
+};
+
+// One lane per pixel: rank every candidate (stable: ties keep their original order, SURVEY.md
+// Appendix B.2), write the sorted disparities, and move each candidate's C-channel column of the
+// volume to its sorted slot.  Memory candidates get their volume from past_conv:
+// Conv3d(1->C, 1x1x1, no bias) + BatchNorm + SiLU of the remembered cost (coarse.py:42,98).
+__global__ void __launch_bounds__(256)
+merge_candidates_kernel(const float* __restrict__ vol, const float* __restrict__ samp, const float* __restrict__ mem_samp,
+                        const float* __restrict__ mem_cost, const float* __restrict__ pw, const float* __restrict__ pscale,
+                        const float* __restrict__ pshift, float* __restrict__ out_samp, float* __restrict__ out_vol,
+                        const Merge p) {
+  const int DT = p.D0 + p.K;
+  const long long n = static_cast<long long>(p.B) * p.HW;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(i / p.HW);
+    const int px = static_cast<int>(i - static_cast<long long>(b) * p.HW);
+    float s[MERGE_DMAX];
+#pragma unroll
+    for (int j = 0; j < MERGE_DMAX; ++j) {
+      float v = INFINITY;
+      if (j < p.D0) v = p.implicit_samples ? static_cast<float>(j) : samp[(static_cast<size_t>(b) * p.D0 + j) * p.HW + px];
+      else if (j < DT) v = mem_samp ? mem_samp[(static_cast<size_t>(b) * p.K + (j - p.D0)) * p.HW + px] : 0.f;
+      s[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < MERGE_DMAX; ++j) {
+      if (j >= DT) continue;
+      int rank = 0;
+#pragma unroll
+      for (int q = 0; q < MERGE_DMAX; ++q)
+        if (q < DT) rank += (s[q] < s[j]) || (s[q] == s[j] && q < j);
+      out_samp[(static_cast<size_t>(b) * DT + rank) * p.HW + px] = s[j];
+      float* ov = out_vol + static_cast<size_t>(b) * p.out_bstride + static_cast<size_t>(rank) * p.HW + px;
+      if (j < p.D0) {
+        const float* iv = vol + static_cast<size_t>(b) * p.vol_bstride + static_cast<size_t>(j) * p.HW + px;
+        for (int c = 0; c < p.C; ++c) ov[static_cast<size_t>(c) * p.out_cstride] = iv[static_cast<size_t>(c) * p.vol_cstride];
+      } else {
+        const float m = mem_cost ? mem_cost[(static_cast<size_t>(b) * p.K + (j - p.D0)) * p.HW + px] : 0.f;
+        for (int c = 0; c < p.C; ++c) ov[static_cast<size_t>(c) * p.out_cstride] = silu(pw[c] * m * pscale[c] + pshift[c]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- 9-tap upsamplers
+// ConvexUpsample x r (r = 2): mask [B, 9*r*r, H, W] viewed (9, r, r); out [B,1,rH,rW]
+__global__ void __launch_bounds__(256)
+convex_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ disp, float* __restrict__ out,
+                       int B, int H, int W, int r, float disp_scale) {
+  const int HW = H * W, Ho = H * r, Wo = W * r;
+  const long long n = static_cast<long long>(B) * Ho * Wo;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int ox = static_cast<int>(i % Wo);
+    const long long t = i / Wo;
+    const int oy = static_cast<int>(t % Ho), b = static_cast<int>(t / Ho);
+    const int y = oy / r, ry = oy - y * r, x = ox / r, rx = ox - x * r;
+    const float* mp = mask + (static_cast<size_t>(b) * 9 * r * r + ry * r + rx) * HW + static_cast<size_t>(y) * W + x;
+    const float* dp = disp + static_cast<size_t>(b) * HW;
+    float m[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { m[k] = mp[static_cast<size_t>(k) * r * r * HW]; mx = fmaxf(mx, m[k]); }
+    float den = 0.f, acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float e = expf(m[k] - mx);
+      den += e;
+      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? dp[yy * W + xx] * disp_scale : 0.f;
+      acc += e * v;
+    }
+    out[i] = acc / den;
+  }
+}
+
+// UNet.upsample: mask [B,9,Ho,Wo] softmax over 9; out = sum_k bilinear(unfold(disp)_k * Wo/w)(oy,ox) * p_k
+__global__ void __launch_bounds__(256)
+unet_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ disp, float* __restrict__ out,
+                     int B, int h, int w, int Ho, int Wo, float sh, float sw) {
+  const long long n = static_cast<long long>(B) * Ho * Wo;
+  const size_t HWo = static_cast<size_t>(Ho) * Wo;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int ox = static_cast<int>(i % Wo);
+    const long long t = i / Wo;
+    const int oy = static_cast<int>(t % Ho), b = static_cast<int>(t / Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    lin_src(sh, oy, h, y0, y1, ly);
+    lin_src(sw, ox, w, x0, x1, lx);
+    const float* mp = mask + static_cast<size_t>(b) * 9 * HWo + static_cast<size_t>(oy) * Wo + ox;
+    const float* dp = disp + static_cast<size_t>(b) * h * w;
+    float m[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { m[k] = mp[k * HWo]; mx = fmaxf(mx, m[k]); }
+    float den = 0.f, acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float e = expf(m[k] - mx);
+      den += e;
+      const int dy = k / 3 - 1, dx = k % 3 - 1;
+      auto at = [&](int yy, int xx) {
+        yy += dy; xx += dx;
+        // disp * w_out / w_in in the reference's evaluation order (module.py:478)
+        return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dp[yy * w + xx] * static_cast<float>(Wo) / static_cast<float>(w) : 0.f;
+      };
+      const float top = (1.f - lx) * at(y0, x0) + lx * at(y0, x1);
+      const float bot = (1.f - lx) * at(y1, x0) + lx * at(y1, x1);
+      acc += e * ((1.f - ly) * top + ly * bot);
+    }
+    out[i] = acc / den;
+  }
+}
+
+// ------------------------------------------------------------------------------- ConvTranspose2d k4 s2 p1
+// out (2H, 2W): oy = 2 iy - 1 + ky: even oy=2m: (ky=1, iy=m), (ky=3, iy=m-1); odd oy=2m+1: (ky=0, iy=m+1), (ky=2, iy=m).
+// weights [Cin][4][4][CoutPad]
+template <int COUT>
+__global__ void __launch_bounds__(256)
+deconv2d_k4s2_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                     const float* __restrict__ shift, float* __restrict__ y, int B, int Cin, int Cout, int H, int W, int act,
+                     long long out_bstride) {
+  const int b = blockIdx.z;
+  const int Ho = 2 * H, Wo = 2 * W;
+  const size_t HW = static_cast<size_t>(H) * W;
+  const float* xb = x + static_cast<size_t>(b) * Cin * HW;
+  const int n = Ho * Wo;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
+    const int oy = o / Wo, ox = o - oy * Wo;
+    const int my = oy >> 1, mx = ox >> 1;
+    int iy[2], ky[2], ix[2], kx[2];
+    if ((oy & 1) == 0) { iy[0] = my; ky[0] = 1; iy[1] = my - 1; ky[1] = 3; }
+    else { iy[0] = my + 1; ky[0] = 0; iy[1] = my; ky[1] = 2; }
+    if ((ox & 1) == 0) { ix[0] = mx; kx[0] = 1; ix[1] = mx - 1; kx[1] = 3; }
+    else { ix[0] = mx + 1; kx[0] = 0; ix[1] = mx; kx[1] = 2; }
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xc = xb + static_cast<size_t>(ci) * HW;
+      const float* wc = w + static_cast<size_t>(ci) * 16 * COUT;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (iy[a] < 0 || iy[a] >= H) continue;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (ix[c] < 0 || ix[c] >= W) continue;
+          const float xv = xc[static_cast<size_t>(iy[a]) * W + ix[c]];
+          const float* wt = wc + (ky[a] * 4 + kx[c]) * COUT;
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[co], xv, acc[co]);
+        }
+      }
+    }
+    float* yb = y + static_cast<size_t>(b) * out_bstride + o;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+      if (co < Cout) {
+        const float v = acc[co] * scale[co] + shift[co];
+        yb[static_cast<size_t>(co) * n] = act == 2 ? fmaxf(v, 0.f) : (act == 1 ? silu(v) : v);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------- bilinear resize
+__global__ void __launch_bounds__(256)
+resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, int BC, int h, int w, int Ho, int Wo,
+                       float sh, float sw, float vscale) {
+  const long long n = static_cast<long long>(BC) * Ho * Wo;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int ox = static_cast<int>(i % Wo);
+    const long long t = i / Wo;
+    const int oy = static_cast<int>(t % Ho), bc = static_cast<int>(t / Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    lin_src(sh, oy, h, y0, y1, ly);
+    lin_src(sw, ox, w, x0, x1, lx);
+    const float* p = x + static_cast<size_t>(bc) * h * w;
+    const float top = (1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1];
+    const float bot = (1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1];
+    out[i] = ((1.f - ly) * top + ly * bot) * vscale;
+  }
+}
+
+}  // namespace
+
+extern "C" int ts_resize3d_add_act_fwd(const float* a, const float* add, float* out, int B, int C, int Da, int Ha, int Wa,
+                                       int D, int H, int W, int act, long long a_bstride, long long a_cstride,
+                                       long long add_bstride, long long add_cstride, long long out_bstride,
+                                       long long out_cstride, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && Da > 0 && Ha > 0 && Wa > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "resize3d: non-positive size");
+  TS_REQUIRE(B <= 65535 && C <= 65535, TS_ERR_UNSUPPORTED, "resize3d: grid too large");
+  TS_REQUIRE_PTR(a); TS_REQUIRE_PTR(out);
+  Resize3 p;
+  p.C = C; p.Da = Da; p.Ha = Ha; p.Wa = Wa; p.D = D; p.H = H; p.W = W;
+  p.sd = ac_scale(Da, D); p.sh = ac_scale(Ha, H); p.sw = ac_scale(Wa, W);
+  p.act = act;
+  p.a_bstride = a_bstride; p.a_cstride = a_cstride; p.b_bstride = add_bstride; p.b_cstride = add_cstride;
+  p.o_bstride = out_bstride; p.o_cstride = out_cstride;
+  const int n = D * H * W;
+  int blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(resize_add_act_kernel, dim3(blocks, C, B), dim3(256), 0, ts::as_stream(stream), a, add, out, p);
+  return ts::launched("resize_add_act_kernel");
+}
+
+extern "C" int ts_pool3d5_avgmax_fwd(const float* x, float* out_avg, float* out_max, int B, int C, int D, int H, int W,
+                                     long long x_bstride, long long x_cstride, long long avg_bstride, long long avg_cstride,
+                                     long long max_bstride, long long max_cstride, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "pool3d5: non-positive size");
+  TS_REQUIRE(B <= 65535 && C <= 65535, TS_ERR_UNSUPPORTED, "pool3d5: grid too large");
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(out_avg); TS_REQUIRE_PTR(out_max);
+  Pool5 p;
+  p.C = C; p.D = D; p.H = H; p.W = W;
+  p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.avg_bstride = avg_bstride; p.avg_cstride = avg_cstride;
+  p.max_bstride = max_bstride; p.max_cstride = max_cstride;
+  const int tiles = ((H + PT_Y - 1) / PT_Y) * ((W + PT_X - 1) / PT_X);
+  hipLaunchKernelGGL(pool5_avgmax_kernel, dim3(tiles, C, B), dim3(256), 0, ts::as_stream(stream), x, out_avg, out_max, p);
+  return ts::launched("pool5_avgmax_kernel");
+}
+
+extern "C" int ts_merge_candidates_fwd(const float* volume, const float* sample, const float* mem_sample, const float* mem_cost,
+                                       const float* past_w, const float* past_scale, const float* past_shift,
+                                       float* out_sample, float* out_volume, int B, int C, int D0, int K, int H, int W,
+                                       long long vol_bstride, long long vol_cstride, long long out_bstride,
+                                       long long out_cstride, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && D0 > 0 && K >= 0 && H > 0 && W > 0, TS_ERR_SHAPE, "merge_candidates: non-positive size");
+  TS_REQUIRE(D0 + K <= MERGE_DMAX, TS_ERR_UNSUPPORTED, "merge_candidates: more than %d candidates", MERGE_DMAX);
+  TS_REQUIRE_PTR(volume); TS_REQUIRE_PTR(out_sample); TS_REQUIRE_PTR(out_volume);
+  if (K > 0) { TS_REQUIRE_PTR(past_w); TS_REQUIRE_PTR(past_scale); TS_REQUIRE_PTR(past_shift); }
+  Merge p;
+  p.B = B; p.C = C; p.D0 = D0; p.K = K; p.HW = H * W; p.implicit_samples = sample ? 0 : 1;
+  p.vol_bstride = vol_bstride; p.vol_cstride = vol_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
+  hipLaunchKernelGGL(merge_candidates_kernel, dim3(grid_for(static_cast<long long>(B) * H * W, 256)), dim3(256), 0,
+                     ts::as_stream(stream), volume, sample, mem_sample, mem_cost, past_w, past_scale, past_shift,
+                     out_sample, out_volume, p);
+  return ts::launched("merge_candidates_kernel");
+}
+
+extern "C" int ts_convex_upsample_fwd(const float* mask, const float* disp, float* out, int B, int H, int W, int factor,
+                                      float disp_scale, void* stream) {
+  TS_REQUIRE(B > 0 && H > 0 && W > 0 && factor >= 1, TS_ERR_SHAPE, "convex_upsample: bad size");
+  TS_REQUIRE_PTR(mask); TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(out);
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3(grid_for(static_cast<long long>(B) * H * W * factor * factor, 256)), dim3(256), 0,
+                     ts::as_stream(stream), mask, disp, out, B, H, W, factor, disp_scale);
+  return ts::launched("convex_upsample_kernel");
+}
+
+extern "C" int ts_unet_upsample_fwd(const float* mask, const float* disp, float* out, int B, int h, int w, int Ho, int Wo,
+                                    void* stream) {
+  TS_REQUIRE(B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, TS_ERR_SHAPE, "unet_upsample: bad size");
+  TS_REQUIRE_PTR(mask); TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(out);
+  hipLaunchKernelGGL(unet_upsample_kernel, dim3(grid_for(static_cast<long long>(B) * Ho * Wo, 256)), dim3(256), 0,
+                     ts::as_stream(stream), mask, disp, out, B, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo));
+  return ts::launched("unet_upsample_kernel");
+}
+
+extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                                    int B, int Cin, int Cout, int H, int W, int act, long long out_bstride, void* stream) {
+  TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "deconv2d: non-positive size");
+  TS_REQUIRE(Cout <= 32, TS_ERR_UNSUPPORTED, "deconv2d: Cout=%d > 32", Cout);
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(scale); TS_REQUIRE_PTR(shift); TS_REQUIRE_PTR(y);
+  int blocks = (4 * H * W + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  const dim3 grid(blocks, 1, B);
+  hipStream_t st = ts::as_stream(stream);
+  if (Cout <= 16) hipLaunchKernelGGL(deconv2d_k4s2_kernel<16>, grid, dim3(256), 0, st, x, w_t, scale, shift, y, B, Cin, Cout, H, W, act, out_bstride);
+  else hipLaunchKernelGGL(deconv2d_k4s2_kernel<32>, grid, dim3(256), 0, st, x, w_t, scale, shift, y, B, Cin, Cout, H, W, act, out_bstride);
+  return ts::launched("deconv2d_k4s2_kernel");
+}
+
+extern "C" int ts_resize_bilinear_fwd(const float* x, float* out, int BC, int h, int w, int Ho, int Wo, float value_scale,
+                                      void* stream) {
+  TS_REQUIRE(BC > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, TS_ERR_SHAPE, "resize_bilinear: bad size");
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(out);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(static_cast<long long>(BC) * Ho * Wo, 256)), dim3(256), 0,
+                     ts::as_stream(stream), x, out, BC, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo), value_scale);
+  return ts::launched("resize_bilinear_kernel");
+}

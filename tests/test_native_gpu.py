@@ -1,0 +1,120 @@
+"""GPU: the all-HIP inference path (aggregation.native / InferenceEngine) against the nn.Module path
+on the same weights, against the reference's golden outputs, and each K3 op against torch."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import synth
+from helpers import load, t, dims_from_golden, aggregator_inputs, epe
+from test_aggregator_gpu import _build, _check_against_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _rand(seed, *shape, scale=1.0, dev=None):
+    return t(synth.normal(seed, "x%d" % len(shape), shape, scale), dev)
+
+
+# ------------------------------------------------------------------------------------------- ops
+@pytest.mark.parametrize("cin,cout,stride,dil,act", [(24, 8, 1, 1, "SiLU"), (16, 32, 2, 1, "SiLU"), (8, 16, 1, 2, None),
+                                                      (40, 64, 1, 1, "ReLU"), (16, 1, 1, 1, None)])
+def test_conv_hw_vs_torch(cin, cout, stride, dil, act):
+    from temporalstereo_amd.layers import Conv3d
+    from temporalstereo_amd.aggregation import native
+    dev = _dev()
+    torch.manual_seed(1)
+    m = Conv3d(cin, cout, (1, 3, 3), (1, stride, stride), (0, dil, dil), (1, dil, dil), bias=True,
+               norm=('BN3d', cout), activation=act).to(dev).eval()
+    m.norm.running_mean.normal_(0, 0.2); m.norm.running_var.uniform_(0.5, 1.5); m.norm.weight.data.uniform_(0.5, 1.5)
+    x = _rand(2, 2, cin, 5, 21, 37, dev=dev)
+    with torch.no_grad():
+        ref = m(x)
+    got = native.conv_hw(x, native.fold_wrapper(m, "hw"), stride, dil)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("k,stride,dil,pad", [(3, 1, 1, 1), (3, 2, 1, 1), (3, 1, 2, 2), (5, 1, 1, 2), (1, 1, 1, 0)])
+def test_conv_d_vs_torch(k, stride, dil, pad):
+    from temporalstereo_amd.layers import Conv3d
+    from temporalstereo_amd.aggregation import native
+    dev = _dev()
+    torch.manual_seed(2)
+    m = Conv3d(16, 16, (k, 1, 1), (stride, 1, 1), (pad, 0, 0), (dil, 1, 1), bias=False, norm=('BN3d', 16),
+               activation='SiLU').to(dev).eval()
+    m.norm.running_mean.normal_(0, 0.2); m.norm.running_var.uniform_(0.5, 1.5)
+    x = _rand(3, 2, 16, 7, 9, 13, dev=dev)
+    with torch.no_grad():
+        ref = m(x)
+    got = native.conv_d(x, native.fold_wrapper(m, "d"), k, stride, dil, pad)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_transposed_separable_vs_torch():
+    from temporalstereo_amd.aggregation import native
+    from temporalstereo_amd.aggregation.blocks import DepthwiseConvTranspose3D, DepthwiseConv3D
+    dev = _dev()
+    torch.manual_seed(3)
+    for mod, transposed in ((DepthwiseConvTranspose3D(16, 8, 3, 2, 1, 1, activation=None), True),
+                            (DepthwiseConv3D(16, 32, 3, 2, 1), False), (DepthwiseConv3D(8, 8, 3, 1, 2, dilation=2), False)):
+        mod = mod.to(dev).eval()
+        for bn in [m for m in mod.modules() if isinstance(m, nn.BatchNorm3d)]:
+            bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+        x = _rand(4, 2, mod.conv[0].in_channels, 3, 9, 15, dev=dev)
+        with torch.no_grad():
+            ref = mod(x)
+        got = native.SepConv(mod, transposed)(x)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_resize_add_act_pool_and_bilinear_vs_torch():
+    from temporalstereo_amd.aggregation import native
+    dev = _dev()
+    a = _rand(5, 2, 8, 4, 18, 30, dev=dev); b = _rand(6, 2, 8, 3, 17, 30, dev=dev)
+    ref = F.silu(F.interpolate(a, size=(3, 17, 30), mode='trilinear', align_corners=True) + b)
+    np.testing.assert_allclose(native.resize_add_act(a, b, (3, 17, 30)).cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    x = _rand(7, 2, 6, 7, 20, 45, dev=dev)
+    avg = torch.empty_like(x); mx = torch.empty_like(x)
+    native.pool5(x, avg, mx)
+    np.testing.assert_allclose(avg.cpu().numpy(), F.avg_pool3d(x, 5, 1, 2).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(mx.cpu().numpy(), F.max_pool3d(x, 5, 1, 2).cpu().numpy())
+    y = _rand(8, 2, 3, 17, 30, dev=dev)
+    ref = F.interpolate(y * 2.5, size=(8, 15), mode='bilinear', align_corners=True)
+    np.testing.assert_allclose(native.resize_bilinear(y, (8, 15), 2.5).cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("name", ["agg_tiny_single", "agg_tiny_temporal"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_native_engine_matches_reference(name, graph):
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    g = load(name); dev = _dev()
+    dims = dims_from_golden(g)
+    net = _build(dims, int(g["seed"]), dev, golden=g)
+    lf, rf, il, ir, prev = aggregator_inputs(g, dims, dev)
+    eng = InferenceEngine(net, backend="native", graph=graph)
+    outs = eng(lf, rf, il, ir, prev)
+    _check_against_golden(g, outs)
+    outs2 = eng(lf, rf, il, ir, prev)            # replay / second call gives the same answer
+    assert epe(outs2[0][0].cpu(), t(g["disp_full"])) < 1e-3
+
+
+def test_native_vs_module_config1():
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    g = load("agg_config1_256x512"); dev = _dev()
+    dims = dims_from_golden(g)
+    net = _build(dims, int(g["seed"]), dev, golden=g)
+    lf, rf, il, ir, prev = aggregator_inputs(g, dims, dev)
+    with torch.no_grad():
+        ref = net(lf, rf, il, ir, dict(prev))
+    got = InferenceEngine(net, backend="native", graph=False)(lf, rf, il, ir, dict(prev))
+    for a, b in zip(got[0], ref[0]):
+        assert epe(a.cpu(), b.cpu()) * (512 / a.shape[-1]) < 1e-3
+    assert epe(got[0][0][:, :, ::4, ::4].cpu(), t(g["disp_full_sub4"])) < 1e-3

@@ -181,8 +181,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (config 2: 1)")
-    ap.add_argument("--mode", default="auto", choices=["auto", "module", "engine"],
-                    help="module: nn.Module forward; engine: fused HIP inference engine (+hipGraph)")
+    ap.add_argument("--mode", default="native", choices=["native", "native-graph", "module", "module-graph"],
+                    help="native: all-HIP inference path (aggregation.native); module: nn.Module forward "
+                         "(torch/MIOpen convolutions); -graph: replayed as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -206,16 +207,9 @@ def main():
     inputs = make_inputs(dev, seed + rank, a.batch)
     calibrate_batchnorm(net, inputs)
 
-    runner, mode = None, a.mode
-    if mode in ("auto", "engine"):
-        try:
-            from temporalstereo_amd.aggregation.engine import InferenceEngine
-            runner = InferenceEngine(net)
-            mode = "engine"
-        except ImportError:
-            if mode == "engine":
-                raise
-            mode = "module"
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    mode = a.mode
+    runner = InferenceEngine(net, backend=mode.split("-")[0], graph=mode.endswith("-graph"))
 
     def step():
         with torch.no_grad():

@@ -111,6 +111,321 @@ conv_hw_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the matrix cores, all four conv families in one kernel:
+//     out[co][px] = sum_{tap, ci} W[ci][tap][co] * X[ci][px shifted by tap]
+// with v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation: parity is unchanged).  The point
+// is not FLOPs (f32 MFMA == the VALU rate on gfx950) but operand delivery: one MFMA takes ONE LDS
+// dword per lane for each operand and retires 1024 MACs, where the VALU form needs a weight per FMA.
+//
+//   workgroup = 256 output pixels x (CB*16) output channels; wave w owns 64 pixels as four 16-pixel
+//   blocks and keeps 4*CB accumulator tiles.  Per (tap, 4 input channels): CB weight fragments + 4
+//   input fragments from LDS, 4*CB MFMAs.
+//   K loop = chunks of 8 input channels.  While a chunk is being multiplied, the next chunk's input
+//   tile and weights are already in flight from global memory into registers (issued before the
+//   MFMAs), and are written to LDS after them -- global latency hides under the matrix work, which is
+//   what makes the many small layers of the hourglass cheap.
+//   MODE_HW : (1,3,3) taps, stride 1|2, dilation 1|2.  Tile = 8 x 32 pixels of one depth plane.
+//   MODE_HWT: ConvTranspose (1,3,3), stride 2, padding 1, output_padding 1, as four parity classes,
+//             each an ordinary 1/2/2/4-tap convolution over the input grid.
+//   MODE_D  : (k,1,1) taps, k = 1|3|5, stride/dilation along D, or its stride-2 transposed form.
+//             Tile = 256 consecutive pixels of one output depth.
+// ------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+enum { MODE_HW = 0, MODE_HWT = 1, MODE_D = 2 };
+constexpr int IG_NC = 8;        // input channels per K chunk
+
+struct IG {
+  int Cin, Cout, coutp;         // coutp: padded channel count of the weight / scale / shift arrays
+  int D, H, W;                  // input: planes per channel, plane geometry
+  int Do, Ho, Wo;               // output
+  int stride, dil, pad, k, transposed;
+  int act;
+  float act_param;
+  long long in_bstride, in_cstride, out_bstride, out_cstride;
+  int tiles_x, co_groups;
+};
+
+template <int MODE, bool S2>
+struct StageGeom {                       // rows / column-groups each thread stages per channel
+  static constexpr int RR = (MODE == MODE_D) ? 1 : (S2 ? 5 : 3);
+  static constexpr int QC = (MODE == MODE_D) ? 1 : (S2 ? 2 : 1);
+};
+
+template <int CB, int MODE, int KT, bool S2>
+__global__ void __launch_bounds__(256)
+ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+               const float* __restrict__ shift, float* __restrict__ y, const IG p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WP = (CB * 16) | 16;                  // weight row pitch (k-slots on disjoint banks)
+  constexpr int RR = StageGeom<MODE, S2>::RR, QC = StageGeom<MODE, S2>::QC;
+  constexpr int NTR = (MODE == MODE_D) ? KT : 1;      // planes staged per channel (MODE_D: one per tap)
+  constexpr int RWN = (KT * IG_NC * CB * 16 + 255) / 256;
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int cog = blockIdx.z % p.co_groups, b = blockIdx.z / p.co_groups;
+  const int co0 = cog * CB * 16;
+  const int od = blockIdx.y;
+
+  // ---- geometry of this workgroup -------------------------------------------------------------
+  int tile = blockIdx.x, pa = 0, pbit = 0;
+  if (MODE == MODE_HWT) { pa = (tile & 3) >> 1; pbit = tile & 1; tile >>= 2; }
+  int in_rows = 1, in_cols = 256, pitch = 256, iy0 = 0, ix0 = 0, ty0 = 0, tx0 = 0;
+  if (MODE == MODE_HW) {
+    ty0 = (tile / p.tiles_x) * 8; tx0 = (tile % p.tiles_x) * 32;
+    in_rows = 7 * p.stride + 2 * p.dil + 1; in_cols = 31 * p.stride + 2 * p.dil + 1;
+    pitch = in_cols | 1;
+    iy0 = ty0 * p.stride - p.pad; ix0 = tx0 * p.stride - p.pad;
+  } else if (MODE == MODE_HWT) {
+    ty0 = (tile / p.tiles_x) * 8; tx0 = (tile % p.tiles_x) * 32;
+    in_rows = 9; in_cols = 33; pitch = 33;
+    iy0 = ty0; ix0 = tx0;
+  }
+  int chan_elems = (MODE == MODE_D) ? NTR * 256 : in_rows * pitch;
+  chan_elems += (16 - (chan_elems & 31)) & 31;         // == 16 (mod 32)
+  float* in_tile = lds;
+  float* w_tile = lds + IG_NC * chan_elems;            // [KT][IG_NC][WP]
+  const size_t HW = static_cast<size_t>(p.H) * p.W;
+  const float* xb = x + static_cast<size_t>(b) * p.in_bstride;
+
+  // MODE_D: which input plane and which weight tap each staged plane is (uniform)
+  int plane_id[NTR], plane_wt[NTR], ntaps = KT;
+  if (MODE == MODE_D) {
+    if (p.transposed) {
+      ntaps = 0;
+      if ((od & 1) == 0) { plane_id[0] = od >> 1; plane_wt[0] = 1; ntaps = 1; }
+      else {
+        plane_id[0] = (od - 1) >> 1; plane_wt[0] = 2; ntaps = 1;
+        if (NTR > 1 && ((od + 1) >> 1) < p.D) { plane_id[1] = (od + 1) >> 1; plane_wt[1] = 0; ntaps = 2; }
+      }
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) if (t >= ntaps) { plane_id[t] = -1; plane_wt[t] = 0; }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) {
+        const int id = od * p.stride + t * p.dil - p.pad;
+        plane_id[t] = (id >= 0 && id < p.D) ? id : -1;
+        plane_wt[t] = t;
+      }
+    }
+  } else {
+    xb += static_cast<size_t>(od) * HW;                // HW modes: depth plane od of every channel
+  }
+  const int px0 = (MODE == MODE_D) ? blockIdx.x * 256 : 0;
+
+  // ---- per-lane fragment bases ----------------------------------------------------------------
+  int boff[4];
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) {
+    if (MODE == MODE_D) boff[pb] = kq * chan_elems + wave * 64 + pb * 16 + j;
+    else {
+      const int row = wave * 2 + (pb >> 1), col = (pb & 1) * 16 + j;
+      const int st = (MODE == MODE_HW) ? p.stride : 1;
+      boff[pb] = kq * chan_elems + row * st * pitch + col * st;
+    }
+  }
+  const int aoff = kq * WP + j;
+
+  v4f acc[CB][4];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  // ---- register prefetch of one K chunk ---------------------------------------------------------
+  const int tcol = threadIdx.x & 63, trow = threadIdx.x >> 6;
+  float rin[IG_NC][NTR * RR * QC];
+  float rw[RWN];
+  auto fetch = [&](int c0) {
+    const int nc = min(IG_NC, p.Cin - c0);
+#pragma unroll
+    for (int c = 0; c < IG_NC; ++c) {
+      const float* xc = xb + static_cast<size_t>(c0 + c) * p.in_cstride;
+      if (MODE == MODE_D) {
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+          const int px = px0 + threadIdx.x;
+          rin[c][t] = (c < nc && plane_id[t] >= 0 && px < static_cast<int>(HW)) ? xc[static_cast<size_t>(plane_id[t]) * HW + px] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+          const int cy = trow + 4 * r, gy = iy0 + cy;
+          const bool rowok = (c < nc) && cy < in_rows && gy >= 0 && gy < p.H;
+#pragma unroll
+          for (int q = 0; q < QC; ++q) {
+            const int cx = tcol + 64 * q, gx = ix0 + cx;
+            rin[c][r * QC + q] = (rowok && cx < in_cols && gx >= 0 && gx < p.W) ? xc[static_cast<size_t>(gy) * p.W + gx] : 0.f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RWN; ++q) {
+      const int i = threadIdx.x + 256 * q;
+      const int co = i % (CB * 16);
+      const int r = i / (CB * 16);
+      const int ci = r % IG_NC, tap = r / IG_NC;
+      rw[q] = (tap < KT && ci < nc && co0 + co < p.coutp) ? w[(static_cast<size_t>(c0 + ci) * KT + tap) * p.coutp + co0 + co] : 0.f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int c = 0; c < IG_NC; ++c) {
+      if (MODE == MODE_D) {
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) in_tile[c * chan_elems + t * 256 + threadIdx.x] = rin[c][t];
+      } else {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+          const int cy = trow + 4 * r;
+#pragma unroll
+          for (int q = 0; q < QC; ++q) {
+            const int cx = tcol + 64 * q;
+            if (cy < in_rows && cx < in_cols) in_tile[c * chan_elems + cy * pitch + cx] = rin[c][r * QC + q];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RWN; ++q) {
+      const int i = threadIdx.x + 256 * q;
+      const int co = i % (CB * 16);
+      const int r = i / (CB * 16);
+      if (r < KT * IG_NC) w_tile[r * WP + co] = rw[q];
+    }
+  };
+
+  fetch(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += IG_NC) {
+    __syncthreads();                  // everyone is done reading the previous chunk
+    commit();
+    __syncthreads();
+    if (c0 + IG_NC < p.Cin) fetch(c0 + IG_NC);          // next chunk in flight under the MFMAs below
+    if (MODE == MODE_HW) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int toff = (t / 3) * p.dil * pitch + (t % 3) * p.dil;
+        const float* wt = w_tile + (t * IG_NC) * WP + aoff;
+#pragma unroll
+        for (int cq = 0; cq < IG_NC / 4; ++cq) {
+          float a[CB], bv[4];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) bv[pb] = in_tile[boff[pb] + cq * 4 * chan_elems + toff];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+              acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+        }
+      }
+    } else if (MODE == MODE_HWT) {
+      // parity (pa, pbit): rows use (ky=1,dy=0) | (ky=2,dy=0),(ky=0,dy=1); same for columns
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta) {
+        if (ta > pa) continue;
+        const int ky = pa ? (ta ? 0 : 2) : 1, dy = ta;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+          if (tb > pbit) continue;
+          const int kx = pbit ? (tb ? 0 : 2) : 1, dx = tb;
+          const int toff = dy * pitch + dx;
+          const float* wt = w_tile + ((ky * 3 + kx) * IG_NC) * WP + aoff;
+#pragma unroll
+          for (int cq = 0; cq < IG_NC / 4; ++cq) {
+            float a[CB], bv[4];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) bv[pb] = in_tile[boff[pb] + cq * 4 * chan_elems + toff];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+              for (int pb = 0; pb < 4; ++pb)
+                acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) {
+        if (t >= ntaps) continue;
+        const float* wt = w_tile + (plane_wt[t] * IG_NC) * WP + aoff;
+#pragma unroll
+        for (int cq = 0; cq < IG_NC / 4; ++cq) {
+          float a[CB], bv[4];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) bv[pb] = in_tile[boff[pb] + cq * 4 * chan_elems + t * 256];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+              acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds channels kq*4 + r of pixel j of each 16x16 tile ----------------------
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) {
+    size_t opix;
+    if (MODE == MODE_D) {
+      const int px = px0 + wave * 64 + pb * 16 + j;
+      if (px >= static_cast<int>(HW)) continue;
+      opix = static_cast<size_t>(od) * HW + px;
+    } else {
+      int oy = ty0 + wave * 2 + (pb >> 1), ox = tx0 + (pb & 1) * 16 + j;
+      if (MODE == MODE_HWT) {
+        if (oy >= p.H || ox >= p.W) continue;
+        oy = 2 * oy + pa; ox = 2 * ox + pbit;
+      } else if (oy >= p.Ho || ox >= p.Wo) continue;
+      opix = (static_cast<size_t>(od) * p.Ho + oy) * p.Wo + ox;
+    }
+    float* yb = y + static_cast<size_t>(b) * p.out_bstride + opix;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + cb * 16 + kq * 4 + r;
+        if (co < p.Cout) yb[static_cast<size_t>(co) * p.out_cstride] = apply_act(acc[cb][pb][r] * scale[co] + shift[co], p.act, p.act_param);
+      }
+  }
+}
+
+template <int MODE, int KT, bool S2>
+int launch_ig(const float* x, const float* w, const float* scale, const float* shift, float* y, IG p, int B,
+              int grid_x, int grid_y, hipStream_t st) {
+  // widest channel block that still leaves enough workgroups to fill the chip
+  const int need = (p.Cout + 15) / 16;                 // 16-channel blocks
+  int cb = need >= 4 ? 4 : (need >= 2 ? 2 : 1);
+  auto groups = [&](int c) { return (need + c - 1) / c; };
+  while (cb > 1 && static_cast<long long>(grid_x) * grid_y * B * groups(cb) < 2 * ts::kNumCU) cb >>= 1;
+  p.co_groups = groups(cb);
+  int chan;
+  if (MODE == MODE_D) chan = KT * 256;
+  else if (MODE == MODE_HWT) chan = 9 * 33;
+  else chan = (7 * p.stride + 2 * p.dil + 1) * ((31 * p.stride + 2 * p.dil + 1) | 1);
+  chan += (16 - (chan & 31)) & 31;
+  const int wp = (cb * 16) | 16;
+  const size_t lds = (static_cast<size_t>(IG_NC) * chan + static_cast<size_t>(KT) * IG_NC * wp) * sizeof(float);
+  const dim3 grid(grid_x, grid_y, B * p.co_groups);
+  if (lds > 64 * 1024) {
+    if (cb == 4) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<4, MODE, KT, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    else if (cb == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<2, MODE, KT, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<1, MODE, KT, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  }
+  if (cb == 4) hipLaunchKernelGGL((ig_conv_kernel<4, MODE, KT, S2>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  else if (cb == 2) hipLaunchKernelGGL((ig_conv_kernel<2, MODE, KT, S2>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  else hipLaunchKernelGGL((ig_conv_kernel<1, MODE, KT, S2>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  return ts::launched("ig_conv_kernel");
+}
+
 struct ConvD {
   int B, Cin, Cout, Din, Dout, HW;
   int k, stride, dil, pad;     // along D
@@ -257,34 +572,45 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw: non-positive size");
   TS_REQUIRE(stride == 1 || stride == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: stride must be 1 or 2");
   TS_REQUIRE(dilation == 1 || dilation == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: dilation must be 1 or 2");
+  TS_REQUIRE(!(stride == 2 && dilation == 2), TS_ERR_UNSUPPORTED, "conv3d_hw: stride 2 with dilation 2");
   TS_REQUIRE(!transposed || (stride == 2 && dilation == 1), TS_ERR_UNSUPPORTED, "conv3d_hw: transposed form is stride 2, dilation 1");
   TS_REQUIRE(act >= 0 && act <= 3, TS_ERR_SHAPE, "conv3d_hw: unknown activation");
-  TS_REQUIRE(B <= 65535 && D <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw: grid too large");
+  TS_REQUIRE(D <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw: grid too large");
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(scale); TS_REQUIRE_PTR(shift); TS_REQUIRE_PTR(y);
   const int bucket = cout_bucket(Cout);
   TS_REQUIRE(bucket > 0, TS_ERR_UNSUPPORTED, "conv3d_hw: Cout=%d > 64", Cout);
-  ConvHW p;
-  p.B = B; p.Cin = Cin; p.Cout = Cout; p.D = D; p.H = H; p.W = W;
-  p.stride = stride; p.dil = dilation; p.pad = dilation; p.act = act; p.act_param = act_param;
-  p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   hipStream_t st = ts::as_stream(stream);
+  if (bucket == 1) {            // single-channel heads: vector-ALU direct form
+    TS_REQUIRE(!transposed && B <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw: Cout=1 supports the forward form only");
+    ConvHW q;
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.D = D; q.H = H; q.W = W;
+    q.stride = stride; q.dil = dilation; q.pad = dilation; q.act = act; q.act_param = act_param;
+    q.in_bstride = in_bstride; q.in_cstride = in_cstride; q.out_bstride = out_bstride; q.out_cstride = out_cstride;
+    q.Ho = (H - 1) / stride + 1; q.Wo = (W - 1) / stride + 1;
+    const int tiles = ((q.Ho + TILE_Y - 1) / TILE_Y) * ((q.Wo + TILE_X - 1) / TILE_X);
+    const int in_rows = (TILE_Y - 1) * stride + 2 * dilation + 1;
+    const int in_cols_p = ((TILE_X - 1) * stride + 2 * dilation + 1) | 1;
+    const size_t lds_bytes = static_cast<size_t>(CI_CHUNK) * in_rows * in_cols_p * sizeof(float);
+    hipLaunchKernelGGL(conv_hw_kernel<1>, dim3(tiles, D, B), dim3(256), lds_bytes, st, x, w_t, scale, shift, y, q);
+    return ts::launched("conv_hw_kernel");
+  }
+  IG p;
+  p.Cin = Cin; p.Cout = Cout; p.coutp = bucket; p.D = D; p.H = H; p.W = W; p.Do = D;
+  p.stride = stride; p.dil = dilation; p.pad = dilation; p.k = 3; p.transposed = transposed;
+  p.act = act; p.act_param = act_param;
+  p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
+  p.co_groups = 1;
   if (transposed) {
     p.Ho = 2 * H; p.Wo = 2 * W;
-    int blocks = (p.Ho * p.Wo + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    const dim3 grid(blocks, D, B);
-    TS_DISPATCH_COUT(bucket, deconv_hw_kernel, grid, dim3(256), 0, st, x, w_t, scale, shift, y, p);
-    return ts::launched("deconv_hw_kernel");
+    p.tiles_x = (W + 31) / 32;
+    const int tiles = ((H + 7) / 8) * p.tiles_x;
+    return launch_ig<MODE_HWT, 9, false>(x, w_t, scale, shift, y, p, B, tiles * 4, D, st);
   }
-  p.Ho = (H + 2 * p.pad - 2 * dilation - 1) / stride + 1;
-  p.Wo = (W + 2 * p.pad - 2 * dilation - 1) / stride + 1;
-  const int tiles = ((p.Ho + TILE_Y - 1) / TILE_Y) * ((p.Wo + TILE_X - 1) / TILE_X);
-  const int in_rows = (TILE_Y - 1) * stride + 2 * dilation + 1;
-  const int in_cols_p = ((TILE_X - 1) * stride + 2 * dilation + 1) | 1;
-  const size_t lds_bytes = static_cast<size_t>(CI_CHUNK) * in_rows * in_cols_p * sizeof(float);
-  const dim3 grid(tiles, D, B);
-  TS_DISPATCH_COUT(bucket, conv_hw_kernel, grid, dim3(256), lds_bytes, st, x, w_t, scale, shift, y, p);
-  return ts::launched("conv_hw_kernel");
+  p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
+  p.tiles_x = (p.Wo + 31) / 32;
+  const int tiles = ((p.Ho + 7) / 8) * p.tiles_x;
+  if (stride == 2) return launch_ig<MODE_HW, 9, true>(x, w_t, scale, shift, y, p, B, tiles, D, st);
+  return launch_ig<MODE_HW, 9, false>(x, w_t, scale, shift, y, p, B, tiles, D, st);
 }
 
 // x [B,Cin,Din,H,W] -> y [B,Cout,Dout,H,W]; w_t is [Cin][k][CoutPad].  k in {1,3,5}.  transposed != 0:
@@ -303,22 +629,31 @@ extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* sc
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(scale); TS_REQUIRE_PTR(shift); TS_REQUIRE_PTR(y);
   const int bucket = cout_bucket(Cout);
   TS_REQUIRE(bucket > 0, TS_ERR_UNSUPPORTED, "conv3d_d: Cout=%d > 64", Cout);
-  ConvD p;
-  p.B = B; p.Cin = Cin; p.Cout = Cout; p.Din = Din; p.HW = H * W;
-  p.k = k; p.stride = stride; p.dil = dilation; p.pad = padding; p.act = act; p.act_param = act_param;
-  p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
-  p.Dout = transposed ? 2 * Din : (Din + 2 * padding - dilation * (k - 1) - 1) / stride + 1;
-  TS_REQUIRE(p.Dout > 0 && p.Dout <= 65535 && B <= 65535, TS_ERR_SHAPE, "conv3d_d: bad output depth");
-  int blocks = (p.HW + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  const dim3 grid(blocks, p.Dout, B);
+  const int Dout = transposed ? 2 * Din : (Din + 2 * padding - dilation * (k - 1) - 1) / stride + 1;
+  TS_REQUIRE(Dout > 0 && Dout <= 65535, TS_ERR_SHAPE, "conv3d_d: bad output depth");
   hipStream_t st = ts::as_stream(stream);
-  if (transposed) {
-    TS_DISPATCH_COUT(bucket, deconv_d_kernel, grid, dim3(256), 0, st, x, w_t, scale, shift, y, p);
-    return ts::launched("deconv_d_kernel");
+  if (bucket == 1) {
+    TS_REQUIRE(B <= 65535, TS_ERR_UNSUPPORTED, "conv3d_d: batch too large");
+    ConvD q;
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.Din = Din; q.HW = H * W; q.Dout = Dout;
+    q.k = k; q.stride = stride; q.dil = dilation; q.pad = padding; q.act = act; q.act_param = act_param;
+    q.in_bstride = in_bstride; q.in_cstride = in_cstride; q.out_bstride = out_bstride; q.out_cstride = out_cstride;
+    int blocks = (q.HW + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (transposed) hipLaunchKernelGGL(deconv_d_kernel<1>, dim3(blocks, Dout, B), dim3(256), 0, st, x, w_t, scale, shift, y, q);
+    else hipLaunchKernelGGL(conv_d_kernel<1>, dim3(blocks, Dout, B), dim3(256), 0, st, x, w_t, scale, shift, y, q);
+    return ts::launched("conv_d_kernel");
   }
-  TS_DISPATCH_COUT(bucket, conv_d_kernel, grid, dim3(256), 0, st, x, w_t, scale, shift, y, p);
-  return ts::launched("conv_d_kernel");
+  IG p;
+  p.Cin = Cin; p.Cout = Cout; p.coutp = bucket; p.D = Din; p.H = H; p.W = W; p.Do = Dout; p.Ho = H; p.Wo = W;
+  p.stride = stride; p.dil = dilation; p.pad = padding; p.k = k; p.transposed = transposed;
+  p.act = act; p.act_param = act_param;
+  p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
+  p.tiles_x = 1; p.co_groups = 1;
+  const int tiles = (H * W + 255) / 256;
+  if (k == 1) return launch_ig<MODE_D, 1, false>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
+  if (k == 3) return launch_ig<MODE_D, 3, false>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
+  return launch_ig<MODE_D, 5, false>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
 }
 
 extern "C" int ts_conv_cout_pad(int cout) { return cout_bucket(cout); }

@@ -316,9 +316,10 @@ class NativePrecise(_LevelBase):
     def _c2d(x, f, stride, out=None):
         return conv_hw(x, f, stride, 1, out=out)
 
-    def encode(self, img, cat4):
-        """UNet.encoder for one image; the 1/4 feature goes straight into its slice of `cat4`."""
-        x = self._c2d(img.unsqueeze(2), self.enc[0], self.enc_stride[0])
+    def encode(self, imgs, cat4):
+        """UNet.encoder (module.py:459-466) for the left and right images at once (stacked on the batch
+        axis); the 1/4 features go straight into their channel slice of `cat4`."""
+        x = self._c2d(imgs.unsqueeze(2), self.enc[0], self.enc_stride[0])
         s2 = self._c2d(x, self.enc[1], self.enc_stride[1])
         x = self._c2d(s2, self.enc[2], self.enc_stride[2])
         self._c2d(x, self.enc[3], self.enc_stride[3], out=cat4[:, self.in_planes:].unsqueeze(2))
@@ -332,11 +333,11 @@ class NativePrecise(_LevelBase):
 
     def __call__(self, left, right, low, high, left_image, right_image, prev_info):
         B, Cf, H, W = left.shape
-        lcat = torch.empty((B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)
-        rcat = torch.empty_like(lcat)
+        both = torch.empty((2 * B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)   # [left | right] x [feat | spx4]
+        lcat, rcat = both[:B], both[B:]
         lcat[:, :Cf].copy_(left); rcat[:, :Cf].copy_(right)
-        s2l = self.encode(left_image, lcat)
-        self.encode(right_image, rcat)
+        s2 = self.encode(torch.cat([left_image, right_image], dim=0), both)
+        s2l = s2[:B]
         ds = _candidates(low, high).contiguous()
         raw = TF.block_cost(lcat, rcat, ds, self.scales)
         cost, off = self.heads(self.init3d(raw))

@@ -304,22 +304,25 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     __syncthreads();
     if (c0 + IG_NC < p.Cin) fetch(c0 + IG_NC);          // next chunk in flight under the MFMAs below
     if (MODE == MODE_HW) {
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky) {                 // rolled: keeps the fragment registers of one tap row live
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int toff = (t / 3) * p.dil * pitch + (t % 3) * p.dil;
-        const float* wt = w_tile + (t * IG_NC) * WP + aoff;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int toff = ky * p.dil * pitch + kx * p.dil;
+          const float* wt = w_tile + ((ky * 3 + kx) * IG_NC) * WP + aoff;
 #pragma unroll
-        for (int cq = 0; cq < IG_NC / 4; ++cq) {
-          float a[CB], bv[4];
+          for (int cq = 0; cq < IG_NC / 4; ++cq) {
+            float a[CB], bv[4];
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
+            for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
 #pragma unroll
-          for (int pb = 0; pb < 4; ++pb) bv[pb] = in_tile[boff[pb] + cq * 4 * chan_elems + toff];
+            for (int pb = 0; pb < 4; ++pb) bv[pb] = in_tile[boff[pb] + cq * 4 * chan_elems + toff];
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
+            for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb)
-              acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+              for (int pb = 0; pb < 4; ++pb)
+                acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+          }
         }
       }
     } else if (MODE == MODE_HWT) {

@@ -25,6 +25,10 @@ import os
 import sys
 import time
 
+# the one framework pass this script makes (BatchNorm calibration) should not trigger MIOpen's
+# exhaustive solver search (seconds of naive-kernel benchmarking that would drown a profile)
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+
 import numpy as np
 import torch
 
@@ -250,8 +254,16 @@ def main():
             ach = nbytes / k1_times[pkey]
             all_b = sum(k1_algorithmic_bytes(*k) for k in k1_times)
             all_t = sum(k1_times.values())
+            traffic = None
+            try:    # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected in-process)
+                with open(os.path.join(ROOT, "profiles", "r01_k1_hbm_traffic_pmc.json")) as fh:
+                    pm = json.load(fh)
+                if list(pm["workload_key"]) == list(pkey):
+                    traffic = pm["hbm_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = dict(bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
-                            traffic=None,
+                            traffic=traffic,
                             measured="HIP events on the launch stream around the C-ABI call, %d back-to-back "
                                      "launches on the pipeline's own tensors right after the timed steps" % max(a.steps, 20),
                             kernel="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample) on "

@@ -1,6 +1,6 @@
 """Deterministic synthetic inputs shared by tools/gen_golden.py (reference side, build container)
 and the tests / bench (product side).  Pure numpy `RandomState` (frozen legacy stream) so the
-same seed gives the same bytes on every machine; nothing is read from /root/reference.
+same seed gives the same bytes on every machine; nothing is read from the reference checkout.
 
 Shapes follow SURVEY.md section 8(d): unit-variance, spatially smooth features at 1/4, 1/8, 1/16 of
 the run resolution (low-passed N(0,1), see `smooth`), images likewise, weights by the reference initialiser's distribution

@@ -146,19 +146,21 @@ struct IG {
   int tiles_x, co_groups;
 };
 
-template <int MODE, bool S2>
+template <int MODE, int ST>
 struct StageGeom {                       // rows / column-groups each thread stages per channel
-  static constexpr int RR = (MODE == MODE_D) ? 1 : (S2 ? 5 : 3);
-  static constexpr int QC = (MODE == MODE_D) ? 1 : (S2 ? 2 : 1);
+  static constexpr int RR = (MODE == MODE_D) ? 1 : (ST == 2 ? 5 : 3);
+  static constexpr int QC = (MODE == MODE_D) ? 1 : (ST == 2 ? 2 : 1);
 };
 
-template <int CB, int MODE, int KT, bool S2>
+// ST / DL: stride and dilation of MODE_HW as compile-time constants, so that every LDS fragment read is
+// `base register + immediate` (no address arithmetic between MFMAs).
+template <int CB, int MODE, int KT, int ST, int DL>
 __global__ void __launch_bounds__(256)
 ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                const float* __restrict__ shift, float* __restrict__ y, const IG p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WP = (CB * 16) | 16;                  // weight row pitch (k-slots on disjoint banks)
-  constexpr int RR = StageGeom<MODE, S2>::RR, QC = StageGeom<MODE, S2>::QC;
+  constexpr int RR = StageGeom<MODE, ST>::RR, QC = StageGeom<MODE, ST>::QC;
   constexpr int NTR = (MODE == MODE_D) ? KT : 1;      // planes staged per channel (MODE_D: one per tap)
   constexpr int RWN = (KT * IG_NC * CB * 16 + 255) / 256;
 
@@ -171,19 +173,20 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   // ---- geometry of this workgroup -------------------------------------------------------------
   int tile = blockIdx.x, pa = 0, pbit = 0;
   if (MODE == MODE_HWT) { pa = (tile & 3) >> 1; pbit = tile & 1; tile >>= 2; }
-  int in_rows = 1, in_cols = 256, pitch = 256, iy0 = 0, ix0 = 0, ty0 = 0, tx0 = 0;
+  constexpr int in_rows = (MODE == MODE_HW) ? 7 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 10 : 9) : 1);
+  constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 34 : 33) : 256);
+  constexpr int pitch = (MODE == MODE_D) ? 256 : (in_cols | 1);
+  constexpr int chan_raw = (MODE == MODE_D) ? NTR * 256 : in_rows * pitch;
+  constexpr int chan_elems = chan_raw + ((16 - (chan_raw & 31)) & 31);       // == 16 (mod 32)
+  int iy0 = 0, ix0 = 0, ty0 = 0, tx0 = 0;
   if (MODE == MODE_HW) {
     ty0 = (tile / p.tiles_x) * 8; tx0 = (tile % p.tiles_x) * 32;
-    in_rows = 7 * p.stride + 2 * p.dil + 1; in_cols = 31 * p.stride + 2 * p.dil + 1;
-    pitch = in_cols | 1;
-    iy0 = ty0 * p.stride - p.pad; ix0 = tx0 * p.stride - p.pad;
+    iy0 = ty0 * ST - DL; ix0 = tx0 * ST - DL;                              // padding == dilation
   } else if (MODE == MODE_HWT) {
+    // KT == 9 : k3 s2 p1 op1, taps reach rows/cols {0,+1};  KT == 16: k4 s2 p1, taps reach {-1,0,+1}
     ty0 = (tile / p.tiles_x) * 8; tx0 = (tile % p.tiles_x) * 32;
-    in_rows = 9; in_cols = 33; pitch = 33;
-    iy0 = ty0; ix0 = tx0;
+    iy0 = ty0 - ((KT == 16) ? 1 : 0); ix0 = tx0 - ((KT == 16) ? 1 : 0);
   }
-  int chan_elems = (MODE == MODE_D) ? NTR * 256 : in_rows * pitch;
-  chan_elems += (16 - (chan_elems & 31)) & 31;         // == 16 (mod 32)
   float* in_tile = lds;
   float* w_tile = lds + IG_NC * chan_elems;            // [KT][IG_NC][WP]
   const size_t HW = static_cast<size_t>(p.H) * p.W;
@@ -221,7 +224,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     if (MODE == MODE_D) boff[pb] = kq * chan_elems + wave * 64 + pb * 16 + j;
     else {
       const int row = wave * 2 + (pb >> 1), col = (pb & 1) * 16 + j;
-      const int st = (MODE == MODE_HW) ? p.stride : 1;
+      constexpr int st = (MODE == MODE_HW) ? ST : 1;
       boff[pb] = kq * chan_elems + row * st * pitch + col * st;
     }
   }
@@ -304,11 +307,11 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     __syncthreads();
     if (c0 + IG_NC < p.Cin) fetch(c0 + IG_NC);          // next chunk in flight under the MFMAs below
     if (MODE == MODE_HW) {
-#pragma unroll 1
-      for (int ky = 0; ky < 3; ++ky) {                 // rolled: keeps the fragment registers of one tap row live
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const int toff = ky * p.dil * pitch + kx * p.dil;
+          const int toff = ky * DL * pitch + kx * DL;
           const float* wt = w_tile + ((ky * 3 + kx) * IG_NC) * WP + aoff;
 #pragma unroll
           for (int cq = 0; cq < IG_NC / 4; ++cq) {
@@ -326,17 +329,22 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
         }
       }
     } else if (MODE == MODE_HWT) {
-      // parity (pa, pbit): rows use (ky=1,dy=0) | (ky=2,dy=0),(ky=0,dy=1); same for columns
+      // output parity (pa, pbit) selects which kernel taps land on input pixels:
+      //   k3 s2 p1 (KT 9):  even -> (k=1, d=0);            odd -> (k=2, d=0), (k=0, d=+1)
+      //   k4 s2 p1 (KT 16): even -> (k=1, d=0), (k=3, d=-1); odd -> (k=2, d=0), (k=0, d=+1)
+      constexpr int KS = (KT == 16) ? 4 : 3, ORG = (KT == 16) ? 1 : 0;
 #pragma unroll
       for (int ta = 0; ta < 2; ++ta) {
-        if (ta > pa) continue;
-        const int ky = pa ? (ta ? 0 : 2) : 1, dy = ta;
+        int ky, dy;
+        if (pa) { ky = ta ? 0 : 2; dy = ta ? 1 : 0; }
+        else { if (ta && KT != 16) continue; ky = ta ? 3 : 1; dy = ta ? -1 : 0; }
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-          if (tb > pbit) continue;
-          const int kx = pbit ? (tb ? 0 : 2) : 1, dx = tb;
-          const int toff = dy * pitch + dx;
-          const float* wt = w_tile + ((ky * 3 + kx) * IG_NC) * WP + aoff;
+          int kx, dx;
+          if (pbit) { kx = tb ? 0 : 2; dx = tb ? 1 : 0; }
+          else { if (tb && KT != 16) continue; kx = tb ? 3 : 1; dx = tb ? -1 : 0; }
+          const int toff = (dy + ORG) * pitch + dx + ORG;
+          const float* wt = w_tile + ((ky * KS + kx) * IG_NC) * WP + aoff;
 #pragma unroll
           for (int cq = 0; cq < IG_NC / 4; ++cq) {
             float a[CB], bv[4];
@@ -401,31 +409,31 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   }
 }
 
-template <int MODE, int KT, bool S2>
+template <int MODE, int KT, int ST, int DL>
 int launch_ig(const float* x, const float* w, const float* scale, const float* shift, float* y, IG p, int B,
               int grid_x, int grid_y, hipStream_t st) {
   // widest channel block that still leaves enough workgroups to fill the chip
   const int need = (p.Cout + 15) / 16;                 // 16-channel blocks
   int cb = need >= 4 ? 4 : (need >= 2 ? 2 : 1);
   auto groups = [&](int c) { return (need + c - 1) / c; };
-  while (cb > 1 && static_cast<long long>(grid_x) * grid_y * B * groups(cb) < 2 * ts::kNumCU) cb >>= 1;
+  while (cb > 1 && static_cast<long long>(grid_x) * grid_y * B * groups(cb) < ts::kNumCU + ts::kNumCU / 2) cb >>= 1;
   p.co_groups = groups(cb);
   int chan;
   if (MODE == MODE_D) chan = KT * 256;
-  else if (MODE == MODE_HWT) chan = 9 * 33;
-  else chan = (7 * p.stride + 2 * p.dil + 1) * ((31 * p.stride + 2 * p.dil + 1) | 1);
+  else if (MODE == MODE_HWT) chan = (KT == 16) ? 10 * 35 : 9 * 33;
+  else chan = (7 * ST + 2 * DL + 1) * ((31 * ST + 2 * DL + 1) | 1);
   chan += (16 - (chan & 31)) & 31;
   const int wp = (cb * 16) | 16;
   const size_t lds = (static_cast<size_t>(IG_NC) * chan + static_cast<size_t>(KT) * IG_NC * wp) * sizeof(float);
   const dim3 grid(grid_x, grid_y, B * p.co_groups);
   if (lds > 64 * 1024) {
-    if (cb == 4) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<4, MODE, KT, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    else if (cb == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<2, MODE, KT, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<1, MODE, KT, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (cb == 4) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<4, MODE, KT, ST, DL>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    else if (cb == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<2, MODE, KT, ST, DL>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<1, MODE, KT, ST, DL>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   }
-  if (cb == 4) hipLaunchKernelGGL((ig_conv_kernel<4, MODE, KT, S2>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
-  else if (cb == 2) hipLaunchKernelGGL((ig_conv_kernel<2, MODE, KT, S2>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
-  else hipLaunchKernelGGL((ig_conv_kernel<1, MODE, KT, S2>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  if (cb == 4) hipLaunchKernelGGL((ig_conv_kernel<4, MODE, KT, ST, DL>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  else if (cb == 2) hipLaunchKernelGGL((ig_conv_kernel<2, MODE, KT, ST, DL>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  else hipLaunchKernelGGL((ig_conv_kernel<1, MODE, KT, ST, DL>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
   return ts::launched("ig_conv_kernel");
 }
 
@@ -607,13 +615,14 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
     p.Ho = 2 * H; p.Wo = 2 * W;
     p.tiles_x = (W + 31) / 32;
     const int tiles = ((H + 7) / 8) * p.tiles_x;
-    return launch_ig<MODE_HWT, 9, false>(x, w_t, scale, shift, y, p, B, tiles * 4, D, st);
+    return launch_ig<MODE_HWT, 9, 1, 1>(x, w_t, scale, shift, y, p, B, tiles * 4, D, st);
   }
   p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
   p.tiles_x = (p.Wo + 31) / 32;
   const int tiles = ((p.Ho + 7) / 8) * p.tiles_x;
-  if (stride == 2) return launch_ig<MODE_HW, 9, true>(x, w_t, scale, shift, y, p, B, tiles, D, st);
-  return launch_ig<MODE_HW, 9, false>(x, w_t, scale, shift, y, p, B, tiles, D, st);
+  if (stride == 2) return launch_ig<MODE_HW, 9, 2, 1>(x, w_t, scale, shift, y, p, B, tiles, D, st);
+  if (dilation == 2) return launch_ig<MODE_HW, 9, 1, 2>(x, w_t, scale, shift, y, p, B, tiles, D, st);
+  return launch_ig<MODE_HW, 9, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, D, st);
 }
 
 // x [B,Cin,Din,H,W] -> y [B,Cout,Dout,H,W]; w_t is [Cin][k][CoutPad].  k in {1,3,5}.  transposed != 0:
@@ -654,9 +663,27 @@ extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* sc
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   p.tiles_x = 1; p.co_groups = 1;
   const int tiles = (H * W + 255) / 256;
-  if (k == 1) return launch_ig<MODE_D, 1, false>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
-  if (k == 3) return launch_ig<MODE_D, 3, false>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
-  return launch_ig<MODE_D, 5, false>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
+  if (k == 1) return launch_ig<MODE_D, 1, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
+  if (k == 3) return launch_ig<MODE_D, 3, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
+  return launch_ig<MODE_D, 5, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
+}
+
+// ConvTranspose2d(kernel 4, stride 2, padding 1) of UNet (module.py:453-457): x [B,Cin,H,W] -> y [B,Cout,2H,2W]
+// (y may be a channel slice: out_bstride in elements); w_t [Cin][4][4][CoutPad], CoutPad = 16 | 32.
+extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                                    int B, int Cin, int Cout, int H, int W, int act, long long out_bstride, void* stream) {
+  TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "deconv2d: non-positive size");
+  TS_REQUIRE(Cout <= 32, TS_ERR_UNSUPPORTED, "deconv2d: Cout=%d > 32", Cout);
+  TS_REQUIRE(act >= 0 && act <= 2, TS_ERR_SHAPE, "deconv2d: unknown activation");
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(scale); TS_REQUIRE_PTR(shift); TS_REQUIRE_PTR(y);
+  IG p;
+  p.Cin = Cin; p.Cout = Cout; p.coutp = Cout <= 16 ? 16 : 32; p.D = 1; p.H = H; p.W = W; p.Do = 1; p.Ho = 2 * H; p.Wo = 2 * W;
+  p.stride = 2; p.dil = 1; p.pad = 1; p.k = 4; p.transposed = 1; p.act = act; p.act_param = 0.f;
+  p.in_bstride = static_cast<long long>(Cin) * H * W; p.in_cstride = static_cast<long long>(H) * W;
+  p.out_bstride = out_bstride; p.out_cstride = 4ll * H * W;
+  p.tiles_x = (W + 31) / 32; p.co_groups = 1;
+  const int tiles = ((H + 7) / 8) * p.tiles_x;
+  return launch_ig<MODE_HWT, 16, 1, 1>(x, w_t, scale, shift, y, p, B, tiles * 4, 1, ts::as_stream(stream));
 }
 
 extern "C" int ts_conv_cout_pad(int cout) { return cout_bucket(cout); }

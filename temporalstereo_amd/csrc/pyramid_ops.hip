@@ -6,7 +6,6 @@
 //   merge_candidates past_conv + cat + sort + gather along D (coarse.py:84-105, fine.py:105-122)
 //   convex_upsample  softmax-over-9 weighted x2 upsampling (ConvexUpsample.forward, module.py:336-353)
 //   unet_upsample    softmax-over-9 weighted x4 upsampling (UNet.upsample, module.py:468-482)
-//   deconv2d_k4s2    ConvTranspose2d(kernel 4, stride 2, padding 1) (UNet.deconv4/deconv2, module.py:453-457)
 //   resize_bilinear  F.interpolate(bilinear, align_corners) with a value scale (memory resizes,
 //                    coarse.py:91-96, precise.py:100-103, projects/TemporalStereo/TemporalStereo.py:305-309)
 //
@@ -145,12 +144,15 @@ struct Merge {
 // Appendix B.2), write the sorted disparities, and move each candidate's C-channel column of the
 // volume to its sorted slot.  Memory candidates get their volume from past_conv:
 // Conv3d(1->C, 1x1x1, no bias) + BatchNorm + SiLU of the remembered cost (coarse.py:42,98).
+constexpr int MERGE_CPB = 4;    // channels moved per workgroup row (grid.y walks channel groups)
+
 __global__ void __launch_bounds__(256)
 merge_candidates_kernel(const float* __restrict__ vol, const float* __restrict__ samp, const float* __restrict__ mem_samp,
                         const float* __restrict__ mem_cost, const float* __restrict__ pw, const float* __restrict__ pscale,
                         const float* __restrict__ pshift, float* __restrict__ out_samp, float* __restrict__ out_vol,
                         const Merge p) {
   const int DT = p.D0 + p.K;
+  const int c0 = blockIdx.y * MERGE_CPB;
   const long long n = static_cast<long long>(p.B) * p.HW;
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
@@ -171,14 +173,22 @@ merge_candidates_kernel(const float* __restrict__ vol, const float* __restrict__
 #pragma unroll
       for (int q = 0; q < MERGE_DMAX; ++q)
         if (q < DT) rank += (s[q] < s[j]) || (s[q] == s[j] && q < j);
-      out_samp[(static_cast<size_t>(b) * DT + rank) * p.HW + px] = s[j];
+      if (c0 == 0) out_samp[(static_cast<size_t>(b) * DT + rank) * p.HW + px] = s[j];
       float* ov = out_vol + static_cast<size_t>(b) * p.out_bstride + static_cast<size_t>(rank) * p.HW + px;
       if (j < p.D0) {
         const float* iv = vol + static_cast<size_t>(b) * p.vol_bstride + static_cast<size_t>(j) * p.HW + px;
-        for (int c = 0; c < p.C; ++c) ov[static_cast<size_t>(c) * p.out_cstride] = iv[static_cast<size_t>(c) * p.vol_cstride];
+#pragma unroll
+        for (int cc = 0; cc < MERGE_CPB; ++cc) {
+          const int c = c0 + cc;
+          if (c < p.C) ov[static_cast<size_t>(c) * p.out_cstride] = iv[static_cast<size_t>(c) * p.vol_cstride];
+        }
       } else {
         const float m = mem_cost ? mem_cost[(static_cast<size_t>(b) * p.K + (j - p.D0)) * p.HW + px] : 0.f;
-        for (int c = 0; c < p.C; ++c) ov[static_cast<size_t>(c) * p.out_cstride] = silu(pw[c] * m * pscale[c] + pshift[c]);
+#pragma unroll
+        for (int cc = 0; cc < MERGE_CPB; ++cc) {
+          const int c = c0 + cc;
+          if (c < p.C) ov[static_cast<size_t>(c) * p.out_cstride] = silu(pw[c] * m * pscale[c] + pshift[c]);
+        }
       }
     }
   }
@@ -254,56 +264,6 @@ unet_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ d
   }
 }
 
-// ------------------------------------------------------------------------------- ConvTranspose2d k4 s2 p1
-// out (2H, 2W): oy = 2 iy - 1 + ky: even oy=2m: (ky=1, iy=m), (ky=3, iy=m-1); odd oy=2m+1: (ky=0, iy=m+1), (ky=2, iy=m).
-// weights [Cin][4][4][CoutPad]
-template <int COUT>
-__global__ void __launch_bounds__(256)
-deconv2d_k4s2_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-                     const float* __restrict__ shift, float* __restrict__ y, int B, int Cin, int Cout, int H, int W, int act,
-                     long long out_bstride) {
-  const int b = blockIdx.z;
-  const int Ho = 2 * H, Wo = 2 * W;
-  const size_t HW = static_cast<size_t>(H) * W;
-  const float* xb = x + static_cast<size_t>(b) * Cin * HW;
-  const int n = Ho * Wo;
-  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
-    const int oy = o / Wo, ox = o - oy * Wo;
-    const int my = oy >> 1, mx = ox >> 1;
-    int iy[2], ky[2], ix[2], kx[2];
-    if ((oy & 1) == 0) { iy[0] = my; ky[0] = 1; iy[1] = my - 1; ky[1] = 3; }
-    else { iy[0] = my + 1; ky[0] = 0; iy[1] = my; ky[1] = 2; }
-    if ((ox & 1) == 0) { ix[0] = mx; kx[0] = 1; ix[1] = mx - 1; kx[1] = 3; }
-    else { ix[0] = mx + 1; kx[0] = 0; ix[1] = mx; kx[1] = 2; }
-    float acc[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-    for (int ci = 0; ci < Cin; ++ci) {
-      const float* xc = xb + static_cast<size_t>(ci) * HW;
-      const float* wc = w + static_cast<size_t>(ci) * 16 * COUT;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        if (iy[a] < 0 || iy[a] >= H) continue;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          if (ix[c] < 0 || ix[c] >= W) continue;
-          const float xv = xc[static_cast<size_t>(iy[a]) * W + ix[c]];
-          const float* wt = wc + (ky[a] * 4 + kx[c]) * COUT;
-#pragma unroll
-          for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[co], xv, acc[co]);
-        }
-      }
-    }
-    float* yb = y + static_cast<size_t>(b) * out_bstride + o;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co)
-      if (co < Cout) {
-        const float v = acc[co] * scale[co] + shift[co];
-        yb[static_cast<size_t>(co) * n] = act == 2 ? fmaxf(v, 0.f) : (act == 1 ? silu(v) : v);
-      }
-  }
-}
-
 // ------------------------------------------------------------------------------- bilinear resize
 __global__ void __launch_bounds__(256)
 resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, int BC, int h, int w, int Ho, int Wo,
@@ -374,7 +334,7 @@ extern "C" int ts_merge_candidates_fwd(const float* volume, const float* sample,
   Merge p;
   p.B = B; p.C = C; p.D0 = D0; p.K = K; p.HW = H * W; p.implicit_samples = sample ? 0 : 1;
   p.vol_bstride = vol_bstride; p.vol_cstride = vol_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
-  hipLaunchKernelGGL(merge_candidates_kernel, dim3(grid_for(static_cast<long long>(B) * H * W, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(merge_candidates_kernel, dim3(grid_for(static_cast<long long>(B) * H * W, 256), (C + MERGE_CPB - 1) / MERGE_CPB), dim3(256), 0,
                      ts::as_stream(stream), volume, sample, mem_sample, mem_cost, past_w, past_scale, past_shift,
                      out_sample, out_volume, p);
   return ts::launched("merge_candidates_kernel");
@@ -396,20 +356,6 @@ extern "C" int ts_unet_upsample_fwd(const float* mask, const float* disp, float*
   hipLaunchKernelGGL(unet_upsample_kernel, dim3(grid_for(static_cast<long long>(B) * Ho * Wo, 256)), dim3(256), 0,
                      ts::as_stream(stream), mask, disp, out, B, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo));
   return ts::launched("unet_upsample_kernel");
-}
-
-extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
-                                    int B, int Cin, int Cout, int H, int W, int act, long long out_bstride, void* stream) {
-  TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "deconv2d: non-positive size");
-  TS_REQUIRE(Cout <= 32, TS_ERR_UNSUPPORTED, "deconv2d: Cout=%d > 32", Cout);
-  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(scale); TS_REQUIRE_PTR(shift); TS_REQUIRE_PTR(y);
-  int blocks = (4 * H * W + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  const dim3 grid(blocks, 1, B);
-  hipStream_t st = ts::as_stream(stream);
-  if (Cout <= 16) hipLaunchKernelGGL(deconv2d_k4s2_kernel<16>, grid, dim3(256), 0, st, x, w_t, scale, shift, y, B, Cin, Cout, H, W, act, out_bstride);
-  else hipLaunchKernelGGL(deconv2d_k4s2_kernel<32>, grid, dim3(256), 0, st, x, w_t, scale, shift, y, B, Cin, Cout, H, W, act, out_bstride);
-  return ts::launched("deconv2d_k4s2_kernel");
 }
 
 extern "C" int ts_resize_bilinear_fwd(const float* x, float* out, int BC, int h, int w, int Ho, int Wo, float value_scale,

@@ -136,7 +136,10 @@ int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const
                      int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
                      int transposed, int act, float act_param,
                      long long in_bstride, long long in_cstride, long long out_bstride,
-                     long long out_cstride, void* stream);
+                     long long out_cstride, void* workspace, size_t workspace_bytes, void* stream);
+/* scratch ts_conv3d_hw_fwd can use to split a long reduction over more workgroups (0 = never splits at
+ * this shape; passing NULL / too little simply disables the split) */
+size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride, int transposed);
 int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
                     int B, int Cin, int Cout, int Din, int H, int W, int k, int stride, int dilation,
                     int padding, int transposed, int act, float act_param,

@@ -95,9 +95,12 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
         out = torch.empty((B, f.cout, D, Ho, Wo), device=x.device, dtype=torch.float32)
     ib, ic = _strides5(x)
     ob, oc = _strides5(out)
-    rc = _lib.lib().ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
-                                     B, Cin, f.cout, D, H, W, stride, dilation, int(transposed),
-                                     f.act if act is None else act, float(act_param), ib, ic, ob, oc, _stream())
+    L = _lib.lib()
+    wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, f.cout, D, H, W, stride, int(transposed)))
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
+    rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
+                            B, Cin, f.cout, D, H, W, stride, dilation, int(transposed),
+                            f.act if act is None else act, float(act_param), ib, ic, ob, oc, _lib.ptr(ws), wsb, _stream())
     _lib.check(rc, "ts_conv3d_hw_fwd")
     return out
 

@@ -133,7 +133,7 @@ conv_hw_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 // ------------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
 enum { MODE_HW = 0, MODE_HWT = 1, MODE_D = 2 };
-constexpr int IG_NC = 8;        // input channels per K chunk
+constexpr int IG_NC_DEFAULT = 8;   // input channels per K chunk (16 for long-K stride-1 layers)
 
 struct IG {
   int Cin, Cout, coutp;         // coutp: padded channel count of the weight / scale / shift arrays
@@ -144,6 +144,9 @@ struct IG {
   float act_param;
   long long in_bstride, in_cstride, out_bstride, out_cstride;
   int tiles_x, co_groups;
+  int ksplit, kspan;            // split-K: this many slices of `kspan` input channels each (partials -> workspace)
+  float* partial;               // [ksplit][B][Cout][Do*Ho*Wo] raw sums when ksplit > 1
+  int B;
 };
 
 template <int MODE, int ST>
@@ -154,7 +157,7 @@ struct StageGeom {                       // rows / column-groups each thread sta
 
 // ST / DL: stride and dilation of MODE_HW as compile-time constants, so that every LDS fragment read is
 // `base register + immediate` (no address arithmetic between MFMAs).
-template <int CB, int MODE, int KT, int ST, int DL>
+template <int CB, int MODE, int KT, int ST, int DL, int IG_NC>
 __global__ void __launch_bounds__(256)
 ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                const float* __restrict__ shift, float* __restrict__ y, const IG p) {
@@ -166,7 +169,9 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
-  const int cog = blockIdx.z % p.co_groups, b = blockIdx.z / p.co_groups;
+  const int cog = blockIdx.z % p.co_groups;
+  const int ks = (blockIdx.z / p.co_groups) % p.ksplit, b = blockIdx.z / (p.co_groups * p.ksplit);
+  const int kbeg = ks * p.kspan, kend = min(p.Cin, kbeg + p.kspan);
   const int co0 = cog * CB * 16;
   const int od = blockIdx.y;
 
@@ -241,7 +246,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   float rin[IG_NC][NTR * RR * QC];
   float rw[RWN];
   auto fetch = [&](int c0) {
-    const int nc = min(IG_NC, p.Cin - c0);
+    const int nc = min(IG_NC, kend - c0);
 #pragma unroll
     for (int c = 0; c < IG_NC; ++c) {
       const float* xc = xb + static_cast<size_t>(c0 + c) * p.in_cstride;
@@ -300,12 +305,12 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     }
   };
 
-  fetch(0);
-  for (int c0 = 0; c0 < p.Cin; c0 += IG_NC) {
+  fetch(kbeg);
+  for (int c0 = kbeg; c0 < kend; c0 += IG_NC) {
     __syncthreads();                  // everyone is done reading the previous chunk
     commit();
     __syncthreads();
-    if (c0 + IG_NC < p.Cin) fetch(c0 + IG_NC);          // next chunk in flight under the MFMAs below
+    if (c0 + IG_NC < kend) fetch(c0 + IG_NC);           // next chunk in flight under the MFMAs below
     if (MODE == MODE_HW) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
@@ -398,6 +403,18 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       } else if (oy >= p.Ho || ox >= p.Wo) continue;
       opix = (static_cast<size_t>(od) * p.Ho + oy) * p.Wo + ox;
     }
+    if (p.ksplit > 1) {          // raw partial sums; conv_splitk_finish applies the epilogue
+      const size_t plane = static_cast<size_t>(p.Do) * p.Ho * p.Wo;
+      float* pb_ = p.partial + (static_cast<size_t>(ks) * p.B + b) * p.Cout * plane + opix;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + cb * 16 + kq * 4 + r;
+          if (co < p.Cout) pb_[static_cast<size_t>(co) * plane] = acc[cb][pb][r];
+        }
+      continue;
+    }
     float* yb = y + static_cast<size_t>(b) * p.out_bstride + opix;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -409,14 +426,31 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   }
 }
 
-template <int MODE, int KT, int ST, int DL>
+// sums the split-K partials in a fixed order (deterministic) and applies scale / shift / activation
+__global__ void __launch_bounds__(256)
+conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ scale, const float* __restrict__ shift,
+                   float* __restrict__ y, int B, int Cout, long long plane, int ksplit, int act, float act_param,
+                   long long out_bstride, long long out_cstride) {
+  const long long n = static_cast<long long>(B) * Cout * plane;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long px = i % plane;
+    const long long t = i / plane;
+    const int co = static_cast<int>(t % Cout), b = static_cast<int>(t / Cout);
+    float v = 0.f;
+    for (int k = 0; k < ksplit; ++k) v += partial[k * n + i];
+    y[b * out_bstride + co * out_cstride + px] = apply_act(v * scale[co] + shift[co], act, act_param);
+  }
+}
+
+template <int MODE, int KT, int ST, int DL, int IG_NC = IG_NC_DEFAULT>
 int launch_ig(const float* x, const float* w, const float* scale, const float* shift, float* y, IG p, int B,
               int grid_x, int grid_y, hipStream_t st) {
   // widest channel block that still leaves enough workgroups to fill the chip
   const int need = (p.Cout + 15) / 16;                 // 16-channel blocks
   int cb = need >= 4 ? 4 : (need >= 2 ? 2 : 1);
   auto groups = [&](int c) { return (need + c - 1) / c; };
-  while (cb > 1 && static_cast<long long>(grid_x) * grid_y * B * groups(cb) < ts::kNumCU + ts::kNumCU / 2) cb >>= 1;
+  while (cb > 1 && static_cast<long long>(grid_x) * grid_y * B * p.ksplit * groups(cb) < ts::kNumCU + ts::kNumCU / 2) cb >>= 1;
   p.co_groups = groups(cb);
   int chan;
   if (MODE == MODE_D) chan = KT * 256;
@@ -425,15 +459,16 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   chan += (16 - (chan & 31)) & 31;
   const int wp = (cb * 16) | 16;
   const size_t lds = (static_cast<size_t>(IG_NC) * chan + static_cast<size_t>(KT) * IG_NC * wp) * sizeof(float);
-  const dim3 grid(grid_x, grid_y, B * p.co_groups);
+  const dim3 grid(grid_x, grid_y, B * p.co_groups * p.ksplit);
+  p.B = B;
   if (lds > 64 * 1024) {
-    if (cb == 4) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<4, MODE, KT, ST, DL>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    else if (cb == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<2, MODE, KT, ST, DL>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<1, MODE, KT, ST, DL>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (cb == 4) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<4, MODE, KT, ST, DL, IG_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    else if (cb == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<2, MODE, KT, ST, DL, IG_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<1, MODE, KT, ST, DL, IG_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   }
-  if (cb == 4) hipLaunchKernelGGL((ig_conv_kernel<4, MODE, KT, ST, DL>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
-  else if (cb == 2) hipLaunchKernelGGL((ig_conv_kernel<2, MODE, KT, ST, DL>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
-  else hipLaunchKernelGGL((ig_conv_kernel<1, MODE, KT, ST, DL>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  if (cb == 4) hipLaunchKernelGGL((ig_conv_kernel<4, MODE, KT, ST, DL, IG_NC>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  else if (cb == 2) hipLaunchKernelGGL((ig_conv_kernel<2, MODE, KT, ST, DL, IG_NC>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  else hipLaunchKernelGGL((ig_conv_kernel<1, MODE, KT, ST, DL, IG_NC>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
   return ts::launched("ig_conv_kernel");
 }
 
@@ -560,6 +595,17 @@ int cout_bucket(int cout) {
   return -1;
 }
 
+// Split-K factor of a (1,3,3) convolution: long reductions on grids too small to fill the chip are cut
+// into slices handled by separate workgroups (partials summed in a fixed order afterwards).
+int conv_hw_ksplit(int B, int Cin, int Cout, int D, int Ho, int Wo) {
+  if (cout_bucket(Cout) < 8) return 1;
+  const long long tiles = static_cast<long long>((Ho + 7) / 8) * ((Wo + 31) / 32) * D * B;
+  const int groups = (Cout + 15) / 16;
+  int ks = 1;
+  while (ks < 8 && tiles * groups * ks < 3 * ts::kNumCU && Cin / (ks * 2) >= 32) ks *= 2;
+  return ks;
+}
+
 }  // namespace
 
 #define TS_DISPATCH_COUT(bucket, KERNEL, ...)                                      \
@@ -579,7 +625,7 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
                                 int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
                                 int transposed, int act, float act_param,
                                 long long in_bstride, long long in_cstride, long long out_bstride,
-                                long long out_cstride, void* stream) {
+                                long long out_cstride, void* workspace, size_t workspace_bytes, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw: non-positive size");
   TS_REQUIRE(stride == 1 || stride == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: stride must be 1 or 2");
   TS_REQUIRE(dilation == 1 || dilation == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: dilation must be 1 or 2");
@@ -610,7 +656,7 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   p.stride = stride; p.dil = dilation; p.pad = dilation; p.k = 3; p.transposed = transposed;
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
-  p.co_groups = 1;
+  p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
   if (transposed) {
     p.Ho = 2 * H; p.Wo = 2 * W;
     p.tiles_x = (W + 31) / 32;
@@ -620,9 +666,25 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
   p.tiles_x = (p.Wo + 31) / 32;
   const int tiles = ((p.Ho + 7) / 8) * p.tiles_x;
-  if (stride == 2) return launch_ig<MODE_HW, 9, 2, 1>(x, w_t, scale, shift, y, p, B, tiles, D, st);
-  if (dilation == 2) return launch_ig<MODE_HW, 9, 1, 2>(x, w_t, scale, shift, y, p, B, tiles, D, st);
-  return launch_ig<MODE_HW, 9, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, D, st);
+  const int ksplit = conv_hw_ksplit(B, Cin, Cout, D, p.Ho, p.Wo);
+  const size_t need = static_cast<size_t>(ksplit) * B * Cout * D * p.Ho * p.Wo * sizeof(float);
+  const bool split = ksplit > 1 && workspace != nullptr && workspace_bytes >= need;
+  if (split) {
+    p.ksplit = ksplit;
+    p.kspan = ((Cin + ksplit - 1) / ksplit + IG_NC_DEFAULT - 1) / IG_NC_DEFAULT * IG_NC_DEFAULT;
+    p.partial = reinterpret_cast<float*>(workspace);
+  }
+  int rc;
+  if (stride == 2) rc = launch_ig<MODE_HW, 9, 2, 1>(x, w_t, scale, shift, y, p, B, tiles, D, st);
+  else if (dilation == 2) rc = launch_ig<MODE_HW, 9, 1, 2>(x, w_t, scale, shift, y, p, B, tiles, D, st);
+  else rc = launch_ig<MODE_HW, 9, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, D, st);
+  if (rc || !split) return rc;
+  const long long plane = static_cast<long long>(D) * p.Ho * p.Wo;
+  long long blocks = (static_cast<long long>(B) * Cout * plane + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv_splitk_finish, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, p.partial, scale, shift, y,
+                     B, Cout, plane, ksplit, act, act_param, out_bstride, out_cstride);
+  return ts::launched("conv_splitk_finish");
 }
 
 // x [B,Cin,Din,H,W] -> y [B,Cout,Dout,H,W]; w_t is [Cin][k][CoutPad].  k in {1,3,5}.  transposed != 0:
@@ -661,7 +723,7 @@ extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* sc
   p.stride = stride; p.dil = dilation; p.pad = padding; p.k = k; p.transposed = transposed;
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
-  p.tiles_x = 1; p.co_groups = 1;
+  p.tiles_x = 1; p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
   const int tiles = (H * W + 255) / 256;
   if (k == 1) return launch_ig<MODE_D, 1, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
   if (k == 3) return launch_ig<MODE_D, 3, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
@@ -681,9 +743,17 @@ extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const floa
   p.stride = 2; p.dil = 1; p.pad = 1; p.k = 4; p.transposed = 1; p.act = act; p.act_param = 0.f;
   p.in_bstride = static_cast<long long>(Cin) * H * W; p.in_cstride = static_cast<long long>(H) * W;
   p.out_bstride = out_bstride; p.out_cstride = 4ll * H * W;
-  p.tiles_x = (W + 31) / 32; p.co_groups = 1;
+  p.tiles_x = (W + 31) / 32; p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
   const int tiles = ((H + 7) / 8) * p.tiles_x;
   return launch_ig<MODE_HWT, 16, 1, 1>(x, w_t, scale, shift, y, p, B, tiles * 4, 1, ts::as_stream(stream));
 }
 
 extern "C" int ts_conv_cout_pad(int cout) { return cout_bucket(cout); }
+
+// bytes of scratch ts_conv3d_hw_fwd can use for split-K at this shape (0: it will not split)
+extern "C" size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride, int transposed) {
+  if (transposed || B <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int ks = conv_hw_ksplit(B, Cin, Cout, D, Ho, Wo);
+  return ks > 1 ? static_cast<size_t>(ks) * B * Cout * D * Ho * Wo * sizeof(float) : 0;
+}

@@ -171,8 +171,13 @@ int ts_unet_upsample_fwd(const float* mask, const float* disp, float* out, int B
                          void* stream);
 int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
                          int B, int Cin, int Cout, int H, int W, int act, long long out_bstride, void* stream);
-int ts_resize_bilinear_fwd(const float* x, float* out, int BC, int h, int w, int Ho, int Wo, float value_scale,
-                           void* stream);
+int ts_resize_bilinear_fwd(const float* x, float* out, int B, int C, int h, int w, int Ho, int Wo, float value_scale,
+                           long long out_bstride, void* stream);
+/* search range of the next level and its five candidates from an upsampled disparity:
+ * low = d - range, high = d + range (aggregation/TemporalStereo/TemporalStereo.py:110,119);
+ * candidates[:, off+i] = |high-low| * {0,3,4,5,8}/8 + min(low,high)  (fine.py:82-87, precise.py:73-78) */
+int ts_range_candidates_fwd(const float* disp, float* low, float* high, float* candidates, int B, int H, int W,
+                            float range, int channel_offset, int channels_total, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement support (no reference counterpart): float4 streams used by bench.py to calibrate

@@ -142,13 +142,28 @@ def pool5(x, out_avg, out_max):
     _lib.check(rc, "ts_pool3d5_avgmax_fwd")
 
 
-def resize_bilinear(x, size, value_scale=1.0):
+def resize_bilinear(x, size, value_scale=1.0, out=None):
+    """F.interpolate(x * value_scale, size, 'bilinear', align_corners=True); `out` may be a channel slice."""
     B, C, h, w = x.shape
-    out = torch.empty((B, C, size[0], size[1]), device=x.device, dtype=torch.float32)
-    rc = _lib.lib().ts_resize_bilinear_fwd(_lib.ptr(x.contiguous()), _lib.ptr(out), B * C, h, w, size[0], size[1],
-                                           float(value_scale), _stream())
+    if out is None:
+        out = torch.empty((B, C, size[0], size[1]), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().ts_resize_bilinear_fwd(_lib.ptr(x.contiguous()), _lib.ptr(out), B, C, h, w, size[0], size[1],
+                                           float(value_scale), out.stride(0), _stream())
     _lib.check(rc, "ts_resize_bilinear_fwd")
     return out
+
+
+def range_candidates(disp, rng, extra_front=0):
+    """(low, high, candidates [B, extra_front + 5, H, W]) of the next level from an upsampled disparity;
+    the first `extra_front` candidate planes are left for the caller (local-map candidates)."""
+    B, _, H, W = disp.shape
+    low = torch.empty_like(disp)
+    high = torch.empty_like(disp)
+    cand = torch.empty((B, extra_front + 5, H, W), device=disp.device, dtype=torch.float32)
+    rc = _lib.lib().ts_range_candidates_fwd(_lib.ptr(disp), _lib.ptr(low), _lib.ptr(high), _lib.ptr(cand), B, H, W,
+                                            float(rng), extra_front, extra_front + 5, _stream())
+    _lib.check(rc, "ts_range_candidates_fwd")
+    return low, high, cand
 
 
 # ------------------------------------------------------------------------------------------- blocks
@@ -292,13 +307,7 @@ def _candidates(low, high):
 
 
 class NativeFine(_MergingLevel):
-    def __call__(self, left, right, low, high, prev_info):
-        ds = _candidates(low, high)
-        lm = prev_info.get('local_map', None)
-        if lm is not None and prev_info.get('local_map_size', 0) > 0:
-            H, W = low.shape[-2:]
-            ds = torch.cat([resize_bilinear(lm, (H, W), W / lm.shape[-1]), ds], dim=1)
-        ds = ds.contiguous()
+    def __call__(self, left, right, ds, prev_info):
         raw = TF.block_cost(left, right, ds, self.scales)
         return self.merge_fuse_predict(self.init3d(raw), ds, prev_info, left, resize_memory=False)
 
@@ -334,14 +343,13 @@ class NativePrecise(_LevelBase):
                                              B, Cin, f.cout, H, W, f.act, out_bstride, _stream())
         _lib.check(rc, "ts_deconv2d_k4s2_fwd")
 
-    def __call__(self, left, right, low, high, left_image, right_image, prev_info):
+    def __call__(self, left, right, ds, left_image, right_image, prev_info):
         B, Cf, H, W = left.shape
         both = torch.empty((2 * B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)   # [left | right] x [feat | spx4]
         lcat, rcat = both[:B], both[B:]
         lcat[:, :Cf].copy_(left); rcat[:, :Cf].copy_(right)
         s2 = self.encode(torch.cat([left_image, right_image], dim=0), both)
         s2l = s2[:B]
-        ds = _candidates(low, high).contiguous()
         raw = TF.block_cost(lcat, rcat, ds, self.scales)
         cost, off = self.heads(self.init3d(raw))
         disp, mem_s, mem_c = TF.topk_softargmax(cost, ds, off, k=self.topk)
@@ -380,11 +388,15 @@ class NativeAggregator:
         r4, r8, r16 = right_feats
         disps, costs, offs, samples, ranges = [], [], [], [], []
         d, c, o, s = self.coarse(l16.contiguous(), r16.contiguous(), prev_info)
-        low, high = d - rng, d + rng
+        lm = prev_info.get('local_map', None)                       # fine.py:89-93: local-map candidates go first
+        nl = lm.shape[1] if (lm is not None and prev_info.get('local_map_size', 0) > 0) else 0
+        low, high, ds = range_candidates(d, rng, nl)
+        if nl:
+            resize_bilinear(lm, d.shape[-2:], d.shape[-1] / lm.shape[-1], out=ds[:, :nl])
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
-        d, c, o, s = self.fine(l8.contiguous(), r8.contiguous(), low, high, prev_info)
-        low, high = d - rng, d + rng
+        d, c, o, s = self.fine(l8.contiguous(), r8.contiguous(), ds, prev_info)
+        low, high, ds = range_candidates(d, rng)
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
-        full, d, c, o, s = self.precise(l4, r4, low, high, left_image.contiguous(), right_image.contiguous(), prev_info)
+        full, d, c, o, s = self.precise(l4, r4, ds, left_image.contiguous(), right_image.contiguous(), prev_info)
         disps += [d, full]; costs.append(c); offs.append(o); samples.append(s)
         return disps[::-1], costs[::-1], samples[::-1], offs[::-1], ranges[::-1], prev_info

@@ -11,15 +11,12 @@
 //   conv_d  : (k,1,1) taps (k = 1,3,5) along D; every pixel column is independent.
 // plus their stride-2 transposed forms.
 //
-// Design (fp32 everywhere -- the parity bar |dEPE| < 1e-3 px is an fp32 bar; f32 MFMA runs at the
-// VALU rate on gfx950, so the matrix cores buy no FLOPs here): direct convolution on the vector
-// ALU with the weights of the current (channel, tap) held in SGPRs -- every lane of a wavefront
-// needs the same Cout weights, so they come through the scalar cache with s_load_dwordxN and feed
-// v_fmac as the scalar operand; a lane owns one output pixel and all Cout accumulators, so each
-// input value fetched from LDS is used Cout times.  Input tiles (+halo) are staged through LDS a
-// chunk of channels at a time with coalesced row loads; stores are row-contiguous.
-// Weights are pre-laid out [Cin][taps][Cout] (Cout contiguous) by the host so one scalar load
-// brings all output channels of a tap.
+// fp32 everywhere (the parity bar |dEPE| < 1e-3 px is an fp32 bar).  A first version ran these as
+// direct convolutions on the vector ALU with the weights in SGPRs (s_load_dwordx16 -> v_fmac with a
+// scalar operand); it stalled on lgkmcnt(0) -- SMEM returns out of order, so every tap waited for
+// its scalar loads AND its LDS read -- and reached 3-15 TFLOP/s.  The implicit-GEMM MFMA kernel
+// below replaced it (6-70 TFLOP/s on the same layers).
+// Weights are pre-laid out [Cin][taps][CoutPad] (output channel contiguous) by the host.
 #include "ts_common.hpp"
 
 namespace {
@@ -33,81 +30,6 @@ __device__ __forceinline__ float apply_act(float v, int act, float p) {
     // PredictionHeads.regress_offset (module.py:384-390): tanh(x/100).clamp(-1,1) * delta
     case ACT_TANH_OFFSET: return fminf(fmaxf(tanhf(v / 100.f), -1.f), 1.f) * p;
     default: return v;
-  }
-}
-
-struct ConvHW {
-  int B, Cin, Cout, D, H, W, Ho, Wo;
-  int stride, dil, pad;        // in H and W
-  int act;
-  float act_param;
-  int in_cstride_planes;       // input channel stride in (D*H*W) planes units == D (dense) ...
-  long long in_bstride, out_bstride;   // elements between batch items (allows channel-sliced views)
-  long long in_cstride, out_cstride;   // elements between channels
-};
-
-constexpr int TILE_Y = 8, TILE_X = 32;     // output pixels per workgroup (256 lanes, x fastest)
-constexpr int CI_CHUNK = 8;
-
-// y[b,co,d,oy,ox] = act( scale[co] * sum_{ci,ky,kx} w[ci][ky][kx][co] * x[b,ci,d,oy*s+ky*dl-p,ox*s+kx*dl-p] + shift[co] )
-template <int COUT>
-__global__ void __launch_bounds__(256)
-conv_hw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-               const float* __restrict__ shift, float* __restrict__ y, const ConvHW p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tiles_x = (p.Wo + TILE_X - 1) / TILE_X;
-  const int tile = blockIdx.x;
-  const int ty0 = (tile / tiles_x) * TILE_Y, tx0 = (tile % tiles_x) * TILE_X;
-  const int d = blockIdx.y, b = blockIdx.z;
-  const int tx = threadIdx.x & (TILE_X - 1), ty = threadIdx.x / TILE_X;
-  const int oy = ty0 + ty, ox = tx0 + tx;
-  const int in_rows = (TILE_Y - 1) * p.stride + 2 * p.dil + 1;
-  const int in_cols = (TILE_X - 1) * p.stride + 2 * p.dil + 1;
-  const int in_cols_p = in_cols | 1;                        // odd row pitch: spreads banks for stride 2
-  const int iy0 = ty0 * p.stride - p.pad, ix0 = tx0 * p.stride - p.pad;
-  const size_t HW = static_cast<size_t>(p.H) * p.W;
-  const float* xb = x + static_cast<size_t>(b) * p.in_bstride + static_cast<size_t>(d) * HW;
-
-  float acc[COUT];
-#pragma unroll
-  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-
-  const int chan_elems = in_rows * in_cols_p;
-  for (int c0 = 0; c0 < p.Cin; c0 += CI_CHUNK) {
-    const int nc = min(CI_CHUNK, p.Cin - c0);
-    __syncthreads();
-    // stage nc channels x in_rows x in_cols (zero outside the image)
-    for (int i = threadIdx.x; i < nc * in_rows * in_cols; i += blockDim.x) {
-      const int cx = i % in_cols;
-      const int r = i / in_cols;
-      const int cy = r % in_rows, c = r / in_rows;
-      const int gy = iy0 + cy, gx = ix0 + cx;
-      float v = 0.f;
-      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-        v = xb[static_cast<size_t>(c0 + c) * p.in_cstride + static_cast<size_t>(gy) * p.W + gx];
-      lds[c * chan_elems + cy * in_cols_p + cx] = v;
-    }
-    __syncthreads();
-    const float* lt = lds + (ty * p.stride) * in_cols_p + tx * p.stride;
-    for (int c = 0; c < nc; ++c) {
-      const float* wc = w + static_cast<size_t>(c0 + c) * 9 * COUT;       // wave-uniform -> scalar loads
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float xv = lt[c * chan_elems + ky * p.dil * in_cols_p + kx * p.dil];
-          const float* wt = wc + (ky * 3 + kx) * COUT;
-#pragma unroll
-          for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[co], xv, acc[co]);
-        }
-    }
-  }
-  if (oy < p.Ho && ox < p.Wo) {
-    float* yb = y + static_cast<size_t>(b) * p.out_bstride + (static_cast<size_t>(d) * p.Ho + oy) * p.Wo + ox;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-      if (co < p.Cout) yb[static_cast<size_t>(co) * p.out_cstride] = apply_act(acc[co] * scale[co] + shift[co], p.act, p.act_param);
-    }
   }
 }
 
@@ -472,125 +394,8 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   return ts::launched("ig_conv_kernel");
 }
 
-struct ConvD {
-  int B, Cin, Cout, Din, Dout, HW;
-  int k, stride, dil, pad;     // along D
-  int act;
-  float act_param;
-  long long in_bstride, out_bstride, in_cstride, out_cstride;
-};
-
-// y[b,co,od,p] = act( scale[co] * sum_{ci,t} w[ci][t][co] * x[b,ci,od*s+t*dl-pad,p] + shift[co] )
-template <int COUT>
-__global__ void __launch_bounds__(256)
-conv_d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-              const float* __restrict__ shift, float* __restrict__ y, const ConvD p) {
-  const int od = blockIdx.y, b = blockIdx.z;
-  const float* xb = x + static_cast<size_t>(b) * p.in_bstride;
-  for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < p.HW; px += gridDim.x * blockDim.x) {
-    float acc[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-    for (int t = 0; t < p.k; ++t) {
-      const int id = od * p.stride + t * p.dil - p.pad;       // uniform
-      if (id < 0 || id >= p.Din) continue;
-      const float* xp = xb + static_cast<size_t>(id) * p.HW + px;
-      for (int ci = 0; ci < p.Cin; ++ci) {
-        const float xv = xp[static_cast<size_t>(ci) * p.in_cstride];
-        const float* wt = w + (static_cast<size_t>(ci) * p.k + t) * COUT;   // uniform -> scalar loads
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[co], xv, acc[co]);
-      }
-    }
-    float* yb = y + static_cast<size_t>(b) * p.out_bstride + static_cast<size_t>(od) * p.HW + px;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co)
-      if (co < p.Cout) yb[static_cast<size_t>(co) * p.out_cstride] = apply_act(acc[co] * scale[co] + shift[co], p.act, p.act_param);
-  }
-}
-
-// ---- transposed, stride 2, kernel 3, padding 1, output_padding 1 (module.py:248-258) ---------------
-// H,W form: out is (2H, 2W).  out[oy] draws from ky with (oy + 1 - ky) even: even oy -> ky=1, iy=oy/2;
-// odd oy -> ky=0 (iy=(oy+1)/2, valid if < H) and ky=2 (iy=(oy-1)/2).  Weight layout [Cin][ky][kx][Cout].
-template <int COUT>
-__global__ void __launch_bounds__(256)
-deconv_hw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-                 const float* __restrict__ shift, float* __restrict__ y, const ConvHW p) {
-  const int d = blockIdx.y, b = blockIdx.z;
-  const size_t HW = static_cast<size_t>(p.H) * p.W;
-  const float* xb = x + static_cast<size_t>(b) * p.in_bstride + static_cast<size_t>(d) * HW;
-  const int n = p.Ho * p.Wo;
-  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
-    const int oy = o / p.Wo, ox = o - oy * p.Wo;
-    // up to two source rows / columns with their tap index (-1: none)
-    int iyA = -1, kyA = 0, iyB = -1, kyB = 0, ixA = -1, kxA = 0, ixB = -1, kxB = 0;
-    if ((oy & 1) == 0) { iyA = oy >> 1; kyA = 1; }
-    else { iyA = (oy - 1) >> 1; kyA = 2; iyB = (oy + 1) >> 1; kyB = 0; if (iyB >= p.H) iyB = -1; }
-    if ((ox & 1) == 0) { ixA = ox >> 1; kxA = 1; }
-    else { ixA = (ox - 1) >> 1; kxA = 2; ixB = (ox + 1) >> 1; kxB = 0; if (ixB >= p.W) ixB = -1; }
-    float acc[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-    for (int ci = 0; ci < p.Cin; ++ci) {
-      const float* xc = xb + static_cast<size_t>(ci) * p.in_cstride;
-      const float* wc = w + static_cast<size_t>(ci) * 9 * COUT;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int iy = a ? iyB : iyA, ky = a ? kyB : kyA;
-        if (iy < 0) continue;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int ix = c ? ixB : ixA, kx = c ? kxB : kxA;
-          if (ix < 0) continue;
-          const float xv = xc[static_cast<size_t>(iy) * p.W + ix];
-          const float* wt = wc + (ky * 3 + kx) * COUT;      // per-lane tap: vector loads (tiny layers only)
-#pragma unroll
-          for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[co], xv, acc[co]);
-        }
-      }
-    }
-    float* yb = y + static_cast<size_t>(b) * p.out_bstride + static_cast<size_t>(d) * n + o;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co)
-      if (co < p.Cout) yb[static_cast<size_t>(co) * p.out_cstride] = apply_act(acc[co] * scale[co] + shift[co], p.act, p.act_param);
-  }
-}
-
-// D form: Dout = 2 * Din.  even od -> t=1, id=od/2; odd od -> t=2 (id=(od-1)/2) and t=0 (id=(od+1)/2 if < Din).
-template <int COUT>
-__global__ void __launch_bounds__(256)
-deconv_d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-                const float* __restrict__ shift, float* __restrict__ y, const ConvD p) {
-  const int od = blockIdx.y, b = blockIdx.z;
-  const float* xb = x + static_cast<size_t>(b) * p.in_bstride;
-  int idA, tA, idB = -1, tB = 0;
-  if ((od & 1) == 0) { idA = od >> 1; tA = 1; }
-  else { idA = (od - 1) >> 1; tA = 2; idB = (od + 1) >> 1; tB = 0; if (idB >= p.Din) idB = -1; }
-  for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < p.HW; px += gridDim.x * blockDim.x) {
-    float acc[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int id = a ? idB : idA, t = a ? tB : tA;       // uniform
-      if (id < 0) continue;
-      const float* xp = xb + static_cast<size_t>(id) * p.HW + px;
-      for (int ci = 0; ci < p.Cin; ++ci) {
-        const float xv = xp[static_cast<size_t>(ci) * p.in_cstride];
-        const float* wt = w + (static_cast<size_t>(ci) * 3 + t) * COUT;
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[co], xv, acc[co]);
-      }
-    }
-    float* yb = y + static_cast<size_t>(b) * p.out_bstride + static_cast<size_t>(od) * p.HW + px;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co)
-      if (co < p.Cout) yb[static_cast<size_t>(co) * p.out_cstride] = apply_act(acc[co] * scale[co] + shift[co], p.act, p.act_param);
-  }
-}
-
 int cout_bucket(int cout) {
-  for (int b : {1, 8, 16, 32, 64})
+  for (int b : {8, 16, 32, 64})
     if (cout <= b) return b;
   return -1;
 }
@@ -598,7 +403,6 @@ int cout_bucket(int cout) {
 // Split-K factor of a (1,3,3) convolution: long reductions on grids too small to fill the chip are cut
 // into slices handled by separate workgroups (partials summed in a fixed order afterwards).
 int conv_hw_ksplit(int B, int Cin, int Cout, int D, int Ho, int Wo) {
-  if (cout_bucket(Cout) < 8) return 1;
   const long long tiles = static_cast<long long>((Ho + 7) / 8) * ((Wo + 31) / 32) * D * B;
   const int groups = (Cout + 15) / 16;
   int ks = 1;
@@ -607,15 +411,6 @@ int conv_hw_ksplit(int B, int Cin, int Cout, int D, int Ho, int Wo) {
 }
 
 }  // namespace
-
-#define TS_DISPATCH_COUT(bucket, KERNEL, ...)                                      \
-  switch (bucket) {                                                                \
-    case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                     \
-    case 8: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                     \
-    case 16: hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__); break;                   \
-    case 32: hipLaunchKernelGGL(KERNEL<32>, __VA_ARGS__); break;                   \
-    default: hipLaunchKernelGGL(KERNEL<64>, __VA_ARGS__); break;                   \
-  }
 
 // x [B,Cin,D,H,W] -> y [B,Cout,D,Ho,Wo]; w_t is [Cin][3][3][CoutPad] with CoutPad = ts_conv_cout_pad(Cout)
 // (zero padded), scale/shift [CoutPad].  Channel/batch strides are in elements so that x / y may be
@@ -637,20 +432,6 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   const int bucket = cout_bucket(Cout);
   TS_REQUIRE(bucket > 0, TS_ERR_UNSUPPORTED, "conv3d_hw: Cout=%d > 64", Cout);
   hipStream_t st = ts::as_stream(stream);
-  if (bucket == 1) {            // single-channel heads: vector-ALU direct form
-    TS_REQUIRE(!transposed && B <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw: Cout=1 supports the forward form only");
-    ConvHW q;
-    q.B = B; q.Cin = Cin; q.Cout = Cout; q.D = D; q.H = H; q.W = W;
-    q.stride = stride; q.dil = dilation; q.pad = dilation; q.act = act; q.act_param = act_param;
-    q.in_bstride = in_bstride; q.in_cstride = in_cstride; q.out_bstride = out_bstride; q.out_cstride = out_cstride;
-    q.Ho = (H - 1) / stride + 1; q.Wo = (W - 1) / stride + 1;
-    const int tiles = ((q.Ho + TILE_Y - 1) / TILE_Y) * ((q.Wo + TILE_X - 1) / TILE_X);
-    const int in_rows = (TILE_Y - 1) * stride + 2 * dilation + 1;
-    const int in_cols_p = ((TILE_X - 1) * stride + 2 * dilation + 1) | 1;
-    const size_t lds_bytes = static_cast<size_t>(CI_CHUNK) * in_rows * in_cols_p * sizeof(float);
-    hipLaunchKernelGGL(conv_hw_kernel<1>, dim3(tiles, D, B), dim3(256), lds_bytes, st, x, w_t, scale, shift, y, q);
-    return ts::launched("conv_hw_kernel");
-  }
   IG p;
   p.Cin = Cin; p.Cout = Cout; p.coutp = bucket; p.D = D; p.H = H; p.W = W; p.Do = D;
   p.stride = stride; p.dil = dilation; p.pad = dilation; p.k = 3; p.transposed = transposed;
@@ -706,18 +487,6 @@ extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* sc
   const int Dout = transposed ? 2 * Din : (Din + 2 * padding - dilation * (k - 1) - 1) / stride + 1;
   TS_REQUIRE(Dout > 0 && Dout <= 65535, TS_ERR_SHAPE, "conv3d_d: bad output depth");
   hipStream_t st = ts::as_stream(stream);
-  if (bucket == 1) {
-    TS_REQUIRE(B <= 65535, TS_ERR_UNSUPPORTED, "conv3d_d: batch too large");
-    ConvD q;
-    q.B = B; q.Cin = Cin; q.Cout = Cout; q.Din = Din; q.HW = H * W; q.Dout = Dout;
-    q.k = k; q.stride = stride; q.dil = dilation; q.pad = padding; q.act = act; q.act_param = act_param;
-    q.in_bstride = in_bstride; q.in_cstride = in_cstride; q.out_bstride = out_bstride; q.out_cstride = out_cstride;
-    int blocks = (q.HW + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (transposed) hipLaunchKernelGGL(deconv_d_kernel<1>, dim3(blocks, Dout, B), dim3(256), 0, st, x, w_t, scale, shift, y, q);
-    else hipLaunchKernelGGL(conv_d_kernel<1>, dim3(blocks, Dout, B), dim3(256), 0, st, x, w_t, scale, shift, y, q);
-    return ts::launched("conv_d_kernel");
-  }
   IG p;
   p.Cin = Cin; p.Cout = Cout; p.coutp = bucket; p.D = Din; p.H = H; p.W = W; p.Do = Dout; p.Ho = H; p.Wo = W;
   p.stride = stride; p.dil = dilation; p.pad = padding; p.k = k; p.transposed = transposed;

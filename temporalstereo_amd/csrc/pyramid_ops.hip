@@ -266,8 +266,8 @@ unet_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ d
 
 // ------------------------------------------------------------------------------- bilinear resize
 __global__ void __launch_bounds__(256)
-resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, int BC, int h, int w, int Ho, int Wo,
-                       float sh, float sw, float vscale) {
+resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, int BC, int C, int h, int w, int Ho, int Wo,
+                       float sh, float sw, float vscale, long long out_bstride) {
   const long long n = static_cast<long long>(BC) * Ho * Wo;
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
@@ -281,11 +281,45 @@ resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, int
     const float* p = x + static_cast<size_t>(bc) * h * w;
     const float top = (1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1];
     const float bot = (1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1];
-    out[i] = ((1.f - ly) * top + ly * bot) * vscale;
+    const int b = bc / C, c = bc - b * C;
+    out[static_cast<size_t>(b) * out_bstride + (static_cast<size_t>(c) * Ho + oy) * Wo + ox] = ((1.f - ly) * top + ly * bot) * vscale;
+  }
+}
+
+// search range and its five candidates from an upsampled disparity (TemporalStereo.py:110,119 and
+// fine.py:82-87 / precise.py:73-78): low = d - r, high = d + r, cand_i = |high-low| * {0,3,4,5,8}/8 + min(low,high)
+__global__ void __launch_bounds__(256)
+range_candidates_kernel(const float* __restrict__ disp, float* __restrict__ low, float* __restrict__ high,
+                        float* __restrict__ cand, int B, int HW, float range, int coff, int ctot) {
+  const long long n = static_cast<long long>(B) * HW;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(i / HW);
+    const int px = static_cast<int>(i - static_cast<long long>(b) * HW);
+    const float d = disp[i];
+    const float lo = d - range, hi = d + range;
+    low[i] = lo; high[i] = hi;
+    const float span = fabsf(hi - lo), base = fminf(lo, hi);
+    float* c = cand + (static_cast<size_t>(b) * ctot + coff) * HW + px;
+    c[0] = span * 0.f + base;
+    c[static_cast<size_t>(1) * HW] = span * 0.375f + base;
+    c[static_cast<size_t>(2) * HW] = span * 0.5f + base;
+    c[static_cast<size_t>(3) * HW] = span * 0.625f + base;
+    c[static_cast<size_t>(4) * HW] = span * 1.f + base;
   }
 }
 
 }  // namespace
+
+extern "C" int ts_range_candidates_fwd(const float* disp, float* low, float* high, float* candidates, int B, int H, int W,
+                                       float range, int channel_offset, int channels_total, void* stream) {
+  TS_REQUIRE(B > 0 && H > 0 && W > 0 && channel_offset >= 0 && channel_offset + 5 <= channels_total, TS_ERR_SHAPE,
+             "range_candidates: bad size");
+  TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(low); TS_REQUIRE_PTR(high); TS_REQUIRE_PTR(candidates);
+  hipLaunchKernelGGL(range_candidates_kernel, dim3(grid_for(static_cast<long long>(B) * H * W, 256)), dim3(256), 0,
+                     ts::as_stream(stream), disp, low, high, candidates, B, H * W, range, channel_offset, channels_total);
+  return ts::launched("range_candidates_kernel");
+}
 
 extern "C" int ts_resize3d_add_act_fwd(const float* a, const float* add, float* out, int B, int C, int Da, int Ha, int Wa,
                                        int D, int H, int W, int act, long long a_bstride, long long a_cstride,
@@ -358,11 +392,12 @@ extern "C" int ts_unet_upsample_fwd(const float* mask, const float* disp, float*
   return ts::launched("unet_upsample_kernel");
 }
 
-extern "C" int ts_resize_bilinear_fwd(const float* x, float* out, int BC, int h, int w, int Ho, int Wo, float value_scale,
-                                      void* stream) {
-  TS_REQUIRE(BC > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, TS_ERR_SHAPE, "resize_bilinear: bad size");
+extern "C" int ts_resize_bilinear_fwd(const float* x, float* out, int B, int C, int h, int w, int Ho, int Wo, float value_scale,
+                                      long long out_bstride, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, TS_ERR_SHAPE, "resize_bilinear: bad size");
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(out);
-  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(static_cast<long long>(BC) * Ho * Wo, 256)), dim3(256), 0,
-                     ts::as_stream(stream), x, out, BC, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo), value_scale);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(static_cast<long long>(B) * C * Ho * Wo, 256)), dim3(256), 0,
+                     ts::as_stream(stream), x, out, B * C, C, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo), value_scale,
+                     out_bstride);
   return ts::launched("resize_bilinear_kernel");
 }

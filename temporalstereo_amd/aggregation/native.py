@@ -301,11 +301,6 @@ class NativeCoarse(_MergingLevel):
         return self.merge_fuse_predict(self.init3d(raw), None, prev_info, left, resize_memory=True)
 
 
-def _candidates(low, high):
-    span, base = torch.abs(high - low), torch.min(low, high)
-    return torch.cat([span * s + base for s in (0.0, 0.375, 0.5, 0.625, 1.0)], dim=1)
-
-
 class NativeFine(_MergingLevel):
     def __call__(self, left, right, ds, prev_info):
         raw = TF.block_cost(left, right, ds, self.scales)

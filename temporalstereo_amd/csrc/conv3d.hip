@@ -54,8 +54,9 @@ __device__ __forceinline__ float apply_act(float v, int act, float p) {
 //             Tile = 256 consecutive pixels of one output depth.
 // ------------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 enum { MODE_HW = 0, MODE_HWT = 1, MODE_D = 2 };
-constexpr int IG_NC_DEFAULT = 8;   // input channels per K chunk (16 for long-K stride-1 layers)
+constexpr unsigned kOOB = 0x80000000u;   // buffer offset past every num_records we allow: the load returns 0
 
 struct IG {
   int Cin, Cout, coutp;         // coutp: padded channel count of the weight / scale / shift arrays
@@ -65,29 +66,44 @@ struct IG {
   int act;
   float act_param;
   long long in_bstride, in_cstride, out_bstride, out_cstride;
+  unsigned in_bytes, w_bytes;   // extent of one batch element of x / of the weight array (buffer range checks)
   int tiles_x, co_groups;
   int ksplit, kspan;            // split-K: this many slices of `kspan` input channels each (partials -> workspace)
   float* partial;               // [ksplit][B][Cout][Do*Ho*Wo] raw sums when ksplit > 1
   int B;
 };
 
-template <int MODE, int ST>
-struct StageGeom {                       // rows / column-groups each thread stages per channel
-  static constexpr int RR = (MODE == MODE_D) ? 1 : (ST == 2 ? 5 : 3);
-  static constexpr int QC = (MODE == MODE_D) ? 1 : (ST == 2 ? 2 : 1);
+template <int MODE, int KT, int ST, int DL>
+struct Geom {
+  static constexpr int RR = (MODE == MODE_D) ? 1 : (ST == 2 ? 5 : 3);   // rows / column groups each thread
+  static constexpr int QC = (MODE == MODE_D) ? 1 : (ST == 2 ? 2 : 1);   // stages per channel
+  static constexpr int NTR = (MODE == MODE_D) ? KT : 1;                 // planes staged per channel (MODE_D)
+  static constexpr int in_rows = (MODE == MODE_HW) ? 7 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 10 : 9) : 1);
+  static constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 34 : 33) : 256);
+  static constexpr int pitch = (MODE == MODE_D) ? 256 : (in_cols | 1);
+  static constexpr int chan_raw = (MODE == MODE_D) ? NTR * 256 : in_rows * pitch;
+  static constexpr int pad0 = (16 - (chan_raw & 31)) & 31;
+  // == 16 (mod 32): the four k-slots of a B fragment sit on disjoint banks; >= 1 spare word (dump slot)
+  static constexpr int chan_elems = chan_raw + (pad0 ? pad0 : 32);
 };
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ig_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
 // ST / DL: stride and dilation of MODE_HW as compile-time constants, so that every LDS fragment read is
-// `base register + immediate` (no address arithmetic between MFMAs).
-template <int CB, int MODE, int KT, int ST, int DL, int IG_NC>
+// `base register + immediate` (no address arithmetic between MFMAs).  NC: input channels per K chunk.
+template <int CB, int MODE, int KT, int ST, int DL, int NC>
 __global__ void __launch_bounds__(256)
 ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                const float* __restrict__ shift, float* __restrict__ y, const IG p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  using G = Geom<MODE, KT, ST, DL>;
   constexpr int WP = (CB * 16) | 16;                  // weight row pitch (k-slots on disjoint banks)
-  constexpr int RR = StageGeom<MODE, ST>::RR, QC = StageGeom<MODE, ST>::QC;
-  constexpr int NTR = (MODE == MODE_D) ? KT : 1;      // planes staged per channel (MODE_D: one per tap)
-  constexpr int RWN = (KT * IG_NC * CB * 16 + 255) / 256;
+  constexpr int RR = G::RR, QC = G::QC, NTR = G::NTR, RQ = NTR * RR * QC;
+  constexpr int in_rows = G::in_rows, in_cols = G::in_cols, pitch = G::pitch, chan_elems = G::chan_elems;
+  constexpr int WV = KT * NC * CB * 4;                // 16-byte weight vectors per chunk
+  constexpr int RWN = (WV + 255) / 256;
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
@@ -100,11 +116,6 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   // ---- geometry of this workgroup -------------------------------------------------------------
   int tile = blockIdx.x, pa = 0, pbit = 0;
   if (MODE == MODE_HWT) { pa = (tile & 3) >> 1; pbit = tile & 1; tile >>= 2; }
-  constexpr int in_rows = (MODE == MODE_HW) ? 7 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 10 : 9) : 1);
-  constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 34 : 33) : 256);
-  constexpr int pitch = (MODE == MODE_D) ? 256 : (in_cols | 1);
-  constexpr int chan_raw = (MODE == MODE_D) ? NTR * 256 : in_rows * pitch;
-  constexpr int chan_elems = chan_raw + ((16 - (chan_raw & 31)) & 31);       // == 16 (mod 32)
   int iy0 = 0, ix0 = 0, ty0 = 0, tx0 = 0;
   if (MODE == MODE_HW) {
     ty0 = (tile / p.tiles_x) * 8; tx0 = (tile % p.tiles_x) * 32;
@@ -115,9 +126,8 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     iy0 = ty0 - ((KT == 16) ? 1 : 0); ix0 = tx0 - ((KT == 16) ? 1 : 0);
   }
   float* in_tile = lds;
-  float* w_tile = lds + IG_NC * chan_elems;            // [KT][IG_NC][WP]
-  const size_t HW = static_cast<size_t>(p.H) * p.W;
-  const float* xb = x + static_cast<size_t>(b) * p.in_bstride;
+  float* w_tile = lds + NC * chan_elems;               // [KT][NC][WP] (+ one dump vector)
+  const unsigned HW = static_cast<unsigned>(p.H) * p.W;
 
   // MODE_D: which input plane and which weight tap each staged plane is (uniform)
   int plane_id[NTR], plane_wt[NTR], ntaps = KT;
@@ -139,10 +149,52 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
         plane_wt[t] = t;
       }
     }
-  } else {
-    xb += static_cast<size_t>(od) * HW;                // HW modes: depth plane od of every channel
   }
   const int px0 = (MODE == MODE_D) ? blockIdx.x * 256 : 0;
+
+  // ---- staging geometry of this thread: where each of its RQ elements of a channel comes from (byte
+  // offset inside the batch element, kOOB = zero padding) and where it goes in the LDS channel tile ----
+  const int tcol = threadIdx.x & 63, trow = threadIdx.x >> 6;
+  unsigned goff[RQ];
+  int loff[RQ];
+  if (MODE == MODE_D) {
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) {
+      const unsigned px = px0 + threadIdx.x;
+      goff[t] = (plane_id[t] >= 0 && px < HW) ? (static_cast<unsigned>(plane_id[t]) * HW + px) * 4u : kOOB;
+      loff[t] = t * 256 + threadIdx.x;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const int cy = trow + 4 * r, gy = iy0 + cy;
+#pragma unroll
+      for (int q = 0; q < QC; ++q) {
+        const int cx = tcol + 64 * q, gx = ix0 + cx;
+        const bool slot = cy < in_rows && cx < in_cols;
+        const bool live = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        goff[r * QC + q] = live ? (static_cast<unsigned>(od) * HW + static_cast<unsigned>(gy) * p.W + gx) * 4u : kOOB;
+        loff[r * QC + q] = slot ? cy * pitch + cx : G::chan_raw;             // dump slot in the channel padding
+      }
+    }
+  }
+  // weights: vector v of a chunk = 4 consecutive output channels of (tap, ci)
+  unsigned woff[RWN];
+  int wci[RWN], wl[RWN];
+#pragma unroll
+  for (int q = 0; q < RWN; ++q) {
+    const int v = threadIdx.x + 256 * q;
+    const int co4 = v % (CB * 4), r = v / (CB * 4);
+    const int ci = r % NC, tap = r / NC;
+    const bool ok = v < WV && co0 + co4 * 4 < p.coutp;
+    woff[q] = ok ? static_cast<unsigned>((ci * KT + tap) * p.coutp + co0 + co4 * 4) * 4u : kOOB;
+    wci[q] = ci;
+    wl[q] = v < WV ? r * WP + co4 * 4 : KT * NC * WP;
+  }
+  const __amdgpu_buffer_rsrc_t xr = ig_rsrc(x + static_cast<size_t>(b) * p.in_bstride, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t wr = ig_rsrc(w, p.w_bytes);
+  const unsigned cstride_b = static_cast<unsigned>(p.in_cstride) * 4u;
+  const unsigned wstride_b = static_cast<unsigned>(KT * p.coutp) * 4u;
 
   // ---- per-lane fragment bases ----------------------------------------------------------------
   int boff[4];
@@ -163,147 +215,115 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
 
-  // ---- register prefetch of one K chunk ---------------------------------------------------------
-  const int tcol = threadIdx.x & 63, trow = threadIdx.x >> 6;
-  float rin[IG_NC][NTR * RR * QC];
-  float rw[RWN];
+  // ---- register prefetch of one K chunk: branch-free buffer loads (zero padding, ragged channel
+  // counts and partial tiles all resolve to out-of-range offsets or zero weights) ------------------
+  float rin[NC][RQ];
+  u32x4 rw[RWN];
   auto fetch = [&](int c0) {
-    const int nc = min(IG_NC, kend - c0);
 #pragma unroll
-    for (int c = 0; c < IG_NC; ++c) {
-      const float* xc = xb + static_cast<size_t>(c0 + c) * p.in_cstride;
-      if (MODE == MODE_D) {
+    for (int c = 0; c < NC; ++c) {
+      // channels past the slice re-read the last real one; their weights are zero
+      const unsigned so = static_cast<unsigned>(min(c0 + c, p.Cin - 1)) * cstride_b;
 #pragma unroll
-        for (int t = 0; t < NTR; ++t) {
-          const int px = px0 + threadIdx.x;
-          rin[c][t] = (c < nc && plane_id[t] >= 0 && px < static_cast<int>(HW)) ? xc[static_cast<size_t>(plane_id[t]) * HW + px] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < RR; ++r) {
-          const int cy = trow + 4 * r, gy = iy0 + cy;
-          const bool rowok = (c < nc) && cy < in_rows && gy >= 0 && gy < p.H;
-#pragma unroll
-          for (int q = 0; q < QC; ++q) {
-            const int cx = tcol + 64 * q, gx = ix0 + cx;
-            rin[c][r * QC + q] = (rowok && cx < in_cols && gx >= 0 && gx < p.W) ? xc[static_cast<size_t>(gy) * p.W + gx] : 0.f;
-          }
-        }
-      }
+      for (int i = 0; i < RQ; ++i) rin[c][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, goff[i], so, 0));
     }
+    const unsigned wso = static_cast<unsigned>(c0) * wstride_b;
 #pragma unroll
-    for (int q = 0; q < RWN; ++q) {
-      const int i = threadIdx.x + 256 * q;
-      const int co = i % (CB * 16);
-      const int r = i / (CB * 16);
-      const int ci = r % IG_NC, tap = r / IG_NC;
-      rw[q] = (tap < KT && ci < nc && co0 + co < p.coutp) ? w[(static_cast<size_t>(c0 + ci) * KT + tap) * p.coutp + co0 + co] : 0.f;
-    }
+    for (int q = 0; q < RWN; ++q)
+      rw[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (wci[q] < kend - c0) ? woff[q] + wso : kOOB, 0, 0);
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int c = 0; c < IG_NC; ++c) {
-      if (MODE == MODE_D) {
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int t = 0; t < NTR; ++t) in_tile[c * chan_elems + t * 256 + threadIdx.x] = rin[c][t];
-      } else {
+      for (int i = 0; i < RQ; ++i) in_tile[c * chan_elems + loff[i]] = rin[c][i];
 #pragma unroll
-        for (int r = 0; r < RR; ++r) {
-          const int cy = trow + 4 * r;
-#pragma unroll
-          for (int q = 0; q < QC; ++q) {
-            const int cx = tcol + 64 * q;
-            if (cy < in_rows && cx < in_cols) in_tile[c * chan_elems + cy * pitch + cx] = rin[c][r * QC + q];
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < RWN; ++q) {
-      const int i = threadIdx.x + 256 * q;
-      const int co = i % (CB * 16);
-      const int r = i / (CB * 16);
-      if (r < KT * IG_NC) w_tile[r * WP + co] = rw[q];
-    }
+    for (int q = 0; q < RWN; ++q) *reinterpret_cast<u32x4*>(w_tile + wl[q]) = rw[q];
   };
 
   fetch(kbeg);
-  for (int c0 = kbeg; c0 < kend; c0 += IG_NC) {
+  for (int c0 = kbeg; c0 < kend; c0 += NC) {
     __syncthreads();                  // everyone is done reading the previous chunk
     commit();
     __syncthreads();
-    if (c0 + IG_NC < kend) fetch(c0 + IG_NC);           // next chunk in flight under the MFMAs below
-    if (MODE == MODE_HW) {
+    if (c0 + NC < kend) fetch(c0 + NC);                 // next chunk in flight under the MFMAs below
+#pragma unroll 1
+    for (int c8 = 0; c8 < NC / 8; ++c8) {               // eight channels at a time (rolled: code size)
+      const float* it = in_tile + c8 * 8 * chan_elems;
+      const float* wt0 = w_tile + c8 * 8 * WP + aoff;
+      if (MODE == MODE_HW) {
+        // 18 steps (tap, 4 channels); the fragments of step s+1 are read from LDS before the MFMAs of
+        // step s issue, so the matrix pipe never waits on an LDS round trip
+        constexpr int NS = 18;
+        float a[2][CB], bv[2][4];
+        auto frag = [&](int s, int slot) {
+          const int tap = s >> 1, cq = s & 1;
+          const int toff = (tap / 3) * DL * pitch + (tap % 3) * DL;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
+          for (int cb = 0; cb < CB; ++cb) a[slot][cb] = wt0[(tap * NC + cq * 4) * WP + cb * 16];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int toff = ky * DL * pitch + kx * DL;
-          const float* wt = w_tile + ((ky * 3 + kx) * IG_NC) * WP + aoff;
+          for (int pb = 0; pb < 4; ++pb) bv[slot][pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
+        };
+        frag(0, 0);
 #pragma unroll
-          for (int cq = 0; cq < IG_NC / 4; ++cq) {
-            float a[CB], bv[4];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) bv[pb] = in_tile[boff[pb] + cq * 4 * chan_elems + toff];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-              for (int pb = 0; pb < 4; ++pb)
-                acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
-          }
-        }
-      }
-    } else if (MODE == MODE_HWT) {
-      // output parity (pa, pbit) selects which kernel taps land on input pixels:
-      //   k3 s2 p1 (KT 9):  even -> (k=1, d=0);            odd -> (k=2, d=0), (k=0, d=+1)
-      //   k4 s2 p1 (KT 16): even -> (k=1, d=0), (k=3, d=-1); odd -> (k=2, d=0), (k=0, d=+1)
-      constexpr int KS = (KT == 16) ? 4 : 3, ORG = (KT == 16) ? 1 : 0;
-#pragma unroll
-      for (int ta = 0; ta < 2; ++ta) {
-        int ky, dy;
-        if (pa) { ky = ta ? 0 : 2; dy = ta ? 1 : 0; }
-        else { if (ta && KT != 16) continue; ky = ta ? 3 : 1; dy = ta ? -1 : 0; }
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-          int kx, dx;
-          if (pbit) { kx = tb ? 0 : 2; dx = tb ? 1 : 0; }
-          else { if (tb && KT != 16) continue; kx = tb ? 3 : 1; dx = tb ? -1 : 0; }
-          const int toff = (dy + ORG) * pitch + dx + ORG;
-          const float* wt = w_tile + ((ky * KS + kx) * IG_NC) * WP + aoff;
-#pragma unroll
-          for (int cq = 0; cq < IG_NC / 4; ++cq) {
-            float a[CB], bv[4];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) bv[pb] = in_tile[boff[pb] + cq * 4 * chan_elems + toff];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-              for (int pb = 0; pb < 4; ++pb)
-                acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NTR; ++t) {
-        if (t >= ntaps) continue;
-        const float* wt = w_tile + (plane_wt[t] * IG_NC) * WP + aoff;
-#pragma unroll
-        for (int cq = 0; cq < IG_NC / 4; ++cq) {
-          float a[CB], bv[4];
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
-#pragma unroll
-          for (int pb = 0; pb < 4; ++pb) bv[pb] = in_tile[boff[pb] + cq * 4 * chan_elems + t * 256];
+        for (int s = 0; s < NS; ++s) {
+          if (s + 1 < NS) frag(s + 1, (s + 1) & 1);
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb)
-              acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+              acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][cb], bv[s & 1][pb], acc[cb][pb], 0, 0, 0);
+        }
+      } else if (MODE == MODE_HWT) {
+        // output parity (pa, pbit) selects which kernel taps land on input pixels:
+        //   k3 s2 p1 (KT 9):  even -> (k=1, d=0);            odd -> (k=2, d=0), (k=0, d=+1)
+        //   k4 s2 p1 (KT 16): even -> (k=1, d=0), (k=3, d=-1); odd -> (k=2, d=0), (k=0, d=+1)
+        constexpr int KS = (KT == 16) ? 4 : 3, ORG = (KT == 16) ? 1 : 0;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta) {
+          int ky, dy;
+          if (pa) { ky = ta ? 0 : 2; dy = ta ? 1 : 0; }
+          else { if (ta && KT != 16) continue; ky = ta ? 3 : 1; dy = ta ? -1 : 0; }
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) {
+            int kx, dx;
+            if (pbit) { kx = tb ? 0 : 2; dx = tb ? 1 : 0; }
+            else { if (tb && KT != 16) continue; kx = tb ? 3 : 1; dx = tb ? -1 : 0; }
+            const int toff = (dy + ORG) * pitch + dx + ORG;
+            const float* wt = wt0 + ((ky * KS + kx) * NC) * WP;
+#pragma unroll
+            for (int cq = 0; cq < 2; ++cq) {
+              float a[CB], bv[4];
+#pragma unroll
+              for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
+#pragma unroll
+              for (int pb = 0; pb < 4; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
+#pragma unroll
+              for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb)
+                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+          if (t >= ntaps) continue;
+          const float* wt = wt0 + (plane_wt[t] * NC) * WP;
+#pragma unroll
+          for (int cq = 0; cq < 2; ++cq) {
+            float a[CB], bv[4];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + t * 256];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+              for (int pb = 0; pb < 4; ++pb)
+                acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+          }
         }
       }
     }
@@ -314,8 +334,8 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   for (int pb = 0; pb < 4; ++pb) {
     size_t opix;
     if (MODE == MODE_D) {
-      const int px = px0 + wave * 64 + pb * 16 + j;
-      if (px >= static_cast<int>(HW)) continue;
+      const unsigned px = px0 + wave * 64 + pb * 16 + j;
+      if (px >= HW) continue;
       opix = static_cast<size_t>(od) * HW + px;
     } else {
       int oy = ty0 + wave * 2 + (pb >> 1), ox = tx0 + (pb & 1) * 16 + j;
@@ -365,33 +385,68 @@ conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ 
   }
 }
 
-template <int MODE, int KT, int ST, int DL, int IG_NC = IG_NC_DEFAULT>
+template <int CB, int MODE, int KT, int ST, int DL, int NC>
+int launch_one(const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
+               dim3 grid, hipStream_t st) {
+  using G = Geom<MODE, KT, ST, DL>;
+  constexpr int WP = (CB * 16) | 16;
+  constexpr size_t lds = (static_cast<size_t>(NC) * G::chan_elems + static_cast<size_t>(KT) * NC * WP + 4) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "ig_conv_kernel: tile does not fit the LDS");
+  auto kern = &ig_conv_kernel<CB, MODE, KT, ST, DL, NC>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;      // per instantiation
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, w, scale, shift, y, p);
+  return ts::launched("ig_conv_kernel");
+}
+
+template <int CB, int MODE, int KT, int ST, int DL>
+int launch_nc(int nc, const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
+              dim3 grid, hipStream_t st) {
+  using G = Geom<MODE, KT, ST, DL>;
+  constexpr int WP = (CB * 16) | 16;
+  constexpr size_t per_ch = (static_cast<size_t>(G::chan_elems) + static_cast<size_t>(KT) * WP) * sizeof(float);
+  constexpr size_t budget = 150 * 1024;
+  if constexpr (32 * per_ch <= budget) { if (nc >= 32) return launch_one<CB, MODE, KT, ST, DL, 32>(x, w, scale, shift, y, p, grid, st); }
+  if constexpr (16 * per_ch <= budget) { if (nc >= 16) return launch_one<CB, MODE, KT, ST, DL, 16>(x, w, scale, shift, y, p, grid, st); }
+  return launch_one<CB, MODE, KT, ST, DL, 8>(x, w, scale, shift, y, p, grid, st);
+}
+
+template <int MODE, int KT, int ST, int DL>
 int launch_ig(const float* x, const float* w, const float* scale, const float* shift, float* y, IG p, int B,
               int grid_x, int grid_y, hipStream_t st) {
   // widest channel block that still leaves enough workgroups to fill the chip
   const int need = (p.Cout + 15) / 16;                 // 16-channel blocks
   int cb = need >= 4 ? 4 : (need >= 2 ? 2 : 1);
   auto groups = [&](int c) { return (need + c - 1) / c; };
-  while (cb > 1 && static_cast<long long>(grid_x) * grid_y * B * p.ksplit * groups(cb) < ts::kNumCU + ts::kNumCU / 2) cb >>= 1;
+  const long long tiles = static_cast<long long>(grid_x) * grid_y * B * p.ksplit;
+  while (cb > 1 && tiles * groups(cb) < ts::kNumCU + ts::kNumCU / 2) cb >>= 1;
   p.co_groups = groups(cb);
-  int chan;
-  if (MODE == MODE_D) chan = KT * 256;
-  else if (MODE == MODE_HWT) chan = (KT == 16) ? 10 * 35 : 9 * 33;
-  else chan = (7 * ST + 2 * DL + 1) * ((31 * ST + 2 * DL + 1) | 1);
-  chan += (16 - (chan & 31)) & 31;
-  const int wp = (cb * 16) | 16;
-  const size_t lds = (static_cast<size_t>(IG_NC) * chan + static_cast<size_t>(KT) * IG_NC * wp) * sizeof(float);
-  const dim3 grid(grid_x, grid_y, B * p.co_groups * p.ksplit);
   p.B = B;
-  if (lds > 64 * 1024) {
-    if (cb == 4) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<4, MODE, KT, ST, DL, IG_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    else if (cb == 2) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<2, MODE, KT, ST, DL, IG_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ig_conv_kernel<1, MODE, KT, ST, DL, IG_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  }
-  if (cb == 4) hipLaunchKernelGGL((ig_conv_kernel<4, MODE, KT, ST, DL, IG_NC>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
-  else if (cb == 2) hipLaunchKernelGGL((ig_conv_kernel<2, MODE, KT, ST, DL, IG_NC>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
-  else hipLaunchKernelGGL((ig_conv_kernel<1, MODE, KT, ST, DL, IG_NC>), grid, dim3(256), lds, st, x, w, scale, shift, y, p);
-  return ts::launched("ig_conv_kernel");
+  // K-chunk size.  A workgroup pays one global-memory round trip per chunk; on a grid that fills the
+  // chip several times over other workgroups hide it (small chunks = small LDS = more of them
+  // resident), on a small grid nothing does, so the chain is made as short as the LDS allows.
+  const long long wgs = tiles * p.co_groups;
+  int nc = 8;
+  if (wgs <= 2 * ts::kNumCU) nc = p.kspan >= 32 ? 32 : (p.kspan >= 16 ? 16 : 8);
+  else if (wgs <= 4 * ts::kNumCU) nc = p.kspan >= 16 ? 16 : 8;
+  const dim3 grid(grid_x, grid_y, B * p.co_groups * p.ksplit);
+  if (cb == 4) return launch_nc<4, MODE, KT, ST, DL>(nc, x, w, scale, shift, y, p, grid, st);
+  if (cb == 2) return launch_nc<2, MODE, KT, ST, DL>(nc, x, w, scale, shift, y, p, grid, st);
+  return launch_nc<1, MODE, KT, ST, DL>(nc, x, w, scale, shift, y, p, grid, st);
+}
+
+// extent checks shared by the entry points: buffer addressing is 32-bit per batch element
+bool ig_extent(IG& p, int KT) {
+  const unsigned long long in_b = (static_cast<unsigned long long>(p.Cin - 1) * p.in_cstride + static_cast<unsigned long long>(p.D) * p.H * p.W) * 4ull;
+  const unsigned long long w_b = static_cast<unsigned long long>(p.Cin) * KT * p.coutp * 4ull;
+  if (in_b >= 0x7fffffffull || w_b >= 0x7fffffffull || p.in_cstride < 0) return false;
+  p.in_bytes = static_cast<unsigned>(in_b); p.w_bytes = static_cast<unsigned>(w_b);
+  return true;
 }
 
 int cout_bucket(int cout) {
@@ -438,6 +493,7 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
+  TS_REQUIRE(ig_extent(p, 9), TS_ERR_UNSUPPORTED, "conv3d_hw: a batch element of x spans 2 GiB or more");
   if (transposed) {
     p.Ho = 2 * H; p.Wo = 2 * W;
     p.tiles_x = (W + 31) / 32;
@@ -452,7 +508,7 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   const bool split = ksplit > 1 && workspace != nullptr && workspace_bytes >= need;
   if (split) {
     p.ksplit = ksplit;
-    p.kspan = ((Cin + ksplit - 1) / ksplit + IG_NC_DEFAULT - 1) / IG_NC_DEFAULT * IG_NC_DEFAULT;
+    p.kspan = ((Cin + ksplit - 1) / ksplit + 7) / 8 * 8;
     p.partial = reinterpret_cast<float*>(workspace);
   }
   int rc;
@@ -493,6 +549,7 @@ extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* sc
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   p.tiles_x = 1; p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
+  TS_REQUIRE(ig_extent(p, k), TS_ERR_UNSUPPORTED, "conv3d_d: a batch element of x spans 2 GiB or more");
   const int tiles = (H * W + 255) / 256;
   if (k == 1) return launch_ig<MODE_D, 1, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
   if (k == 3) return launch_ig<MODE_D, 3, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
@@ -513,6 +570,7 @@ extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const floa
   p.in_bstride = static_cast<long long>(Cin) * H * W; p.in_cstride = static_cast<long long>(H) * W;
   p.out_bstride = out_bstride; p.out_cstride = 4ll * H * W;
   p.tiles_x = (W + 31) / 32; p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
+  TS_REQUIRE(ig_extent(p, 16), TS_ERR_UNSUPPORTED, "deconv2d: a batch element of x spans 2 GiB or more");
   const int tiles = ((H + 7) / 8) * p.tiles_x;
   return launch_ig<MODE_HWT, 16, 1, 1>(x, w_t, scale, shift, y, p, B, tiles * 4, 1, ts::as_stream(stream));
 }

@@ -18,8 +18,13 @@ def wrap(mod, name, describe):
         s.record(); out = orig(*a, **k); e.record(); torch.cuda.synchronize()
         records.append((name, describe(*a, **k), s.elapsed_time(e) * 1e3)); return out
     setattr(mod, name, f)
-wrap(native, "conv_hw", lambda x, f, stride=1, dilation=1, transposed=False, **k: "%d->%d %s s%d d%d %s" % (f.cin, f.cout, tuple(x.shape[2:]), stride, dilation, "T" if transposed else ""))
-wrap(native, "conv_d", lambda x, f, k, stride=1, dilation=1, padding=0, transposed=False, **kw: "%d->%d %s k%d s%d d%d %s" % (f.cin, f.cout, tuple(x.shape[2:]), k, stride, dilation, "T" if transposed else ""))
+import math
+def _gf(x, f, taps, stride, transposed):
+    n = math.prod(x.shape[2:]) * x.shape[0]
+    n = n * (stride * stride if transposed else 1) / (1 if transposed else stride * stride)
+    return " GF=%.3f" % (2.0 * f.cin * f.cout * taps * n / 1e9)
+wrap(native, "conv_hw", lambda x, f, stride=1, dilation=1, transposed=False, **k: "%d->%d %s s%d d%d %s" % (f.cin, f.cout, tuple(x.shape[2:]), stride, dilation, "T" if transposed else "") + _gf(x, f, 4 if transposed and stride == 2 else 9, stride, transposed))
+wrap(native, "conv_d", lambda x, f, k, stride=1, dilation=1, padding=0, transposed=False, **kw: "%d->%d %s k%d s%d d%d %s" % (f.cin, f.cout, tuple(x.shape[2:]), k, stride, dilation, "T" if transposed else "") + _gf(x, f, k, 1, False))
 wrap(native, "resize_add_act", lambda a, add, size, **k: "%s->%s" % (tuple(a.shape[1:]), tuple(size)))
 wrap(native, "pool5", lambda x, a, m: str(tuple(x.shape[1:])))
 wrap(native.TF, "block_cost", lambda l, r, d, s=3: "%s D=%s" % (tuple(l.shape[1:]), d if isinstance(d, int) else d.shape[1]))
@@ -34,4 +39,5 @@ for n, d, us in records:
     key = n + " " + d
     a = agg_t.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += us
 for key, (n, us) in sorted(agg_t.items(), key=lambda kv: -kv[1][1])[:45]:
-    print("%8.1f us  x%-2d  %s" % (us, n, key))
+    gf = float(key.split("GF=")[1]) if "GF=" in key else 0.0
+    print("%8.1f us  x%-2d  %s  %s" % (us, n, key, ("%.1f TF/s" % (gf * n / us / 1e3 * 1e3)) if gf else ""))

@@ -8,7 +8,7 @@ import sqlite3
 import sys
 
 
-def main(path, top=25, window=None):
+def main(path, top=25, window=None, by_grid=False):
     db = sqlite3.connect(path)
     where = ""
     if window:
@@ -16,14 +16,19 @@ def main(path, top=25, window=None):
         where = " where start >= %d and start <= %d" % (tend - int(window[0] * 1e6), tend - int(window[1] * 1e6))
     rows = list(db.execute(
         "select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start), "
-        "max(vgpr_count), max(lds_size), max(workgroup_x), max(grid_x) from kernels" + where + " group by name "
+        "max(vgpr_count), max(lds_size), max(workgroup_x), max(grid_x), max(grid_y), max(grid_z) from kernels" + where +
+        (" group by name, grid_x, grid_y, grid_z " if by_grid else " group by name ") +
         "order by sum(end-start) desc"))
     tot = sum(r[5] for r in rows) or 1
     span = db.execute("select min(start), max(end), count(*) from kernels" + where).fetchone()
     print("kernels: %d dispatches, %d distinct, busy %.3f ms over a %.3f ms span" % (span[2], len(rows), tot / 1e6, (span[1] - span[0]) / 1e6))
     print("%-72s %6s %9s %9s %9s %6s %5s %7s %5s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct", "vgpr", "lds", "wg"))
     for r in rows[:top]:
-        print("%-72s %6d %9.1f %9.1f %9.1f %6.1f %5d %7d %5d" % (r[0][:72], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3,
+        name = r[0][:72]
+        if by_grid:
+            name = (r[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:44]
+                    + " g=%dx%dx%d" % (r[9] // max(r[8], 1), r[10], r[11]))[:72]
+        print("%-72s %6d %9.1f %9.1f %9.1f %6.1f %5d %7d %5d" % (name, r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3,
                                                              100.0 * r[5] / tot, r[6], r[7], r[8]))
 
 
@@ -34,4 +39,6 @@ if __name__ == "__main__":
         i = args.index("--window-ms")
         window = (float(args[i + 1]), float(args[i + 2]))
         args = args[:i] + args[i + 3:]
-    main(args[0], int(args[1]) if len(args) > 1 else 25, window)
+    by_grid = "--by-grid" in args
+    args = [a for a in args if a != "--by-grid"]
+    main(args[0], int(args[1]) if len(args) > 1 else 25, window, by_grid)

@@ -338,17 +338,17 @@ class NativePrecise(_LevelBase):
                                              B, Cin, f.cout, H, W, f.act, out_bstride, _stream())
         _lib.check(rc, "ts_deconv2d_k4s2_fwd")
 
-    def __call__(self, left, right, ds, left_image, right_image, prev_info):
+    def unet_features(self, left, right, left_image, right_image):
+        """Everything of the refinement UNet that does not depend on a disparity: the image encoder
+        (module.py:459-466), the [feature | spx4] concatenation both views feed to block_cost, and the
+        decoder down to the 9-tap upsampling mask (module.py:484-491).  Independent of the pyramid, so
+        the aggregator runs it concurrently with the coarse and fine levels."""
         B, Cf, H, W = left.shape
         both = torch.empty((2 * B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)   # [left | right] x [feat | spx4]
         lcat, rcat = both[:B], both[B:]
         lcat[:, :Cf].copy_(left); rcat[:, :Cf].copy_(right)
         s2 = self.encode(torch.cat([left_image, right_image], dim=0), both)
         s2l = s2[:B]
-        raw = TF.block_cost(lcat, rcat, ds, self.scales)
-        cost, off = self.heads(self.init3d(raw))
-        disp, mem_s, mem_c = TF.topk_softargmax(cost, ds, off, k=self.topk)
-        # UNet.decoder (module.py:484-492)
         f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)
         C32 = self.deconv4.cout
         cat2 = torch.empty((B, C32 + s2l.shape[1], 2 * H, 2 * W), device=left.device, dtype=torch.float32)
@@ -357,7 +357,16 @@ class NativePrecise(_LevelBase):
         g = self._c2d(cat2.unsqueeze(2), self.concat, 1).squeeze(2).contiguous()
         mask = torch.empty((B, 9, 4 * H, 4 * W), device=left.device, dtype=torch.float32)
         self._deconv(g, self.deconv2, mask, mask.stride(0))
-        full = torch.empty((B, 1, 4 * H, 4 * W), device=left.device, dtype=torch.float32)
+        return both, mask
+
+    def __call__(self, both, mask, ds, prev_info):
+        B = both.shape[0] // 2
+        H, W = both.shape[-2:]
+        lcat, rcat = both[:B], both[B:]
+        raw = TF.block_cost(lcat, rcat, ds, self.scales)
+        cost, off = self.heads(self.init3d(raw))
+        disp, mem_s, mem_c = TF.topk_softargmax(cost, ds, off, k=self.topk)
+        full = torch.empty((B, 1, 4 * H, 4 * W), device=both.device, dtype=torch.float32)
         rc = _lib.lib().ts_unet_upsample_fwd(_lib.ptr(mask), _lib.ptr(disp), _lib.ptr(full), B, H, W, 4 * H, 4 * W, _stream())
         _lib.check(rc, "ts_unet_upsample_fwd")
         prev_info['prev_disp'] = full
@@ -375,13 +384,17 @@ class NativeAggregator:
         if any(p.device.type != "cuda" for p in net.parameters()):
             raise RuntimeError("NativeAggregator needs the module on the GPU (there is no CPU path)")
         self.coarse, self.fine, self.precise = NativeCoarse(net.coarse), NativeFine(net.fine), NativePrecise(net.precise)
+        # The coarse and fine levels are a chain of ~70 small kernels (grids of 50-500 workgroups) that
+        # leave most of the 256 CUs idle; the disparity-independent half of the refinement UNet is
+        # ~0.6 ms of wide kernels.  The chain runs on a HIGH-priority stream so that its workgroups are
+        # dispatched ahead of the wide kernels' (which fill whatever is left) and both finish together.
+        dev = next(net.parameters()).device
+        self.fast = torch.cuda.Stream(device=dev, priority=-1)
+        self.overlap = True
 
-    @torch.no_grad()
-    def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):
+    def _pyramid(self, l8, l16, r8, r16, prev_info, out):
         rng = 4
-        l4, l8, l16 = left_feats
-        r4, r8, r16 = right_feats
-        disps, costs, offs, samples, ranges = [], [], [], [], []
+        disps, costs, offs, samples, ranges = out
         d, c, o, s = self.coarse(l16.contiguous(), r16.contiguous(), prev_info)
         lm = prev_info.get('local_map', None)                       # fine.py:89-93: local-map candidates go first
         nl = lm.shape[1] if (lm is not None and prev_info.get('local_map_size', 0) > 0) else 0
@@ -392,6 +405,32 @@ class NativeAggregator:
         d, c, o, s = self.fine(l8.contiguous(), r8.contiguous(), ds, prev_info)
         low, high, ds = range_candidates(d, rng)
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
-        full, d, c, o, s = self.precise(l4, r4, ds, left_image.contiguous(), right_image.contiguous(), prev_info)
+        return ds
+
+    @torch.no_grad()
+    def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):
+        l4, l8, l16 = left_feats
+        r4, r8, r16 = right_feats
+        out = ([], [], [], [], [])
+        disps, costs, offs, samples, ranges = out
+        left_image, right_image = left_image.contiguous(), right_image.contiguous()
+        if self.overlap:
+            # Every use of `fast` starts by waiting on an event of the caller's stream and ends with the
+            # caller's stream waiting on it, so tensors allocated under it are safe to hand over.
+            main = torch.cuda.current_stream()
+            forked, joined = torch.cuda.Event(), torch.cuda.Event()
+            forked.record(main)
+            self.fast.wait_event(forked)
+            # the ten wide launches go out first (0.1 ms of host time), then the long chain: by the
+            # time the device is through the first few chain links everything is enqueued
+            both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
+            with torch.cuda.stream(self.fast):
+                ds = self._pyramid(l8, l16, r8, r16, prev_info, out)
+                joined.record()
+            main.wait_event(joined)
+        else:
+            ds = self._pyramid(l8, l16, r8, r16, prev_info, out)
+            both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
+        full, d, c, o, s = self.precise(both, mask, ds, prev_info)
         disps += [d, full]; costs.append(c); offs.append(o); samples.append(s)
         return disps[::-1], costs[::-1], samples[::-1], offs[::-1], ranges[::-1], prev_info

@@ -405,14 +405,19 @@ int launch_one(const float* x, const float* w, const float* scale, const float* 
 }
 
 template <int CB, int MODE, int KT, int ST, int DL>
-int launch_nc(int nc, const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
+int launch_nc(long long wgs, const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
               dim3 grid, hipStream_t st) {
+  // K-chunk size.  A workgroup pays one global-memory round trip per chunk, so the chunk is made as
+  // long as possible -- but only while every workgroup of the grid stays resident (LDS is what limits
+  // that): co-resident workgroups hide each other's round trips, queued ones do not.
   using G = Geom<MODE, KT, ST, DL>;
   constexpr int WP = (CB * 16) | 16;
   constexpr size_t per_ch = (static_cast<size_t>(G::chan_elems) + static_cast<size_t>(KT) * WP) * sizeof(float);
-  constexpr size_t budget = 150 * 1024;
-  if constexpr (32 * per_ch <= budget) { if (nc >= 32) return launch_one<CB, MODE, KT, ST, DL, 32>(x, w, scale, shift, y, p, grid, st); }
-  if constexpr (16 * per_ch <= budget) { if (nc >= 16) return launch_one<CB, MODE, KT, ST, DL, 16>(x, w, scale, shift, y, p, grid, st); }
+  constexpr size_t lds_cu = 160 * 1024;
+  const size_t per_cu = static_cast<size_t>((wgs + ts::kNumCU - 1) / ts::kNumCU);
+  auto fits = [&](int nc) { return (nc * per_ch + 16) * per_cu <= lds_cu && p.kspan >= nc; };
+  if constexpr (32 * per_ch + 16 <= lds_cu) { if (fits(32)) return launch_one<CB, MODE, KT, ST, DL, 32>(x, w, scale, shift, y, p, grid, st); }
+  if constexpr (16 * per_ch + 16 <= lds_cu) { if (fits(16)) return launch_one<CB, MODE, KT, ST, DL, 16>(x, w, scale, shift, y, p, grid, st); }
   return launch_one<CB, MODE, KT, ST, DL, 8>(x, w, scale, shift, y, p, grid, st);
 }
 
@@ -427,17 +432,11 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   while (cb > 1 && tiles * groups(cb) < ts::kNumCU + ts::kNumCU / 2) cb >>= 1;
   p.co_groups = groups(cb);
   p.B = B;
-  // K-chunk size.  A workgroup pays one global-memory round trip per chunk; on a grid that fills the
-  // chip several times over other workgroups hide it (small chunks = small LDS = more of them
-  // resident), on a small grid nothing does, so the chain is made as short as the LDS allows.
   const long long wgs = tiles * p.co_groups;
-  int nc = 8;
-  if (wgs <= 2 * ts::kNumCU) nc = p.kspan >= 32 ? 32 : (p.kspan >= 16 ? 16 : 8);
-  else if (wgs <= 4 * ts::kNumCU) nc = p.kspan >= 16 ? 16 : 8;
   const dim3 grid(grid_x, grid_y, B * p.co_groups * p.ksplit);
-  if (cb == 4) return launch_nc<4, MODE, KT, ST, DL>(nc, x, w, scale, shift, y, p, grid, st);
-  if (cb == 2) return launch_nc<2, MODE, KT, ST, DL>(nc, x, w, scale, shift, y, p, grid, st);
-  return launch_nc<1, MODE, KT, ST, DL>(nc, x, w, scale, shift, y, p, grid, st);
+  if (cb == 4) return launch_nc<4, MODE, KT, ST, DL>(wgs, x, w, scale, shift, y, p, grid, st);
+  if (cb == 2) return launch_nc<2, MODE, KT, ST, DL>(wgs, x, w, scale, shift, y, p, grid, st);
+  return launch_nc<1, MODE, KT, ST, DL>(wgs, x, w, scale, shift, y, p, grid, st);
 }
 
 // extent checks shared by the entry points: buffer addressing is 32-bit per batch element

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: stereo pairs/s of the cost-volume aggregation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode module|engine]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode native|native-eager|native-graph|module|module-graph]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -185,9 +185,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (config 2: 1)")
-    ap.add_argument("--mode", default="native", choices=["native", "native-graph", "module", "module-graph"],
-                    help="native: all-HIP inference path (aggregation.native); module: nn.Module forward "
-                         "(torch/MIOpen convolutions); -graph: replayed as one hipGraph")
+    ap.add_argument("--mode", default="native", choices=["native", "native-eager", "native-graph", "module", "module-graph"],
+                    help="native: all-HIP inference path (aggregation.native) replayed from a recorded native "
+                         "launch plan; native-eager: the same, issued op by op from Python; module: nn.Module "
+                         "forward (torch/MIOpen convolutions); -graph: replayed as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -213,7 +214,8 @@ def main():
 
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     mode = a.mode
-    runner = InferenceEngine(net, backend=mode.split("-")[0], graph=mode.endswith("-graph"))
+    replay = {"native": "plan", "native-eager": "eager", "native-graph": "graph", "module": "eager", "module-graph": "graph"}[mode]
+    runner = InferenceEngine(net, backend=mode.split("-")[0], replay=replay)
 
     def step():
         with torch.no_grad():

@@ -179,6 +179,27 @@ int ts_resize_bilinear_fwd(const float* x, float* out, int B, int C, int h, int 
 int ts_range_candidates_fwd(const float* disp, float* low, float* high, float* candidates, int B, int H, int W,
                             float range, int channel_offset, int channels_total, void* stream);
 
+/* dst[r * dst_pitch + c] = src[r * src_pitch + c] (elements): writes a tensor into a channel slice of
+ * another -- the torch.cat / slice.copy_ of precise.py:60-63 and module.py:486-489 without torch. */
+int ts_copy_rows_fwd(const float* src, float* dst, long long rows, long long row_elems, long long src_pitch,
+                     long long dst_pitch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Native replay runtime (no reference counterpart; the reference runs eagerly under PyTorch).
+ * A plan is the recorded sequence of launching calls of one pass -- device pointers, shapes and
+ * streams baked in, the contract of a CUDA graph with static buffers -- re-issued by one host call.
+ * ts_plan_add_call: `name` is one of the int-returning launch entry points above, `words` holds its
+ * arguments in order, one 64-bit word each (ints / floats in the low bytes).
+ * ts_stream_fork: to_stream waits for the work enqueued so far on from_stream.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ts_plan ts_plan;
+ts_plan* ts_plan_create(void);
+void ts_plan_destroy(ts_plan* plan);
+int ts_plan_length(const ts_plan* plan);
+int ts_plan_add_call(ts_plan* plan, const char* name, const unsigned long long* words, int n_words);
+int ts_plan_run(ts_plan* plan);
+int ts_stream_fork(void* from_stream, void* to_stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement support (no reference counterpart): float4 streams used by bench.py to calibrate
  * what this box sustains.  kind 0 = fill dst (write-only), 1 = copy src->dst, 2 = read src

@@ -53,11 +53,30 @@ SIGNATURES = {
     "ts_resize_bilinear_fwd": (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_float, ctypes.c_longlong, c_ptr]),
     "ts_range_candidates_fwd": (c_int, [c_f32p] * 4 + [c_int] * 3 + [c_float, c_int, c_int, c_ptr]),
     "ts_project_to_3d_fwd": (c_int, [c_f32p] * 7 + [c_int] * 6 + [c_float, c_ptr]),
+    "ts_copy_rows_fwd": (c_int, [c_f32p] * 2 + [ctypes.c_longlong] * 4 + [c_ptr]),
+    "ts_plan_create": (c_ptr, []),
+    "ts_plan_destroy": (None, [c_ptr]),
+    "ts_plan_length": (c_int, [c_ptr]),
+    "ts_plan_add_call": (c_int, [c_ptr, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong), c_int]),
+    "ts_plan_run": (c_int, [c_ptr]),
+    "ts_stream_fork": (c_int, [c_ptr, c_ptr]),
 }
+
+# entry points that only answer a question (nothing is enqueued): never part of a recorded plan
+_QUERIES = frozenset(n for n in SIGNATURES if n.endswith("_bytes") or n.startswith("ts_plan_") or
+                     n in ("ts_version", "ts_last_error_string", "ts_conv_cout_pad"))
 
 
 def lib():
-    """The loaded library (loads on first use).  Raises RuntimeError when it is not built."""
+    """The loaded library (loads on first use).  Raises RuntimeError when it is not built.
+    While a Recorder is active on this thread, launching calls are also appended to its plan."""
+    rec = getattr(_tls, "recorder", None)
+    if rec is not None:
+        return rec.proxy
+    return _real_lib()
+
+
+def _real_lib():
     global _lib
     if _lib is None:
         with _lock:
@@ -77,14 +96,109 @@ def lib():
     return _lib
 
 
+_tls = threading.local()
+
+
+def _word(argtype, value):
+    """One 64-bit plan word for a ctypes argument (include/ts_hip.h: ts_plan_add_call)."""
+    if isinstance(value, ctypes._SimpleCData):
+        value = value.value
+    if argtype is c_float:
+        import struct
+        return struct.unpack("<I", struct.pack("<f", float(value)))[0]
+    if value is None:
+        return 0
+    return int(value) & 0xFFFFFFFFFFFFFFFF
+
+
+class _RecordingProxy:
+    def __init__(self, recorder):
+        self._rec = recorder
+
+    def __getattr__(self, name):
+        real = getattr(_real_lib(), name)
+        if name in _QUERIES:
+            return real
+        argtypes = SIGNATURES[name][1]
+        rec = self._rec
+
+        def call(*args):
+            rc = real(*args)
+            if rc == 0:
+                words = (ctypes.c_ulonglong * len(args))(*[_word(t, a) for t, a in zip(argtypes, args)])
+                rc2 = _real_lib().ts_plan_add_call(rec.plan, name.encode(), words, len(args))
+                if rc2 != 0:
+                    check(rc2, "ts_plan_add_call(%s)" % name)
+            return rc
+        return call
+
+
+class Recorder:
+    """Context manager: every launching C-ABI call made on this thread inside the block runs as usual
+    AND is appended to a native plan (csrc/plan.hip).  Tensors whose pointers were handed to a call
+    are kept alive by the recorder, so the plan's baked-in pointers stay valid as long as it lives."""
+
+    def __init__(self):
+        self.plan = _real_lib().ts_plan_create()
+        if not self.plan:
+            raise RuntimeError("ts_plan_create failed")
+        self.keep = []
+        self.proxy = _RecordingProxy(self)
+
+    def __enter__(self):
+        if getattr(_tls, "recorder", None) is not None:
+            raise RuntimeError("plan recording does not nest")
+        _tls.recorder = self
+        return self
+
+    def __exit__(self, *exc):
+        _tls.recorder = None
+        return False
+
+    def __len__(self):
+        return int(_real_lib().ts_plan_length(self.plan))
+
+    def run(self):
+        rc = _real_lib().ts_plan_run(self.plan)
+        if rc != 0:
+            check(rc, "ts_plan_run")
+
+    def __del__(self):
+        try:
+            if self.plan:
+                _real_lib().ts_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+
+def recording():
+    """True while a Recorder is active on this thread (ops must then avoid un-recorded torch kernels)."""
+    return getattr(_tls, "recorder", None) is not None
+
+
 def check(rc, what):
     """Turn a non-zero status of the C ABI into RuntimeError (include/ts_hip.h conventions)."""
     if rc != 0:
-        msg = lib().ts_last_error_string().decode("utf-8", "replace")
+        msg = _real_lib().ts_last_error_string().decode("utf-8", "replace")
         kind = "argument error" if rc < 0 else "hipError_t"
         raise RuntimeError("%s failed (%s %d): %s" % (what, kind, rc, msg))
 
 
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    rec = getattr(_tls, "recorder", None)
+    if rec is not None:
+        rec.keep.append(t)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def contiguous(t):
+    """t.contiguous(), except that a copy (an un-recorded torch kernel) is refused while recording."""
+    if t.is_contiguous():
+        return t
+    if recording():
+        raise RuntimeError("plan recording needs contiguous tensors (a .contiguous() copy would not be replayed)")
+    return t.contiguous()

@@ -1,4 +1,4 @@
-"""Inference engine of the aggregation hot path: one hipGraph per input signature.
+"""Inference engine of the aggregation hot path: one recorded launch plan (or hipGraph) per input signature.
 
 The reference runs its forward eagerly (~300 framework ops per pair, SURVEY.md section 7 "tiny
 problem sizes": launch gaps dominate at batch 1).  Here the whole coarse -> fine -> precise pass is
@@ -50,15 +50,38 @@ class _Captured:
     def __init__(self, graph, static_in, static_out):
         self.graph, self.static_in, self.static_out = graph, static_in, static_out
 
+    def replay(self):
+        self.graph.replay()
+
+
+class _Recorded:
+    """A pass recorded into a native plan (csrc/plan.hip): same static-buffer contract as a graph."""
+
+    def __init__(self, recorder, static_in, static_out):
+        self.recorder, self.static_in, self.static_out = recorder, static_in, static_out
+
+    def replay(self):
+        self.recorder.run()
+
 
 class InferenceEngine:
     """`engine(left_feats, right_feats, left_image, right_image, prev_info)` -> same tuple as
     TEMPORALSTEREO.forward, executed as a hipGraph replay."""
 
-    def __init__(self, net, warmup=3, backend="native", graph=True):
+    def __init__(self, net, warmup=3, backend="native", graph=None, replay=None):
         """backend 'native': every stage on libts_hip.so kernels (aggregation.native);
         backend 'module': the nn.Module forward (torch/MIOpen convolutions + HIP K1/K4).
-        graph=False runs the backend directly (no hipGraph)."""
+        replay: 'plan'  -- record the pass once into a native launch plan and re-issue it with one host
+                           call per frame (native backend only; two-stream overlap stays on) [default
+                           for 'native'];
+                'graph' -- capture into a hipGraph [default for 'module'];
+                'eager' -- run the backend directly.
+        graph=True/False is the older spelling of replay='graph'/'eager'."""
+        if replay is None:
+            replay = ("graph" if graph else "eager") if graph is not None else ("plan" if backend == "native" else "graph")
+        if replay not in ("plan", "graph", "eager") or (replay == "plan" and backend != "native"):
+            raise ValueError("replay must be 'plan' (native backend), 'graph' or 'eager'")
+        graph = replay == "graph"
         if any(p.device.type != "cuda" for p in net.parameters()):
             raise RuntimeError("InferenceEngine needs the module on the GPU (there is no CPU path)")
         net = net.eval()
@@ -72,7 +95,7 @@ class InferenceEngine:
             self.net = net
         else:
             raise ValueError("backend must be 'native' or 'module'")
-        self.backend, self.use_graph = backend, graph
+        self.backend, self.use_graph, self.replay = backend, graph, replay
         self.warmup = warmup
         self._graphs = {}
 
@@ -91,19 +114,32 @@ class InferenceEngine:
             out = self.net(static_in[0], static_in[1], static_in[2], static_in[3], dict(static_in[4]))
         return _Captured(graph, static_in, out)
 
+    def _record(self, args):
+        from .. import _lib
+        static_in = _clone_static(args)
+        with torch.no_grad():
+            for _ in range(max(self.warmup - 1, 0)):       # allocator growth, lazy initialisation
+                self.net(static_in[0], static_in[1], static_in[2], static_in[3], dict(static_in[4]))
+            torch.cuda.synchronize()
+            rec = _lib.Recorder()
+            with rec:
+                out = self.net(static_in[0], static_in[1], static_in[2], static_in[3], dict(static_in[4]))
+        torch.cuda.synchronize()
+        return _Recorded(rec, static_in, out)
+
     def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):
         state = {k: v for k, v in prev_info.items()
                  if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}
         args = (list(left_feats), list(right_feats), left_image, right_image, state)
-        if not self.use_graph:
+        if self.replay == "eager":
             with torch.no_grad():
                 return self.net(args[0], args[1], args[2], args[3], dict(prev_info))
         sig = _sig_of(args)
         cap = self._graphs.get(sig)
         if cap is None:
-            cap = self._graphs[sig] = self._capture(args)
+            cap = self._graphs[sig] = self._record(args) if self.replay == "plan" else self._capture(args)
         _copy_into(cap.static_in, args)
-        cap.graph.replay()
+        cap.replay()
         disps, costs, samples, offs, ranges, info = cap.static_out
         out_info = dict(prev_info)
         out_info.update(info)

@@ -29,6 +29,58 @@ def _stream():
     return _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ------------------------------------------------------------------------- independent branches
+# The pyramid is a chain of small dependent launches; wherever two sub-chains are independent
+# (hourglass shortcuts, the two prediction heads, pooling beside the 5x5 conv) the shorter one is
+# issued on an auxiliary high-priority stream so that it leaves the critical path.  Off by default
+# (and during hipGraph capture); NativeAggregator switches it on around a pass.
+_PAR = {"on": False}
+_AUX = {}
+
+
+def _aux_stream():
+    dev = torch.cuda.current_device()
+    st = _AUX.get(dev)
+    if st is None:
+        st = _AUX[dev] = torch.cuda.Stream(device=dev, priority=-1)
+    return st
+
+
+def _edge(src, dst):
+    """`dst` waits for everything enqueued so far on `src`."""
+    rc = _lib.lib().ts_stream_fork(_lib.ctypes.c_void_p(src.cuda_stream), _lib.ctypes.c_void_p(dst.cuda_stream))
+    _lib.check(rc, "ts_stream_fork")
+
+
+class Branch:
+    """`with Branch() as br: ...` issues the block on the auxiliary stream, ordered after what the
+    current stream has enqueued so far; `br.join()` makes the current stream wait for it.  The
+    auxiliary stream is in-order, so one join covers every branch opened before it.
+    Allocator note: a branch always starts with an edge from the consumer stream and is joined before
+    its operands die, which orders every reuse of a cached block after its last reader."""
+
+    def __init__(self):
+        self.on = _PAR["on"]
+        if self.on:
+            self.cur, self.aux = torch.cuda.current_stream(), _aux_stream()
+
+    def __enter__(self):
+        if self.on:
+            _edge(self.cur, self.aux)
+            self.ctx = torch.cuda.stream(self.aux)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            _edge(self.aux, self.cur)
+
+
 def _act_code(mod):
     if mod is None:
         return ACT_NONE
@@ -68,6 +120,26 @@ class Folded:
         else:
             shift[:cout] = b
         self.scale, self.shift = scale.contiguous(), shift.contiguous()
+
+
+def fold_concat(a, b):
+    """One Folded computing [a | b] along Cout (same input, same taps, same activation)."""
+    if (a.cin, a.kind, a.act, a.kshape) != (b.cin, b.kind, b.act, b.kshape):
+        raise ValueError("fold_concat: layers differ in more than their output channels")
+    f = object.__new__(Folded)
+    f.cin, f.cout, f.kind, f.act, f.kshape = a.cin, a.cout + b.cout, a.kind, a.act, a.kshape
+    pad = int(_lib.lib().ts_conv_cout_pad(f.cout))
+    if pad < f.cout:
+        raise NotImplementedError("Cout=%d has no kernel bucket" % f.cout)
+    taps = a.w.shape[1]
+    f.w = torch.zeros(a.cin, taps, pad, device=a.w.device, dtype=torch.float32)
+    f.w[:, :, :a.cout] = a.w[:, :, :a.cout]
+    f.w[:, :, a.cout:f.cout] = b.w[:, :, :b.cout]
+    f.scale = torch.ones(pad, device=a.w.device)
+    f.shift = torch.zeros(pad, device=a.w.device)
+    f.scale[:a.cout] = a.scale[:a.cout]; f.scale[a.cout:f.cout] = b.scale[:b.cout]
+    f.shift[:a.cout] = a.shift[:a.cout]; f.shift[a.cout:f.cout] = b.shift[:b.cout]
+    return f
 
 
 def fold_wrapper(m, kind, transposed=False):
@@ -147,10 +219,18 @@ def resize_bilinear(x, size, value_scale=1.0, out=None):
     B, C, h, w = x.shape
     if out is None:
         out = torch.empty((B, C, size[0], size[1]), device=x.device, dtype=torch.float32)
-    rc = _lib.lib().ts_resize_bilinear_fwd(_lib.ptr(x.contiguous()), _lib.ptr(out), B, C, h, w, size[0], size[1],
+    rc = _lib.lib().ts_resize_bilinear_fwd(_lib.ptr(_lib.contiguous(x)), _lib.ptr(out), B, C, h, w, size[0], size[1],
                                            float(value_scale), out.stride(0), _stream())
     _lib.check(rc, "ts_resize_bilinear_fwd")
     return out
+
+
+def copy_rows(src, dst):
+    """dst[...] = src for a `dst` that is a channel slice of a larger contiguous tensor ([B, C, ...])."""
+    B = src.shape[0]
+    n = src[0].numel()
+    rc = _lib.lib().ts_copy_rows_fwd(_lib.ptr(_lib.contiguous(src)), _lib.ptr(dst), B, n, n, dst.stride(0), _stream())
+    _lib.check(rc, "ts_copy_rows_fwd")
 
 
 def range_candidates(disp, rng, extra_front=0):
@@ -197,10 +277,16 @@ class Hourglass:
         self.c4.f1.act = ACT_SILU
 
     def __call__(self, x):
+        br = Branch()
+        with br:
+            s6 = self.s6(x)                                  # shortcuts: off the critical path
         pre = self.c2(self.c1(x))
-        out = self.c4(self.c3(pre))
-        out = resize_add_act(self.c5(out), self.s5(pre), pre.shape[-3:])
-        return resize_add_act(self.c6(out), self.s6(x), x.shape[-3:])
+        with br:
+            s5 = self.s5(pre)
+        out = self.c5(self.c4(self.c3(pre)))
+        br.join()
+        out = resize_add_act(out, s5, pre.shape[-3:])
+        return resize_add_act(self.c6(out), s6, x.shape[-3:])
 
 
 class Heads:
@@ -208,12 +294,18 @@ class Heads:
 
     def __init__(self, mod):
         self.delta = float(mod.delta)
-        self.c0, self.c1 = fold_wrapper(mod.cost_head[0], "d"), fold_wrapper(mod.cost_head[1], "hw")
-        self.o0, self.o1 = fold_wrapper(mod.off_head[0], "d"), fold_wrapper(mod.off_head[1], "hw")
+        c0, self.c1 = fold_wrapper(mod.cost_head[0], "d"), fold_wrapper(mod.cost_head[1], "hw")
+        o0, self.o1 = fold_wrapper(mod.off_head[0], "d"), fold_wrapper(mod.off_head[1], "hw")
+        self.C = c0.cout
+        self.co0 = fold_concat(c0, o0)          # both heads start with a (3,1,1) conv of the same input: one launch
 
     def __call__(self, x):
-        cost = conv_hw(conv_d(x, self.c0, 3, 1, 1, 1), self.c1)
-        off = conv_hw(conv_d(x, self.o0, 3, 1, 1, 1), self.o1, act=ACT_TANH_OFFSET, act_param=self.delta)
+        y = conv_d(x, self.co0, 3, 1, 1, 1)
+        br = Branch()
+        with br:
+            off = conv_hw(y[:, self.C:], self.o1, act=ACT_TANH_OFFSET, act_param=self.delta)
+        cost = conv_hw(y[:, :self.C], self.c1)
+        br.join()
         return cost.squeeze(1), off.squeeze(1)
 
 
@@ -228,12 +320,16 @@ class ConvexUp:
         w3 = mod.mask[3].weight
         self.m3 = Folded(w3.reshape(w3.shape[0], w3.shape[1], 1, 1, 1), mod.mask[3].bias, None, ACT_NONE, False, "d")
 
-    def __call__(self, feat, disp):
+    def mask(self, feat):
+        """The 9 * r^2 convex-combination logits: a function of the left features only."""
+        return conv_d(conv_hw(feat.unsqueeze(2), self.m0), self.m3, 1)
+
+    def __call__(self, feat, disp, m=None):
         B, _, H, W = disp.shape
-        m = conv_hw(feat.unsqueeze(2), self.m0)
-        m = conv_d(m, self.m3, 1)
+        if m is None:
+            m = self.mask(feat)
         out = torch.empty((B, 1, H * self.r, W * self.r), device=disp.device, dtype=torch.float32)
-        rc = _lib.lib().ts_convex_upsample_fwd(_lib.ptr(m), _lib.ptr(disp.contiguous()), _lib.ptr(out), B, H, W, self.r,
+        rc = _lib.lib().ts_convex_upsample_fwd(_lib.ptr(m), _lib.ptr(_lib.contiguous(disp)), _lib.ptr(out), B, H, W, self.r,
                                                float(self.r), _stream())
         _lib.check(rc, "ts_convex_upsample_fwd")
         return out
@@ -263,7 +359,7 @@ class _MergingLevel(_LevelBase):
             self.fuse = SepConv(mod.fuse.conv_fuse)
         self.up = ConvexUp(mod.convex_upsample)
 
-    def merge_fuse_predict(self, vol, samples, prev_info, feat, resize_memory):
+    def merge_fuse_predict(self, vol, samples, prev_info, feat, resize_memory, mask=None):
         B, C, D0, H, W = vol.shape
         K = self.topk
         memory = prev_info.get('cost_memory', None)
@@ -273,7 +369,7 @@ class _MergingLevel(_LevelBase):
             if resize_memory:                                           # coarse.py:91-96
                 mem_s = resize_bilinear(mem_s, (H, W), W / mem_s.shape[-1])
                 mem_c = resize_bilinear(mem_c, (H, W), 1.0)
-            mem_s, mem_c = mem_s.contiguous(), mem_c.contiguous()
+            mem_s, mem_c = _lib.contiguous(mem_s), _lib.contiguous(mem_c)
         Dm = D0 + K
         nch = 4 * C if self.fusion else C
         cat4 = torch.empty((B, nch, Dm, H, W), device=vol.device, dtype=torch.float32)
@@ -285,26 +381,31 @@ class _MergingLevel(_LevelBase):
                                                 _lib.ptr(samp), _lib.ptr(x0), B, C, D0, K, H, W, vb, vc, ob, oc, _stream())
         _lib.check(rc, "ts_merge_candidates_fwd")
         if self.fusion:                                                 # PyramidFusion, module.py:412-421
+            br = Branch()
+            with br:
+                pool5(x0, cat4[:, 2 * C:3 * C], cat4[:, 3 * C:])
             conv_d(x0, self.conv5, 5, 1, 1, 2, out=cat4[:, C:2 * C])
-            pool5(x0, cat4[:, 2 * C:3 * C], cat4[:, 3 * C:])
+            br.join()
             y = self.fuse(cat4)
         else:
             y = x0
         cost, off = self.heads(y)
         disp, _, _ = TF.topk_softargmax(cost, samp, off, k=self.topk)
-        return self.up(feat, disp), cost, off, samp
+        if callable(mask):
+            mask = mask()                    # produced on another stream: the callable joins it
+        return self.up(feat, disp, mask), cost, off, samp
 
 
 class NativeCoarse(_MergingLevel):
-    def __call__(self, left, right, prev_info):
+    def __call__(self, left, right, prev_info, mask=None):
         raw = TF.block_cost(left, right, int(self.mod.num_sample), self.scales)
-        return self.merge_fuse_predict(self.init3d(raw), None, prev_info, left, resize_memory=True)
+        return self.merge_fuse_predict(self.init3d(raw), None, prev_info, left, resize_memory=True, mask=mask)
 
 
 class NativeFine(_MergingLevel):
-    def __call__(self, left, right, ds, prev_info):
+    def __call__(self, left, right, ds, prev_info, mask=None):
         raw = TF.block_cost(left, right, ds, self.scales)
-        return self.merge_fuse_predict(self.init3d(raw), ds, prev_info, left, resize_memory=False)
+        return self.merge_fuse_predict(self.init3d(raw), ds, prev_info, left, resize_memory=False, mask=mask)
 
 
 class NativePrecise(_LevelBase):
@@ -346,15 +447,17 @@ class NativePrecise(_LevelBase):
         B, Cf, H, W = left.shape
         both = torch.empty((2 * B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)   # [left | right] x [feat | spx4]
         lcat, rcat = both[:B], both[B:]
-        lcat[:, :Cf].copy_(left); rcat[:, :Cf].copy_(right)
-        s2 = self.encode(torch.cat([left_image, right_image], dim=0), both)
+        copy_rows(left, lcat[:, :Cf]); copy_rows(right, rcat[:, :Cf])
+        imgs = torch.empty((2 * B,) + tuple(left_image.shape[1:]), device=left.device, dtype=torch.float32)
+        copy_rows(left_image, imgs[:B]); copy_rows(right_image, imgs[B:])
+        s2 = self.encode(imgs, both)
         s2l = s2[:B]
         f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)
         C32 = self.deconv4.cout
         cat2 = torch.empty((B, C32 + s2l.shape[1], 2 * H, 2 * W), device=left.device, dtype=torch.float32)
-        self._deconv(f.contiguous(), self.deconv4, cat2, cat2.stride(0))
-        cat2[:, C32:].copy_(s2l.squeeze(2))
-        g = self._c2d(cat2.unsqueeze(2), self.concat, 1).squeeze(2).contiguous()
+        self._deconv(_lib.contiguous(f), self.deconv4, cat2, cat2.stride(0))
+        copy_rows(s2l.squeeze(2), cat2[:, C32:])
+        g = _lib.contiguous(self._c2d(cat2.unsqueeze(2), self.concat, 1).squeeze(2))
         mask = torch.empty((B, 9, 4 * H, 4 * W), device=left.device, dtype=torch.float32)
         self._deconv(g, self.deconv2, mask, mask.stride(0))
         return both, mask
@@ -392,17 +495,17 @@ class NativeAggregator:
         self.fast = torch.cuda.Stream(device=dev, priority=-1)
         self.overlap = True
 
-    def _pyramid(self, l8, l16, r8, r16, prev_info, out):
+    def _pyramid(self, l8, l16, r8, r16, prev_info, out, masks=(None, None)):
         rng = 4
         disps, costs, offs, samples, ranges = out
-        d, c, o, s = self.coarse(l16.contiguous(), r16.contiguous(), prev_info)
+        d, c, o, s = self.coarse(_lib.contiguous(l16), _lib.contiguous(r16), prev_info, masks[0])
         lm = prev_info.get('local_map', None)                       # fine.py:89-93: local-map candidates go first
         nl = lm.shape[1] if (lm is not None and prev_info.get('local_map_size', 0) > 0) else 0
         low, high, ds = range_candidates(d, rng, nl)
         if nl:
             resize_bilinear(lm, d.shape[-2:], d.shape[-1] / lm.shape[-1], out=ds[:, :nl])
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
-        d, c, o, s = self.fine(l8.contiguous(), r8.contiguous(), ds, prev_info)
+        d, c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, masks[1])
         low, high, ds = range_candidates(d, rng)
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
@@ -413,24 +516,37 @@ class NativeAggregator:
         r4, r8, r16 = right_feats
         out = ([], [], [], [], [])
         disps, costs, offs, samples, ranges = out
-        left_image, right_image = left_image.contiguous(), right_image.contiguous()
+        left_image, right_image = _lib.contiguous(left_image), _lib.contiguous(right_image)
         if self.overlap:
             # Every use of `fast` starts by waiting on an event of the caller's stream and ends with the
             # caller's stream waiting on it, so tensors allocated under it are safe to hand over.
             main = torch.cuda.current_stream()
-            forked, joined = torch.cuda.Event(), torch.cuda.Event()
-            forked.record(main)
-            self.fast.wait_event(forked)
-            # the ten wide launches go out first (0.1 ms of host time), then the long chain: by the
-            # time the device is through the first few chain links everything is enqueued
-            both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
-            with torch.cuda.stream(self.fast):
-                ds = self._pyramid(l8, l16, r8, r16, prev_info, out)
-                joined.record()
-            main.wait_event(joined)
+            mainp, fastp = _lib.ctypes.c_void_p(main.cuda_stream), _lib.ctypes.c_void_p(self.fast.cuda_stream)
+            _lib.check(_lib.lib().ts_stream_fork(mainp, fastp), "ts_stream_fork")
+            aux = _aux_stream()
+            _edge(main, aux)
+            _PAR["on"] = True
+            try:
+                # convex-upsampling logits of the coarse and fine levels depend on the features only
+                with torch.cuda.stream(aux):
+                    mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
+
+                def joined(m):
+                    def get():
+                        _edge(aux, torch.cuda.current_stream())
+                        return m
+                    return get
+                # the ten wide launches go out first, then the long chain
+                both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
+                with torch.cuda.stream(self.fast):
+                    ds = self._pyramid(l8, l16, r8, r16, prev_info, out, (joined(mc), joined(mf)))
+                _lib.check(_lib.lib().ts_stream_fork(fastp, mainp), "ts_stream_fork")
+                full, d, c, o, s = self.precise(both, mask, ds, prev_info)
+            finally:
+                _PAR["on"] = False
         else:
             ds = self._pyramid(l8, l16, r8, r16, prev_info, out)
             both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
-        full, d, c, o, s = self.precise(both, mask, ds, prev_info)
+            full, d, c, o, s = self.precise(both, mask, ds, prev_info)
         disps += [d, full]; costs.append(c); offs.append(o); samples.append(s)
         return disps[::-1], costs[::-1], samples[::-1], offs[::-1], ranges[::-1], prev_info

@@ -37,15 +37,15 @@ class _BlockCost(torch.autograd.Function):
         _require_gpu(left, right, disp)
         if left.dim() != 4 or left.shape != right.shape:
             raise ValueError("reference_fm / target_fm must be [B,C,H,W] of equal shape")
-        left = left.contiguous()
-        right = right.contiguous()
+        left = _lib.contiguous(left)
+        right = _lib.contiguous(right)
         B, C, H, W = left.shape
         L = _lib.lib()
         sampled = disp is not None
         if sampled:
             if disp.dim() != 4 or disp.shape[0] != B or disp.shape[2:] != left.shape[2:]:
                 raise ValueError("disp_sample must be [B,D,H,W] matching the feature maps")
-            disp = disp.contiguous()
+            disp = _lib.contiguous(disp)
             D = disp.shape[1]
             ctot = 2 * C + scales * (C // 8)
         else:
@@ -73,7 +73,7 @@ class _BlockCost(torch.autograd.Function):
         left, right, disp = ctx.saved_tensors
         B, C, H, W, D, scales, sampled = ctx.meta
         L = _lib.lib()
-        grad_out = grad_out.contiguous()
+        grad_out = _lib.contiguous(grad_out)
         need_l, need_r, need_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gl = torch.empty_like(left) if need_l else None
         gr = torch.empty_like(right) if need_r else None
@@ -113,7 +113,7 @@ class _TopkSoftArgmax(torch.autograd.Function):
         _require_gpu(cost, sample, offset)
         if cost.dim() != 4 or cost.shape != sample.shape or cost.shape != offset.shape:
             raise ValueError("cost, disp_sample and off must be [B,D,H,W] of equal shape")
-        cost, sample, offset = cost.contiguous(), sample.contiguous(), offset.contiguous()
+        cost, sample, offset = _lib.contiguous(cost), _lib.contiguous(sample), _lib.contiguous(offset)
         B, D, H, W = cost.shape
         disp = torch.empty((B, 1, H, W), device=cost.device, dtype=torch.float32)
         tdisp = torch.empty((B, k, H, W), device=cost.device, dtype=torch.float32)
@@ -135,7 +135,7 @@ class _TopkSoftArgmax(torch.autograd.Function):
         need_samp = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         gcost = torch.empty((B, D, H, W), device=disp.device, dtype=torch.float32) if need_cost else None
         gsamp = torch.empty((B, D, H, W), device=disp.device, dtype=torch.float32) if need_samp else None
-        c = lambda t: None if t is None else t.contiguous()
+        c = lambda t: None if t is None else _lib.contiguous(t)
         rc = _lib.lib().ts_topk_softargmax_bwd(_lib.ptr(tdisp), _lib.ptr(tcost), _lib.ptr(tidx), _lib.ptr(disp),
                                                _lib.ptr(c(g_disp)), _lib.ptr(c(g_tdisp)), _lib.ptr(c(g_tcost)),
                                                _lib.ptr(gcost), _lib.ptr(gsamp), B, D, H, W, k, _stream())
@@ -153,7 +153,7 @@ class _SoftArgmin(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cost, sample, temperature, normalize):
         _require_gpu(cost, sample)
-        cost, sample = cost.contiguous(), sample.contiguous()
+        cost, sample = _lib.contiguous(cost), _lib.contiguous(sample)
         B, D, H, W = cost.shape
         disp = torch.empty((B, 1, H, W), device=cost.device, dtype=torch.float32)
         rc = _lib.lib().ts_softargmin_fwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(disp), float(temperature),
@@ -169,7 +169,7 @@ class _SoftArgmin(torch.autograd.Function):
         B, D, H, W, temperature, normalize = ctx.meta
         gc = torch.empty_like(cost) if ctx.needs_input_grad[0] else None
         gs = torch.empty_like(sample) if ctx.needs_input_grad[1] else None
-        rc = _lib.lib().ts_softargmin_bwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(disp), _lib.ptr(g.contiguous()),
+        rc = _lib.lib().ts_softargmin_bwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(disp), _lib.ptr(_lib.contiguous(g)),
                                           _lib.ptr(gc), _lib.ptr(gs), temperature, normalize, B, D, H, W, _stream())
         _lib.check(rc, "ts_softargmin_bwd")
         return gc, gs, None, None
@@ -188,7 +188,7 @@ class _ArgmaxSelect(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cost, sample):
         _require_gpu(cost, sample)
-        cost, sample = cost.contiguous(), sample.contiguous()
+        cost, sample = _lib.contiguous(cost), _lib.contiguous(sample)
         B, D, H, W = cost.shape
         disp = torch.empty((B, 1, H, W), device=cost.device, dtype=torch.float32)
         idx = torch.empty((B, 1, H, W), device=cost.device, dtype=torch.int32)
@@ -223,7 +223,7 @@ class _SplatSum(torch.autograd.Function):
         _require_gpu(inp, flow)
         if flow.shape[1] != 2 or inp.shape[0] != flow.shape[0] or inp.shape[2:] != flow.shape[2:]:
             raise ValueError("flow must be [B,2,H,W] matching the input")
-        inp, flow = inp.contiguous(), flow.contiguous()
+        inp, flow = _lib.contiguous(inp), _lib.contiguous(flow)
         B, C, H, W = inp.shape
         out = torch.empty_like(inp)
         _lib.check(_lib.lib().ts_softsplat_sum_fwd(_lib.ptr(inp), _lib.ptr(flow), _lib.ptr(out), B, C, H, W, _stream()),
@@ -235,7 +235,7 @@ class _SplatSum(torch.autograd.Function):
     def backward(ctx, g):
         inp, flow = ctx.saved_tensors
         B, C, H, W = inp.shape
-        g = g.contiguous()
+        g = _lib.contiguous(g)
         gi = gf = None
         if ctx.needs_input_grad[0]:
             gi = torch.empty_like(inp)
@@ -261,7 +261,7 @@ def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
         t is not None and t.requires_grad for t in (tenInput, tenFlow, tenMetric))
     if strType == 'softmax' and not grad_needed:
         _require_gpu(tenInput, tenFlow, tenMetric)
-        inp, flow, met = tenInput.contiguous(), tenFlow.contiguous(), tenMetric.contiguous()
+        inp, flow, met = _lib.contiguous(tenInput), _lib.contiguous(tenFlow), _lib.contiguous(tenMetric)
         B, C, H, W = inp.shape
         L = _lib.lib()
         out = torch.empty_like(inp)
@@ -292,8 +292,8 @@ def project_to_3d(depth, K, inv_K=None, T_target_to_source=None, eps=1e-7):
     _require_gpu(depth, K, T_target_to_source)
     if inv_K is None:
         inv_K = torch.inverse(K[:, :3, :3])
-    depth = depth.contiguous()
-    K, inv_K, T = K.contiguous(), inv_K.contiguous(), T_target_to_source.contiguous()
+    depth = _lib.contiguous(depth)
+    K, inv_K, T = _lib.contiguous(K), _lib.contiguous(inv_K), _lib.contiguous(T_target_to_source)
     B, C, H, W = depth.shape
     tri = torch.empty_like(depth)
     flow = torch.empty((B, 2 * C, H, W), device=depth.device, dtype=torch.float32)

@@ -46,7 +46,10 @@ DIMS = dict(coarse=dict(in_planes=256, C=32, num_sample=MAX_DISP // 16), fine=di
 
 
 def k1_algorithmic_bytes(B, C, H, W, D, sampled):
-    """inputs once + output once, fp32."""
+    """inputs once + output once, fp32.  sampled == "warped": the inference
+    form that leaves out the D-fold repeat of the left features (ts_block_cost_sampled_warped_fwd)."""
+    if sampled == "warped":
+        return 4 * B * H * W * (2 * C + D + (C + 3 * C // 8) * D)
     if sampled:
         return 4 * B * H * W * (2 * C + D + (2 * C + 3 * C // 8) * D)
     return 4 * B * H * W * (2 * C + (C + 3 * C // 8) * D)
@@ -102,24 +105,29 @@ class K1Probe:
 
     def __enter__(self):
         self.TF._k1_probe = self._probe
-        self._orig = self.TF.block_cost
+        self._orig = {"block_cost": self.TF.block_cost, "block_cost_warped": self.TF.block_cost_warped}
 
-        def remember(reference_fm, target_fm, disp_sample, block_cost_scale=3):
-            B, C, H, W = reference_fm.shape
-            sampled = not isinstance(disp_sample, int)
-            key = (B, C, H, W, disp_sample.shape[1] if sampled else disp_sample, sampled)
-            if key not in self.calls:
-                self.calls[key] = (reference_fm.detach(), target_fm.detach(),
-                                   disp_sample.detach() if sampled else disp_sample, block_cost_scale)
-            return self._orig(reference_fm, target_fm, disp_sample, block_cost_scale)
-        from temporalstereo_amd.aggregation import levels
-        self._levels = levels
-        levels.TF.block_cost = remember
+        def remember(name):
+            orig = self._orig[name]
+
+            def f(reference_fm, target_fm, disp_sample, block_cost_scale=3):
+                B, C, H, W = reference_fm.shape
+                sampled = not isinstance(disp_sample, int)
+                kind = "warped" if name == "block_cost_warped" else sampled
+                key = (B, C, H, W, disp_sample.shape[1] if sampled else disp_sample, kind)
+                if key not in self.calls:
+                    self.calls[key] = (orig, reference_fm.detach(), target_fm.detach(),
+                                       disp_sample.detach() if sampled else disp_sample, block_cost_scale)
+                return orig(reference_fm, target_fm, disp_sample, block_cost_scale)
+            return f
+        for name in self._orig:          # aggregation.levels / aggregation.native reach the ops as TF.<name>
+            setattr(self.TF, name, remember(name))
         return self
 
     def __exit__(self, *exc):
         self.TF._k1_probe = None
-        self._levels.TF.block_cost = self._orig
+        for name, fn in self._orig.items():
+            setattr(self.TF, name, fn)
 
     def _probe(self, key, launch):
         if not self.timing:
@@ -134,12 +142,12 @@ class K1Probe:
     def measure(self, iters):
         self.timing = True
         with torch.no_grad():
-            for key, (l, r, d, sc) in self.calls.items():
+            for key, (fn, l, r, d, sc) in self.calls.items():
                 for _ in range(3):
-                    self._orig(l, r, d, sc)
+                    fn(l, r, d, sc)
                 self.records = [rec for rec in self.records if rec[0] != key]
                 for _ in range(iters):
-                    self._orig(l, r, d, sc)
+                    fn(l, r, d, sc)
         torch.cuda.synchronize()
         self.timing = False
         per = {}
@@ -250,6 +258,8 @@ def main():
         pairs = world * a.batch * a.steps
         # dominant cost-volume launch: the 1/4-resolution (precise) sampled build
         pkey = (a.batch, 2 * DIMS['precise']['in_planes'], RUN_H // 4, RUN_W // 4, 5, True)
+        if pkey not in k1_times:      # the native path builds the volume without the repeated left half
+            pkey = pkey[:5] + ("warped",)
         roofline = None
         if pkey in k1_times:
             nbytes = k1_algorithmic_bytes(*pkey)
@@ -268,8 +278,8 @@ def main():
                             traffic=traffic,
                             measured="HIP events on the launch stream around the C-ABI call, %d back-to-back "
                                      "launches on the pipeline's own tensors right after the timed steps" % max(a.steps, 20),
-                            kernel="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample) on "
-                                   "[%d,%d,%d,%d] x %d candidates" % pkey[:5],
+                            kernel="%s (block_cost_fast + block_cost_upsample) on [%d,%d,%d,%d] x %d candidates"
+                                   % (("ts_block_cost_sampled_warped_fwd" if pkey[5] == "warped" else "ts_block_cost_sampled_fwd",) + pkey[:5]),
                             algorithmic_bytes=nbytes, mean_us=k1_times[pkey] * 1e6,
                             frac_of_measured_copy_ceiling=ach / 6.29e12,
                             all_levels=dict(algorithmic_bytes=all_b, mean_us=all_t * 1e6,

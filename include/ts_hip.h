@@ -51,6 +51,15 @@ int ts_block_cost_sampled_fwd(const float* left, const float* right, const float
                               void* workspace, int B, int C, int H, int W, int D, int scales,
                               void* stream);
 
+/* Inference form of the sampled path: the first C channels of its output are `left` repeated D times
+ * (block_cost.py:51), and the layer that consumes the volume is a (1,3,3) convolution, so
+ *   conv(volume) = conv_{W[:, :C]}(left) broadcast over D  +  conv_{W[:, C:]}(volume[:, C:]).
+ * This entry writes only volume[:, C:]  ->  out [B, C + scales*C/8, D, H, W]  (warped half, then the
+ * correlation blocks); ts_conv3d_hw_fwd takes the left term as its `addend`. */
+int ts_block_cost_sampled_warped_fwd(const float* left, const float* right, const float* disp, float* out,
+                                     void* workspace, int B, int C, int H, int W, int D, int scales,
+                                     void* stream);
+
 /* Backward of the two paths (autograd of the reference's torch ops).  grad_out has the layout
  * of `out`.  grad_left/grad_right [B,C,H,W] and grad_disp [B,D,H,W] are OVERWRITTEN (any may be
  * NULL to skip).  grad_right / grad_disp accumulate with fp32 atomics (order not deterministic,
@@ -136,7 +145,11 @@ int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const
                      int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
                      int transposed, int act, float act_param,
                      long long in_bstride, long long in_cstride, long long out_bstride,
-                     long long out_cstride, void* workspace, size_t workspace_bytes, void* stream);
+                     long long out_cstride, const float* addend, long long addend_bstride,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* addend (may be NULL): [B, Cout, Ho, Wo] (batch stride addend_bstride elements), added to the raw sum of
+ * EVERY depth plane before scale / shift / activation -- the D-invariant part of a convolution over a
+ * volume whose leading channels are a broadcast (see ts_block_cost_sampled_warped_fwd). */
 /* scratch ts_conv3d_hw_fwd can use to split a long reduction over more workgroups (0 = never splits at
  * this shape; passing NULL / too little simply disables the split) */
 size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride, int transposed);

@@ -26,6 +26,7 @@ SIGNATURES = {
     "ts_block_cost_workspace_bytes": (c_size, [c_int] * 6),
     "ts_block_cost_int_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
+    "ts_block_cost_sampled_warped_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_bwd_workspace_bytes": (c_size, [c_int] * 6),
     "ts_block_cost_int_bwd": (c_int, [c_f32p] * 5 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_bwd": (c_int, [c_f32p] * 7 + [c_ptr] + [c_int] * 6 + [c_ptr]),
@@ -41,7 +42,8 @@ SIGNATURES = {
     "ts_softsplat_softmax_workspace_bytes": (c_size, [c_int] * 4),
     "ts_softsplat_softmax_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 4 + [c_ptr]),
     "ts_conv_cout_pad": (c_int, [c_int]),
-    "ts_conv3d_hw_fwd": (c_int, [c_f32p] * 5 + [c_int] * 10 + [c_float] + [ctypes.c_longlong] * 4 + [c_ptr, c_size, c_ptr]),
+    "ts_conv3d_hw_fwd": (c_int, [c_f32p] * 5 + [c_int] * 10 + [c_float] + [ctypes.c_longlong] * 4 +
+                         [c_f32p, ctypes.c_longlong, c_ptr, c_size, c_ptr]),
     "ts_conv3d_hw_workspace_bytes": (c_size, [c_int] * 8),
     "ts_conv3d_d_fwd": (c_int, [c_f32p] * 5 + [c_int] * 12 + [c_float] + [ctypes.c_longlong] * 4 + [c_ptr]),
     "ts_resize3d_add_act_fwd": (c_int, [c_f32p] * 3 + [c_int] * 9 + [ctypes.c_longlong] * 6 + [c_ptr]),

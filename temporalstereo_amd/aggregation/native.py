@@ -122,6 +122,20 @@ class Folded:
         self.scale, self.shift = scale.contiguous(), shift.contiguous()
 
 
+def fold_split_input(f, n):
+    """(head, rest): `head` is the raw convolution over input channels [:n] (no bias / BatchNorm /
+    activation), `rest` the layer over channels [n:] with the original epilogue, so that
+    layer(x) == rest(x[:, n:], addend=head(x[:, :n]))."""
+    head, rest = object.__new__(Folded), object.__new__(Folded)
+    for g, lo, hi in ((head, 0, n), (rest, n, f.cin)):
+        g.cin, g.cout, g.kind, g.kshape = hi - lo, f.cout, f.kind, f.kshape
+        g.w = f.w[lo:hi].contiguous()
+    head.act, rest.act = ACT_NONE, f.act
+    head.scale, head.shift = torch.ones_like(f.scale), torch.zeros_like(f.shift)
+    rest.scale, rest.shift = f.scale, f.shift
+    return head, rest
+
+
 def fold_concat(a, b):
     """One Folded computing [a | b] along Cout (same input, same taps, same activation)."""
     if (a.cin, a.kind, a.act, a.kshape) != (b.cin, b.kind, b.act, b.kshape):
@@ -154,8 +168,8 @@ def _strides5(t):
     return t.stride(0), t.stride(1)
 
 
-def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0):
-    """x [B,Cin,D,H,W] -> [B,Cout,D,Ho,Wo]."""
+def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0, addend=None):
+    """x [B,Cin,D,H,W] -> [B,Cout,D,Ho,Wo].  addend [B,Cout,1,Ho,Wo]: added to every depth plane's raw sum."""
     B, Cin, D, H, W = x.shape
     assert Cin == f.cin, (Cin, f.cin)
     if transposed:
@@ -172,7 +186,8 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
     rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
                             B, Cin, f.cout, D, H, W, stride, dilation, int(transposed),
-                            f.act if act is None else act, float(act_param), ib, ic, ob, oc, _lib.ptr(ws), wsb, _stream())
+                            f.act if act is None else act, float(act_param), ib, ic, ob, oc,
+                            _lib.ptr(addend), addend.stride(0) if addend is not None else 0, _lib.ptr(ws), wsb, _stream())
     _lib.check(rc, "ts_conv3d_hw_fwd")
     return out
 
@@ -261,8 +276,8 @@ class SepConv:
         if c0.kernel_size != (1, 3, 3) or c0.padding[1] != self.dil or c1.stride[0] != self.stride:
             raise NotImplementedError("separable conv outside the (1,3,3)+(k,1,1) family: %r" % (mod,))
 
-    def __call__(self, x, out=None):
-        y = conv_hw(x, self.f0, self.stride, self.dil, self.transposed)
+    def __call__(self, x, out=None, addend=None):
+        y = conv_hw(x, self.f0, self.stride, self.dil, self.transposed, addend=addend)
         return conv_d(y, self.f1, self.k, self.stride, self.dil, self.pad_d, self.transposed, out=out)
 
 
@@ -342,8 +357,22 @@ class _LevelBase:
         self.init0, self.hg, self.init2 = SepConv(mod.init3d[0]), Hourglass(mod.init3d[1]), SepConv(mod.init3d[2])
         self.heads = Heads(mod.pred_heads)
 
-    def init3d(self, raw):
-        return self.init2(self.hg(self.init0(raw)))
+    def init3d(self, raw, addend=None):
+        return self.init2(self.hg(self.init0(raw, addend=addend)))
+
+    def split_reference_half(self):
+        """Sampled levels: the first C channels of the volume are the left features repeated over D
+        (block_cost.py:51) and init3d starts with a (1,3,3) convolution, so that part of the first
+        layer is computed once per pixel (`left_term`) instead of once per candidate, and the volume
+        is built without it (ts_block_cost_sampled_warped_fwd)."""
+        f0 = self.init0.f0
+        C = f0.cin * 8 // (16 + self.scales)             # cin == 2C + scales * C/8
+        if 2 * C + self.scales * (C // 8) != f0.cin or self.init0.stride != 1 or self.init0.transposed:
+            raise NotImplementedError("first aggregation layer is not a stride-1 conv over [left | warped | corr]")
+        self.init0_left, self.init0.f0 = fold_split_input(f0, C)
+
+    def left_term(self, left):
+        return conv_hw(left.unsqueeze(2), self.init0_left, 1, self.init0.dil)
 
 
 class _MergingLevel(_LevelBase):
@@ -403,9 +432,14 @@ class NativeCoarse(_MergingLevel):
 
 
 class NativeFine(_MergingLevel):
-    def __call__(self, left, right, ds, prev_info, mask=None):
-        raw = TF.block_cost(left, right, ds, self.scales)
-        return self.merge_fuse_predict(self.init3d(raw), ds, prev_info, left, resize_memory=False, mask=mask)
+    def __init__(self, mod):
+        super().__init__(mod)
+        self.split_reference_half()
+
+    def __call__(self, left, right, ds, prev_info, mask=None, left_term=None):
+        raw = TF.block_cost_warped(left, right, ds, self.scales)
+        lt = left_term() if callable(left_term) else (left_term if left_term is not None else self.left_term(left))
+        return self.merge_fuse_predict(self.init3d(raw, lt), ds, prev_info, left, resize_memory=False, mask=mask)
 
 
 class NativePrecise(_LevelBase):
@@ -419,6 +453,7 @@ class NativePrecise(_LevelBase):
         self.concat = fold_wrapper(u.concat, "hw")
         self.deconv2 = Folded(u.deconv2.weight, u.deconv2.bias, None, ACT_NONE, True, "deconv2d")
         self.in_planes = mod.in_planes
+        self.split_reference_half()
 
     @staticmethod
     def _c2d(x, f, stride, out=None):
@@ -451,6 +486,7 @@ class NativePrecise(_LevelBase):
         imgs = torch.empty((2 * B,) + tuple(left_image.shape[1:]), device=left.device, dtype=torch.float32)
         copy_rows(left_image, imgs[:B]); copy_rows(right_image, imgs[B:])
         s2 = self.encode(imgs, both)
+        lterm = self.left_term(lcat)
         s2l = s2[:B]
         f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)
         C32 = self.deconv4.cout
@@ -460,14 +496,15 @@ class NativePrecise(_LevelBase):
         g = _lib.contiguous(self._c2d(cat2.unsqueeze(2), self.concat, 1).squeeze(2))
         mask = torch.empty((B, 9, 4 * H, 4 * W), device=left.device, dtype=torch.float32)
         self._deconv(g, self.deconv2, mask, mask.stride(0))
-        return both, mask
+        return both, (mask, lterm)
 
-    def __call__(self, both, mask, ds, prev_info):
+    def __call__(self, both, mask_lterm, ds, prev_info):
         B = both.shape[0] // 2
         H, W = both.shape[-2:]
+        mask, lterm = mask_lterm
         lcat, rcat = both[:B], both[B:]
-        raw = TF.block_cost(lcat, rcat, ds, self.scales)
-        cost, off = self.heads(self.init3d(raw))
+        raw = TF.block_cost_warped(lcat, rcat, ds, self.scales)
+        cost, off = self.heads(self.init3d(raw, lterm))
         disp, mem_s, mem_c = TF.topk_softargmax(cost, ds, off, k=self.topk)
         full = torch.empty((B, 1, 4 * H, 4 * W), device=both.device, dtype=torch.float32)
         rc = _lib.lib().ts_unet_upsample_fwd(_lib.ptr(mask), _lib.ptr(disp), _lib.ptr(full), B, H, W, 4 * H, 4 * W, _stream())
@@ -495,7 +532,7 @@ class NativeAggregator:
         self.fast = torch.cuda.Stream(device=dev, priority=-1)
         self.overlap = True
 
-    def _pyramid(self, l8, l16, r8, r16, prev_info, out, masks=(None, None)):
+    def _pyramid(self, l8, l16, r8, r16, prev_info, out, masks=(None, None, None)):
         rng = 4
         disps, costs, offs, samples, ranges = out
         d, c, o, s = self.coarse(_lib.contiguous(l16), _lib.contiguous(r16), prev_info, masks[0])
@@ -505,7 +542,7 @@ class NativeAggregator:
         if nl:
             resize_bilinear(lm, d.shape[-2:], d.shape[-1] / lm.shape[-1], out=ds[:, :nl])
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
-        d, c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, masks[1])
+        d, c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, masks[1], masks[2])
         low, high, ds = range_candidates(d, rng)
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
@@ -530,6 +567,7 @@ class NativeAggregator:
                 # convex-upsampling logits of the coarse and fine levels depend on the features only
                 with torch.cuda.stream(aux):
                     mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
+                    ltf = self.fine.left_term(_lib.contiguous(l8))
 
                 def joined(m):
                     def get():
@@ -539,7 +577,7 @@ class NativeAggregator:
                 # the ten wide launches go out first, then the long chain
                 both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
                 with torch.cuda.stream(self.fast):
-                    ds = self._pyramid(l8, l16, r8, r16, prev_info, out, (joined(mc), joined(mf)))
+                    ds = self._pyramid(l8, l16, r8, r16, prev_info, out, (joined(mc), joined(mf), joined(ltf)))
                 _lib.check(_lib.lib().ts_stream_fork(fastp, mainp), "ts_stream_fork")
                 full, d, c, o, s = self.precise(both, mask, ds, prev_info)
             finally:

@@ -28,8 +28,10 @@ constexpr int TR = 4;   // feature rows per workgroup == pooling footprint of sc
 struct Shape {
   int B, C, H, W, D, scales;
   int G;          // C / 8
-  int mainC;      // C (int path) or 2C (sampled path)
+  int mainC;      // C (int path) or 2C (sampled path; C when the reference half is omitted)
   int Ctot;       // mainC + scales * G
+  int omit_ref;   // sampled path: do not write the D-fold broadcast of `left` (see ts_block_cost_sampled_warped_fwd)
+  int tch;        // sampled path: first channel of the warped half (C, or 0 when the reference half is omitted)
   int H1, W1, H2, W2;
   int nbx, nby;   // 4x4 pixel blocks
   int nbxp;       // nbx padded so that a wavefront does not straddle candidates (when cheap)
@@ -269,8 +271,8 @@ block_cost_main(const float* __restrict__ L, const float* __restrict__ R,
           }
           float* pl = plane0 + static_cast<size_t>(g * GRP + c) * cstride + rowoff;
           if constexpr (SAMPLED) {
-            st4<VEC>(pl, x4, W, lv4);                                              // reference half
-            st4<VEC>(pl + static_cast<size_t>(C) * cstride, x4, W, pack(tv));      // warped half
+            if (!s.omit_ref) st4<VEC>(pl, x4, W, lv4);                             // reference half
+            st4<VEC>(pl + static_cast<size_t>(s.tch) * cstride, x4, W, pack(tv));  // warped half
           } else {
             st4<VEC>(pl, x4, W, make_float4(-ev[0] * ev[0], -ev[1] * ev[1], -ev[2] * ev[2], -ev[3] * ev[3]));
           }
@@ -396,7 +398,7 @@ __device__ __forceinline__ float comp(const float4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-template <bool SAMPLED, bool VEC, int NP>
+template <bool SAMPLED, bool VEC, int NP, bool REF>   // REF: write the reference (left-repeat) half
 __global__ void __launch_bounds__(512, 4)   // <= 128 VGPRs: three 5-wave workgroups per CU
 block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
                 const float* __restrict__ disp, float* __restrict__ out,
@@ -519,8 +521,12 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
           }
           const unsigned plane = static_cast<unsigned>(g * GRP + c) * dHW;        // uniform (SGPR)
           if constexpr (SAMPLED) {
-            bst4<VEC>(orsrc, loff, plane, x4, W, lv4);                              // reference half
-            bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));   // warped half
+            if constexpr (REF) {
+              bst4<VEC>(orsrc, loff, plane, x4, W, lv4);                                           // reference half
+              bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));    // warped half
+            } else {
+              bst4<VEC>(orsrc, loff, plane, x4, W, pack(tv));                                     // warped half only
+            }
           } else {
             bst4<VEC>(orsrc, loff, plane, x4, W,
                       make_float4(-ev[0] * ev[0], -ev[1] * ev[1], -ev[2] * ev[2], -ev[3] * ev[3]));
@@ -639,7 +645,7 @@ block_cost_upsample(const float* __restrict__ P1, const float* __restrict__ P2,
   }
 }
 
-int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales) {
+int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales, bool omit_ref = false) {
   TS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, TS_ERR_SHAPE, "block_cost: non-positive size");
   TS_REQUIRE(C % GRP == 0, TS_ERR_SHAPE, "block_cost: C=%d is not a multiple of 8 (block_cost.py:9)", C);
   TS_REQUIRE(scales >= 1 && scales <= 3, TS_ERR_UNSUPPORTED, "block_cost: scales=%d outside 1..3", scales);
@@ -649,7 +655,9 @@ int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int sc
   TS_REQUIRE(B <= 65535 && C / GRP <= 65535, TS_ERR_UNSUPPORTED, "block_cost: grid too large");
   s.B = B; s.C = C; s.H = H; s.W = W; s.D = D; s.scales = scales;
   s.G = C / GRP;
-  s.mainC = sampled ? 2 * C : C;
+  s.omit_ref = (sampled && omit_ref) ? 1 : 0;
+  s.tch = s.omit_ref ? 0 : C;
+  s.mainC = (sampled && !omit_ref) ? 2 * C : C;
   s.Ctot = s.mainC + scales * s.G;
   s.H1 = H / 2; s.W1 = W / 2; s.H2 = H / 4; s.W2 = W / 4;
   s.nbx = (W + 3) / 4; s.nby = (H + 3) / 4;
@@ -676,9 +684,9 @@ size_t pooled_bytes(const Shape& s, int lvl) {
 
 template <bool SAMPLED>
 int launch_fwd(const float* left, const float* right, const float* disp, float* out, void* workspace,
-               int B, int C, int H, int W, int D, int scales, void* stream) {
+               int B, int C, int H, int W, int D, int scales, void* stream, bool omit_ref = false) {
   Shape s;
-  if (int rc = make_shape(s, SAMPLED, B, C, H, W, D, scales)) return rc;
+  if (int rc = make_shape(s, SAMPLED, B, C, H, W, D, scales, omit_ref)) return rc;
   TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(out);
   if (SAMPLED) TS_REQUIRE_PTR(disp);
   if (scales > 1) TS_REQUIRE_PTR(workspace);
@@ -701,9 +709,15 @@ int launch_fwd(const float* left, const float* right, const float* disp, float* 
   const dim3 grid(s.nby, s.G, B);
   hipStream_t st = ts::as_stream(stream);
 
-#define TS_LAUNCH_FAST(V, N)                                                                     \
-  hipLaunchKernelGGL((block_cost_fast<SAMPLED, V, N>), grid, dim3(threads), lds_bytes, st,       \
-                     left, right, disp, out, P1, P2, s)
+#define TS_LAUNCH_FAST(V, N)                                                                        \
+  do {                                                                                               \
+    if (SAMPLED && omit_ref)                                                                         \
+      hipLaunchKernelGGL((block_cost_fast<SAMPLED, V, N, false>), grid, dim3(threads), lds_bytes, st, \
+                         left, right, disp, out, P1, P2, s);                                         \
+    else                                                                                             \
+      hipLaunchKernelGGL((block_cost_fast<SAMPLED, V, N, true>), grid, dim3(threads), lds_bytes, st, \
+                         left, right, disp, out, P1, P2, s);                                         \
+  } while (0)
 #define TS_LAUNCH_WIDE(V)                                                                        \
   hipLaunchKernelGGL((block_cost_main<SAMPLED, V, false, 1>), grid, dim3(threads), 0, st,        \
                      left, right, disp, out, P1, P2, s)
@@ -1018,6 +1032,12 @@ extern "C" int ts_block_cost_sampled_fwd(const float* left, const float* right, 
                                          void* workspace, int B, int C, int H, int W, int D, int scales,
                                          void* stream) {
   return launch_fwd<true>(left, right, disp, out, workspace, B, C, H, W, D, scales, stream);
+}
+
+extern "C" int ts_block_cost_sampled_warped_fwd(const float* left, const float* right, const float* disp, float* out,
+                                                void* workspace, int B, int C, int H, int W, int D, int scales,
+                                                void* stream) {
+  return launch_fwd<true>(left, right, disp, out, workspace, B, C, H, W, D, scales, stream, true);
 }
 
 extern "C" size_t ts_block_cost_bwd_workspace_bytes(int B, int C, int H, int W, int D, int scales) {

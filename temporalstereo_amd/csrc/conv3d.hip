@@ -71,6 +71,8 @@ struct IG {
   int ksplit, kspan;            // split-K: this many slices of `kspan` input channels each (partials -> workspace)
   float* partial;               // [ksplit][B][Cout][Do*Ho*Wo] raw sums when ksplit > 1
   int B;
+  const float* addend;          // [B][Cout][Ho*Wo] added to every depth plane's sum before scale/shift (or null)
+  long long add_bstride;
 };
 
 template <int MODE, int KT, int ST, int DL>
@@ -358,12 +360,18 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       continue;
     }
     float* yb = y + static_cast<size_t>(b) * p.out_bstride + opix;
+    const size_t hw_o = static_cast<size_t>(p.Ho) * p.Wo;
+    const float* ab = (MODE == MODE_HW && p.addend) ? p.addend + static_cast<size_t>(b) * p.add_bstride + (opix - static_cast<size_t>(od) * hw_o) : nullptr;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + cb * 16 + kq * 4 + r;
-        if (co < p.Cout) yb[static_cast<size_t>(co) * p.out_cstride] = apply_act(acc[cb][pb][r] * scale[co] + shift[co], p.act, p.act_param);
+        if (co < p.Cout) {
+          float v = acc[cb][pb][r];
+          if (MODE == MODE_HW && ab) v += ab[static_cast<size_t>(co) * hw_o];
+          yb[static_cast<size_t>(co) * p.out_cstride] = apply_act(v * scale[co] + shift[co], p.act, p.act_param);
+        }
       }
   }
 }
@@ -372,7 +380,8 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 __global__ void __launch_bounds__(256)
 conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ scale, const float* __restrict__ shift,
                    float* __restrict__ y, int B, int Cout, long long plane, int ksplit, int act, float act_param,
-                   long long out_bstride, long long out_cstride) {
+                   long long out_bstride, long long out_cstride, const float* __restrict__ addend, long long add_bstride,
+                   long long hw_o) {
   const long long n = static_cast<long long>(B) * Cout * plane;
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
@@ -381,6 +390,7 @@ conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ 
     const int co = static_cast<int>(t % Cout), b = static_cast<int>(t / Cout);
     float v = 0.f;
     for (int k = 0; k < ksplit; ++k) v += partial[k * n + i];
+    if (addend) v += addend[b * add_bstride + co * hw_o + px % hw_o];
     y[b * out_bstride + co * out_cstride + px] = apply_act(v * scale[co] + shift[co], act, act_param);
   }
 }
@@ -474,7 +484,8 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
                                 int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
                                 int transposed, int act, float act_param,
                                 long long in_bstride, long long in_cstride, long long out_bstride,
-                                long long out_cstride, void* workspace, size_t workspace_bytes, void* stream) {
+                                long long out_cstride, const float* addend, long long addend_bstride,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw: non-positive size");
   TS_REQUIRE(stride == 1 || stride == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: stride must be 1 or 2");
   TS_REQUIRE(dilation == 1 || dilation == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: dilation must be 1 or 2");
@@ -492,6 +503,8 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
+  p.addend = addend; p.add_bstride = addend_bstride;
+  TS_REQUIRE(!(addend && transposed), TS_ERR_UNSUPPORTED, "conv3d_hw: no addend in the transposed form");
   TS_REQUIRE(ig_extent(p, 9), TS_ERR_UNSUPPORTED, "conv3d_hw: a batch element of x spans 2 GiB or more");
   if (transposed) {
     p.Ho = 2 * H; p.Wo = 2 * W;
@@ -519,7 +532,8 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   long long blocks = (static_cast<long long>(B) * Cout * plane + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(conv_splitk_finish, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, p.partial, scale, shift, y,
-                     B, Cout, plane, ksplit, act, act_param, out_bstride, out_cstride);
+                     B, Cout, plane, ksplit, act, act_param, out_bstride, out_cstride, addend, addend_bstride,
+                     static_cast<long long>(p.Ho) * p.Wo);
   return ts::launched("conv_splitk_finish");
 }
 
@@ -548,6 +562,7 @@ extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* sc
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   p.tiles_x = 1; p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
+  p.addend = nullptr; p.add_bstride = 0;
   TS_REQUIRE(ig_extent(p, k), TS_ERR_UNSUPPORTED, "conv3d_d: a batch element of x spans 2 GiB or more");
   const int tiles = (H * W + 255) / 256;
   if (k == 1) return launch_ig<MODE_D, 1, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
@@ -569,6 +584,7 @@ extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const floa
   p.in_bstride = static_cast<long long>(Cin) * H * W; p.in_cstride = static_cast<long long>(H) * W;
   p.out_bstride = out_bstride; p.out_cstride = 4ll * H * W;
   p.tiles_x = (W + 31) / 32; p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
+  p.addend = nullptr; p.add_bstride = 0;
   TS_REQUIRE(ig_extent(p, 16), TS_ERR_UNSUPPORTED, "deconv2d: a batch element of x spans 2 GiB or more");
   const int tiles = ((H + 7) / 8) * p.tiles_x;
   return launch_ig<MODE_HWT, 16, 1, 1>(x, w_t, scale, shift, y, p, B, tiles * 4, 1, ts::as_stream(stream));

@@ -52,6 +52,7 @@ struct Entry {
 // every launching entry point of include/ts_hip.h
 const Entry kTable[] = {
     TS_PLAN_OP(ts_block_cost_int_fwd),      TS_PLAN_OP(ts_block_cost_sampled_fwd),
+    TS_PLAN_OP(ts_block_cost_sampled_warped_fwd),
     TS_PLAN_OP(ts_block_cost_int_bwd),      TS_PLAN_OP(ts_block_cost_sampled_bwd),
     TS_PLAN_OP(ts_topk_softargmax_fwd),     TS_PLAN_OP(ts_topk_softargmax_bwd),
     TS_PLAN_OP(ts_softargmin_fwd),          TS_PLAN_OP(ts_softargmin_bwd),

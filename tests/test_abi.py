@@ -52,6 +52,31 @@ def test_argument_errors_without_gpu(built_lib):
         _lib.check(rc, "ts_block_cost_sampled_fwd")
 
 
+def test_plan_api_without_gpu(built_lib):
+    """Recording validates names and arity up front (csrc/plan.hip); nothing is launched here."""
+    import ctypes as C
+    from temporalstereo_amd import _lib
+    L = _lib.lib()
+    plan = L.ts_plan_create()
+    assert plan
+    w = (C.c_ulonglong * 32)()
+    assert L.ts_plan_add_call(plan, b"ts_no_such_entry", w, 0) == -3
+    assert L.ts_plan_add_call(plan, b"ts_conv_cout_pad", w, 1) == -3            # a query, not a launch
+    assert L.ts_plan_add_call(plan, b"ts_copy_rows_fwd", w, 3) == -2            # takes 7 arguments
+    assert L.ts_plan_add_call(plan, b"ts_copy_rows_fwd", w, 7) == 0
+    assert L.ts_plan_length(plan) == 1
+    assert L.ts_plan_run(plan) == -2 and b"copy_rows" in L.ts_last_error_string()   # zero rows: refused, not launched
+    assert L.ts_plan_run(None) == -1
+    L.ts_plan_destroy(plan)
+    # every launching entry point of the header can be recorded: the plan's table is complete
+    launching = [n for n, (res, _) in _lib.SIGNATURES.items() if res is _lib.c_int and n not in _lib._QUERIES]
+    plan = L.ts_plan_create()
+    for n in launching:
+        assert L.ts_plan_add_call(plan, n.encode(), w, len(_lib.SIGNATURES[n][1])) == 0, n
+    assert L.ts_plan_length(plan) == len(launching)
+    L.ts_plan_destroy(plan)
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     import temporalstereo_amd as ts

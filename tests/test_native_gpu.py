@@ -90,16 +90,93 @@ def test_resize_add_act_pool_and_bilinear_vs_torch():
     np.testing.assert_allclose(native.resize_bilinear(y, (8, 15), 2.5).cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_conv_hw_addend_is_the_split_of_the_input_channels():
+    """layer(x) == rest(x[:, n:], addend = head(x[:, :n]) repeated over D) when x[:, :n] is constant over D
+    (the reference half of the sampled cost volume, block_cost.py:51)."""
+    from temporalstereo_amd.layers import Conv3d
+    from temporalstereo_amd.aggregation import native
+    dev = _dev()
+    torch.manual_seed(5)
+    n, cin, cout, D = 16, 40, 8, 5
+    m = Conv3d(cin, cout, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), bias=False, norm=('BN3d', cout),
+               activation='SiLU').to(dev).eval()
+    m.norm.running_mean.normal_(0, 0.2); m.norm.running_var.uniform_(0.5, 1.5)
+    left = _rand(7, 2, n, 19, 45, dev=dev)
+    rest_in = _rand(8, 2, cin - n, D, 19, 45, dev=dev)
+    x = torch.cat([left.unsqueeze(2).expand(-1, -1, D, -1, -1), rest_in], 1)
+    with torch.no_grad():
+        ref = m(x)
+    head, rest = native.fold_split_input(native.fold_wrapper(m, "hw"), n)
+    got = native.conv_hw(rest_in, rest, addend=native.conv_hw(left.unsqueeze(2), head))
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_block_cost_warped_is_the_volume_without_its_reference_half():
+    import temporalstereo_amd.functional as TF
+    dev = _dev()
+    l, r = _rand(11, 2, 32, 24, 40, dev=dev), _rand(12, 2, 32, 24, 40, dev=dev)
+    d = t(synth.uniform(13, "d", (2, 5, 24, 40), -2.0, 30.0), dev)
+    full = TF.block_cost(l, r, d, 3)
+    part = TF.block_cost_warped(l, r, d, 3)
+    assert part.shape[1] == full.shape[1] - 32
+    assert torch.equal(part, full[:, 32:])
+
+
+def test_copy_rows_and_stream_fork():
+    from temporalstereo_amd import _lib
+    from temporalstereo_amd.aggregation import native
+    dev = _dev()
+    big = torch.zeros(3, 10, 4, 5, device=dev)
+    src = _rand(21, 3, 4, 4, 5, dev=dev)
+    native.copy_rows(src, big[:, 6:])
+    assert torch.equal(big[:, 6:], src) and float(big[:, :6].abs().sum()) == 0.0
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    out = torch.empty(1 << 22, device=dev)
+    with torch.cuda.stream(a):
+        out.fill_(3.0)
+    native._edge(a, b)                                   # b waits for a
+    with torch.cuda.stream(b):
+        out.mul_(2.0)
+    torch.cuda.synchronize()
+    assert float(out.min()) == 6.0 and float(out.max()) == 6.0
+
+
+def test_plan_replay_tracks_new_inputs_and_refuses_unknown_calls():
+    """The recorded plan re-issues the pass on whatever the static input buffers hold."""
+    from temporalstereo_amd import _lib
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    g = load("agg_tiny_single"); dev = _dev()
+    dims = dims_from_golden(g)
+    net = _build(dims, int(g["seed"]), dev, golden=g)
+    lf, rf, il, ir, prev = aggregator_inputs(g, dims, dev)
+    plan = InferenceEngine(net, backend="native", replay="plan")
+    eager = InferenceEngine(net, backend="native", replay="eager")
+    plan(lf, rf, il, ir, dict(prev))                                   # records
+    lf2 = [x.flip(-1).contiguous() for x in lf]; rf2 = [x.flip(-1).contiguous() for x in rf]
+    want = eager(lf2, rf2, il.flip(-1).contiguous(), ir.flip(-1).contiguous(), dict(prev))[0][0].clone()
+    got = plan(lf2, rf2, il.flip(-1).contiguous(), ir.flip(-1).contiguous(), dict(prev))[0][0]
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-4)
+    cap = next(iter(plan._graphs.values()))
+    assert len(cap.recorder) > 50
+    L = _lib.lib()
+    p = L.ts_plan_create()
+    words = (_lib.ctypes.c_ulonglong * 1)(0)
+    assert L.ts_plan_add_call(p, b"ts_version", words, 0) == -3          # not a launching entry point
+    assert L.ts_plan_add_call(p, b"ts_stream_fork", words, 1) == -2      # wrong arity
+    assert L.ts_plan_length(p) == 0 and L.ts_plan_run(p) == 0
+    L.ts_plan_destroy(p)
+
+
 # ------------------------------------------------------------------------------------------- end to end
 @pytest.mark.parametrize("name", ["agg_tiny_single", "agg_tiny_temporal"])
-@pytest.mark.parametrize("graph", [False, True])
-def test_native_engine_matches_reference(name, graph):
+@pytest.mark.parametrize("replay", ["eager", "graph", "plan"])
+def test_native_engine_matches_reference(name, replay):
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     g = load(name); dev = _dev()
     dims = dims_from_golden(g)
     net = _build(dims, int(g["seed"]), dev, golden=g)
     lf, rf, il, ir, prev = aggregator_inputs(g, dims, dev)
-    eng = InferenceEngine(net, backend="native", graph=graph)
+    eng = InferenceEngine(net, backend="native", replay=replay)
     outs = eng(lf, rf, il, ir, prev)
     _check_against_golden(g, outs)
     outs2 = eng(lf, rf, il, ir, prev)            # replay / second call gives the same answer

@@ -67,6 +67,7 @@ struct IG {
   float act_param;
   long long in_bstride, in_cstride, out_bstride, out_cstride;
   unsigned in_bytes, w_bytes;   // extent of one batch element of x / of the weight array (buffer range checks)
+  unsigned out_bytes, part_bytes;   // ... of one batch element of y / of one (slice, batch) block of the partials
   int tiles_x, co_groups;
   int ksplit, kspan;            // split-K: this many slices of `kspan` input channels each (partials -> workspace)
   float* partial;               // [ksplit][B][Cout][Do*Ho*Wo] raw sums when ksplit > 1
@@ -216,6 +217,17 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
+  // epilogue constants of this lane's channels, requested now so that their round trip is over long
+  // before the epilogue (on the small layers it would otherwise sit on the critical path)
+  float esc[CB][4], esh[CB][4];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = min(co0 + cb * 16 + kq * 4 + r, p.coutp - 1);     // clamped: unconditional loads, no branches
+      esc[cb][r] = scale[co];
+      esh[cb][r] = shift[co];
+    }
 
   // ---- register prefetch of one K chunk: branch-free buffer loads (zero padding, ragged channel
   // counts and partial tiles all resolve to out-of-range offsets or zero weights) ------------------
@@ -331,47 +343,46 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     }
   }
 
-  // ---- epilogue: lane holds channels kq*4 + r of pixel j of each 16x16 tile ----------------------
+  // ---- epilogue: lane holds channels kq*4 + r of pixel j of each 16x16 tile.  Stores go through a
+  // buffer descriptor: channels past Cout and pixels outside the image get an out-of-range offset and
+  // are dropped by the hardware, so there is not a single branch around a memory operation here. ----
+  const size_t hw_o = static_cast<size_t>(p.Ho) * p.Wo;
+  const unsigned oplane = static_cast<unsigned>(p.Do) * static_cast<unsigned>(hw_o);          // one output channel
+  const bool split = p.ksplit > 1;
+  const __amdgpu_buffer_rsrc_t yr = split
+      ? ig_rsrc(p.partial + (static_cast<size_t>(ks) * p.B + b) * p.Cout * oplane, p.part_bytes)
+      : ig_rsrc(y + static_cast<size_t>(b) * p.out_bstride, p.out_bytes);
+  const unsigned ocs = split ? oplane * 4u : static_cast<unsigned>(p.out_cstride) * 4u;
+  const float* ab = (MODE == MODE_HW && p.addend) ? p.addend + static_cast<size_t>(b) * p.add_bstride : nullptr;
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
-    size_t opix;
+    unsigned opix, ppix = 0;          // element index inside a channel of y / inside one depth plane
+    bool inside;
     if (MODE == MODE_D) {
       const unsigned px = px0 + wave * 64 + pb * 16 + j;
-      if (px >= HW) continue;
-      opix = static_cast<size_t>(od) * HW + px;
+      inside = px < HW;
+      opix = static_cast<unsigned>(od) * HW + px;
     } else {
       int oy = ty0 + wave * 2 + (pb >> 1), ox = tx0 + (pb & 1) * 16 + j;
       if (MODE == MODE_HWT) {
-        if (oy >= p.H || ox >= p.W) continue;
+        inside = oy < p.H && ox < p.W;
         oy = 2 * oy + pa; ox = 2 * ox + pbit;
-      } else if (oy >= p.Ho || ox >= p.Wo) continue;
-      opix = (static_cast<size_t>(od) * p.Ho + oy) * p.Wo + ox;
+      } else inside = oy < p.Ho && ox < p.Wo;
+      ppix = static_cast<unsigned>(oy) * p.Wo + ox;
+      opix = static_cast<unsigned>(od) * static_cast<unsigned>(hw_o) + ppix;
     }
-    if (p.ksplit > 1) {          // raw partial sums; conv_splitk_finish applies the epilogue
-      const size_t plane = static_cast<size_t>(p.Do) * p.Ho * p.Wo;
-      float* pb_ = p.partial + (static_cast<size_t>(ks) * p.B + b) * p.Cout * plane + opix;
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + cb * 16 + kq * 4 + r;
-          if (co < p.Cout) pb_[static_cast<size_t>(co) * plane] = acc[cb][pb][r];
-        }
-      continue;
-    }
-    float* yb = y + static_cast<size_t>(b) * p.out_bstride + opix;
-    const size_t hw_o = static_cast<size_t>(p.Ho) * p.Wo;
-    const float* ab = (MODE == MODE_HW && p.addend) ? p.addend + static_cast<size_t>(b) * p.add_bstride + (opix - static_cast<size_t>(od) * hw_o) : nullptr;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + cb * 16 + kq * 4 + r;
-        if (co < p.Cout) {
-          float v = acc[cb][pb][r];
-          if (MODE == MODE_HW && ab) v += ab[static_cast<size_t>(co) * hw_o];
-          yb[static_cast<size_t>(co) * p.out_cstride] = apply_act(v * scale[co] + shift[co], p.act, p.act_param);
+        const unsigned off = (inside && co < p.Cout) ? opix * 4u + static_cast<unsigned>(co) * ocs : kOOB;   // per lane: VGPR
+        float v = acc[cb][pb][r];
+        if (!split) {
+          if (MODE == MODE_HW && ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * hw_o + (inside ? ppix : 0u)];
+          v = apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param);
         }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, off, 0, 0);
       }
   }
 }
@@ -434,6 +445,14 @@ int launch_nc(long long wgs, const float* x, const float* w, const float* scale,
 template <int MODE, int KT, int ST, int DL>
 int launch_ig(const float* x, const float* w, const float* scale, const float* shift, float* y, IG p, int B,
               int grid_x, int grid_y, hipStream_t st) {
+  {   // output extents behind the epilogue's buffer descriptors (32-bit offsets per batch element)
+    const unsigned long long plane = static_cast<unsigned long long>(p.Do) * p.Ho * p.Wo;
+    const unsigned long long out_b = (static_cast<unsigned long long>(p.Cout - 1) * p.out_cstride + plane) * 4ull;
+    const unsigned long long part_b = static_cast<unsigned long long>(p.Cout) * plane * 4ull;
+    TS_REQUIRE(out_b < 0x7fffffffull && part_b < 0x7fffffffull && p.out_cstride >= 0, TS_ERR_UNSUPPORTED,
+               "conv: a batch element of y spans 2 GiB or more");
+    p.out_bytes = static_cast<unsigned>(out_b); p.part_bytes = static_cast<unsigned>(part_b);
+  }
   // widest channel block that still leaves enough workgroups to fill the chip
   const int need = (p.Cout + 15) / 16;                 // 16-channel blocks
   int cb = need >= 4 ? 4 : (need >= 2 ? 2 : 1);
@@ -455,6 +474,7 @@ bool ig_extent(IG& p, int KT) {
   const unsigned long long w_b = static_cast<unsigned long long>(p.Cin) * KT * p.coutp * 4ull;
   if (in_b >= 0x7fffffffull || w_b >= 0x7fffffffull || p.in_cstride < 0) return false;
   p.in_bytes = static_cast<unsigned>(in_b); p.w_bytes = static_cast<unsigned>(w_b);
+  p.out_bytes = p.part_bytes = 0;             // set by ig_out_extent once the output geometry is known
   return true;
 }
 

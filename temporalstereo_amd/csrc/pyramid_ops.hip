@@ -94,6 +94,23 @@ pool5_avgmax_kernel(const float* __restrict__ x, float* __restrict__ oavg, float
   const float* xp = x + static_cast<size_t>(b) * p.x_bstride + static_cast<size_t>(c) * p.x_cstride;
   float* ap = oavg + static_cast<size_t>(b) * p.avg_bstride + static_cast<size_t>(c) * p.avg_cstride;
   float* mp = omax + static_cast<size_t>(b) * p.max_bstride + static_cast<size_t>(c) * p.max_cstride;
+  // this thread's (up to two) elements of the haloed plane tile: clamped source offset + padding flag
+  constexpr int TW = PT_X + 4, TN = (PT_Y + 4) * TW;
+  int soff[2], lidx[2];
+  bool pad[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = min(static_cast<int>(threadIdx.x) + 256 * e, TN - 1);       // the surplus threads of e == 1 repeat the last element
+    const int cx = i % TW, cy = i / TW;
+    const int gy = ty0 + cy - 2, gx = tx0 + cx - 2;
+    pad[e] = !(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W);
+    soff[e] = min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1);
+    lidx[e] = cy * (TW + 1) + cx;
+  }
+  float* tl = &tile[0][0];
+  float nxt[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) nxt[e] = xp[soff[e]];                            // plane 0
   float rs[5], rm[5];       // 2-D pooled planes d-4 .. d (ring kept in order by shifting)
 #pragma unroll
   for (int i = 0; i < 5; ++i) { rs[i] = 0.f; rm[i] = -INFINITY; }
@@ -101,21 +118,21 @@ pool5_avgmax_kernel(const float* __restrict__ x, float* __restrict__ oavg, float
     float s2 = 0.f, m2 = -INFINITY;
     if (d < p.D) {
       __syncthreads();
-      for (int i = threadIdx.x; i < (PT_Y + 4) * (PT_X + 4); i += blockDim.x) {
-        const int cx = i % (PT_X + 4), cy = i / (PT_X + 4);
-        const int gy = ty0 + cy - 2, gx = tx0 + cx - 2;
-        // zero for the average (count_include_pad), handled as -inf for the max via the flag below
-        tile[cy][cx] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? xp[d * HW + static_cast<size_t>(gy) * p.W + gx] : NAN;
-      }
+      // zero for the average (count_include_pad) and -inf for the max: padding is marked NaN in the tile
+#pragma unroll
+      for (int e = 0; e < 2; ++e) tl[lidx[e]] = pad[e] ? NAN : nxt[e];
       __syncthreads();
+      const int dn = min(d + 1, p.D - 1);                                      // next plane in flight under the 25 taps
+#pragma unroll
+      for (int e = 0; e < 2; ++e) nxt[e] = xp[dn * HW + soff[e]];
 #pragma unroll
       for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
           const float v = tile[ty + ky][tx + kx];
-          const bool pad = v != v;             // NaN marks padding
-          s2 += pad ? 0.f : v;
-          m2 = pad ? m2 : fmaxf(m2, v);
+          const bool isp = v != v;             // NaN marks padding
+          s2 += isp ? 0.f : v;
+          m2 = isp ? m2 : fmaxf(m2, v);
         }
     }
 #pragma unroll
@@ -146,6 +163,10 @@ struct Merge {
 // Conv3d(1->C, 1x1x1, no bias) + BatchNorm + SiLU of the remembered cost (coarse.py:42,98).
 constexpr int MERGE_CPB = 4;    // channels moved per workgroup row (grid.y walks channel groups)
 
+// DM: compile-time bound on the candidate count.  Every load is unconditional (indices clamped, results
+// selected afterwards) and issued before anything waits, so a lane pays ONE memory round trip for its
+// samples and one for its volume columns instead of one per candidate.
+template <int DM>
 __global__ void __launch_bounds__(256)
 merge_candidates_kernel(const float* __restrict__ vol, const float* __restrict__ samp, const float* __restrict__ mem_samp,
                         const float* __restrict__ mem_cost, const float* __restrict__ pw, const float* __restrict__ pscale,
@@ -154,40 +175,47 @@ merge_candidates_kernel(const float* __restrict__ vol, const float* __restrict__
   const int DT = p.D0 + p.K;
   const int c0 = blockIdx.y * MERGE_CPB;
   const long long n = static_cast<long long>(p.B) * p.HW;
+  const bool has_mem = mem_samp != nullptr && mem_cost != nullptr && p.K > 0;
+  const float* ms = has_mem ? mem_samp : vol;          // any readable address; the value is discarded
+  const float* mc = has_mem ? mem_cost : vol;
+  const int Kc = max(p.K, 1);
+  float w_[MERGE_CPB], sc_[MERGE_CPB], sh_[MERGE_CPB];
+#pragma unroll
+  for (int cc = 0; cc < MERGE_CPB; ++cc) {
+    const int c = min(c0 + cc, p.C - 1);
+    w_[cc] = p.K > 0 ? pw[c] : 0.f; sc_[cc] = p.K > 0 ? pscale[c] : 0.f; sh_[cc] = p.K > 0 ? pshift[c] : 0.f;
+  }
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
     const int b = static_cast<int>(i / p.HW);
     const int px = static_cast<int>(i - static_cast<long long>(b) * p.HW);
-    float s[MERGE_DMAX];
+    float s[DM], m[DM], v[DM][MERGE_CPB];
+    const float* vb = vol + static_cast<size_t>(b) * p.vol_bstride + px;
 #pragma unroll
-    for (int j = 0; j < MERGE_DMAX; ++j) {
-      float v = INFINITY;
-      if (j < p.D0) v = p.implicit_samples ? static_cast<float>(j) : samp[(static_cast<size_t>(b) * p.D0 + j) * p.HW + px];
-      else if (j < DT) v = mem_samp ? mem_samp[(static_cast<size_t>(b) * p.K + (j - p.D0)) * p.HW + px] : 0.f;
-      s[j] = v;
+    for (int j = 0; j < DM; ++j) {
+      const int jv = min(j, p.D0 - 1), jm = min(max(j - p.D0, 0), Kc - 1);
+      const size_t mo = has_mem ? (static_cast<size_t>(b) * p.K + jm) * p.HW + px : 0;
+      s[j] = p.implicit_samples ? static_cast<float>(j) : samp[(static_cast<size_t>(b) * p.D0 + jv) * p.HW + px];
+      const float a = ms[mo];
+      m[j] = mc[mo];
+      if (j >= p.D0) s[j] = (j < DT) ? (has_mem ? a : 0.f) : INFINITY;
+      if (!has_mem) m[j] = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < MERGE_CPB; ++cc)
+        v[j][cc] = vb[static_cast<size_t>(jv) * p.HW + static_cast<size_t>(min(c0 + cc, p.C - 1)) * p.vol_cstride];
     }
 #pragma unroll
-    for (int j = 0; j < MERGE_DMAX; ++j) {
-      if (j >= DT) continue;
+    for (int j = 0; j < DM; ++j) {
       int rank = 0;
 #pragma unroll
-      for (int q = 0; q < MERGE_DMAX; ++q)
-        if (q < DT) rank += (s[q] < s[j]) || (s[q] == s[j] && q < j);
-      if (c0 == 0) out_samp[(static_cast<size_t>(b) * DT + rank) * p.HW + px] = s[j];
-      float* ov = out_vol + static_cast<size_t>(b) * p.out_bstride + static_cast<size_t>(rank) * p.HW + px;
-      if (j < p.D0) {
-        const float* iv = vol + static_cast<size_t>(b) * p.vol_bstride + static_cast<size_t>(j) * p.HW + px;
+      for (int q = 0; q < DM; ++q) rank += (s[q] < s[j]) || (s[q] == s[j] && q < j);     // padding (inf) ranks last
+      if (j < DT) {
+        if (c0 == 0) out_samp[(static_cast<size_t>(b) * DT + rank) * p.HW + px] = s[j];
+        float* ov = out_vol + static_cast<size_t>(b) * p.out_bstride + static_cast<size_t>(rank) * p.HW + px;
 #pragma unroll
         for (int cc = 0; cc < MERGE_CPB; ++cc) {
-          const int c = c0 + cc;
-          if (c < p.C) ov[static_cast<size_t>(c) * p.out_cstride] = iv[static_cast<size_t>(c) * p.vol_cstride];
-        }
-      } else {
-        const float m = mem_cost ? mem_cost[(static_cast<size_t>(b) * p.K + (j - p.D0)) * p.HW + px] : 0.f;
-#pragma unroll
-        for (int cc = 0; cc < MERGE_CPB; ++cc) {
-          const int c = c0 + cc;
-          if (c < p.C) ov[static_cast<size_t>(c) * p.out_cstride] = silu(pw[c] * m * pscale[c] + pshift[c]);
+          const float val = (j < p.D0) ? v[j][cc] : silu(w_[cc] * m[j] * sc_[cc] + sh_[cc]);
+          if (c0 + cc < p.C) ov[static_cast<size_t>(c0 + cc) * p.out_cstride] = val;
         }
       }
     }
@@ -218,7 +246,8 @@ convex_upsample_kernel(const float* __restrict__ mask, const float* __restrict__
       const float e = expf(m[k] - mx);
       den += e;
       const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? dp[yy * W + xx] * disp_scale : 0.f;
+      const float dv = dp[min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];        // unconditional; zero padding by select
+      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? dv * disp_scale : 0.f;
       acc += e * v;
     }
     out[i] = acc / den;
@@ -242,22 +271,36 @@ unet_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ d
     lin_src(sw, ox, w, x0, x1, lx);
     const float* mp = mask + static_cast<size_t>(b) * 9 * HWo + static_cast<size_t>(oy) * Wo + ox;
     const float* dp = disp + static_cast<size_t>(b) * h * w;
+    // All 9 logits and the 4x4 disparity patch around (y0, x0) are requested before anything is used:
+    // the 36 (tap, bilinear corner) reads of the reference all land in that patch.
     float m[9], mx = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { m[k] = mp[k * HWo]; mx = fmaxf(mx, m[k]); }
+    for (int k = 0; k < 9; ++k) m[k] = mp[k * HWo];
+    float pd[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const float dv = dp[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+        // disp * w_out / w_in in the reference's evaluation order (module.py:478); zero padding of unfold
+        pd[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dv * static_cast<float>(Wo) / static_cast<float>(w) : 0.f;
+      }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) mx = fmaxf(mx, m[k]);
+    const bool iy = y1 > y0, ix = x1 > x0;
     float den = 0.f, acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const float e = expf(m[k] - mx);
       den += e;
-      const int dy = k / 3 - 1, dx = k % 3 - 1;
-      auto at = [&](int yy, int xx) {
-        yy += dy; xx += dx;
-        // disp * w_out / w_in in the reference's evaluation order (module.py:478)
-        return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dp[yy * w + xx] * static_cast<float>(Wo) / static_cast<float>(w) : 0.f;
-      };
-      const float top = (1.f - lx) * at(y0, x0) + lx * at(y0, x1);
-      const float bot = (1.f - lx) * at(y1, x0) + lx * at(y1, x1);
+      const int ry = k / 3, rx = k % 3;            // patch row / column of (y0 + dy, x0 + dx)
+      const float a00 = pd[ry][rx];
+      const float a01 = ix ? pd[ry][rx + 1] : a00;
+      const float a10 = iy ? pd[ry + 1][rx] : a00;
+      const float a11 = iy ? (ix ? pd[ry + 1][rx + 1] : pd[ry + 1][rx]) : a01;
+      const float top = (1.f - lx) * a00 + lx * a01;
+      const float bot = (1.f - lx) * a10 + lx * a11;
       acc += e * ((1.f - ly) * top + ly * bot);
     }
     out[i] = acc / den;
@@ -368,9 +411,14 @@ extern "C" int ts_merge_candidates_fwd(const float* volume, const float* sample,
   Merge p;
   p.B = B; p.C = C; p.D0 = D0; p.K = K; p.HW = H * W; p.implicit_samples = sample ? 0 : 1;
   p.vol_bstride = vol_bstride; p.vol_cstride = vol_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
-  hipLaunchKernelGGL(merge_candidates_kernel, dim3(grid_for(static_cast<long long>(B) * H * W, 256), (C + MERGE_CPB - 1) / MERGE_CPB), dim3(256), 0,
-                     ts::as_stream(stream), volume, sample, mem_sample, mem_cost, past_w, past_scale, past_shift,
-                     out_sample, out_volume, p);
+  const dim3 grid(grid_for(static_cast<long long>(B) * H * W, 256), (C + MERGE_CPB - 1) / MERGE_CPB);
+#define TS_MERGE(DMV)                                                                                              \
+  hipLaunchKernelGGL(merge_candidates_kernel<DMV>, grid, dim3(256), 0, ts::as_stream(stream), volume, sample,      \
+                     mem_sample, mem_cost, past_w, past_scale, past_shift, out_sample, out_volume, p)
+  if (D0 + K <= 8) TS_MERGE(8);
+  else if (D0 + K <= 14) TS_MERGE(14);
+  else TS_MERGE(MERGE_DMAX);
+#undef TS_MERGE
   return ts::launched("merge_candidates_kernel");
 }
 

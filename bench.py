@@ -223,7 +223,8 @@ def main():
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     mode = a.mode
     replay = {"native": "plan", "native-eager": "eager", "native-graph": "graph", "module": "eager", "module-graph": "graph"}[mode]
-    runner = InferenceEngine(net, backend=mode.split("-")[0], replay=replay)
+    # inputs='bind': the features stay where the (out-of-scope) backbone would write them, resident in HBM
+    runner = InferenceEngine(net, backend=mode.split("-")[0], replay=replay, inputs="bind")
 
     def step():
         with torch.no_grad():

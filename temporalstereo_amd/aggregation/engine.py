@@ -24,6 +24,16 @@ def _sig_of(obj):
     return ("V", obj)
 
 
+def _ptrs_of(obj):
+    if torch.is_tensor(obj):
+        return (obj.data_ptr(),)
+    if isinstance(obj, dict):
+        return tuple(p for k in sorted(obj, key=str) for p in _ptrs_of(obj[k]))
+    if isinstance(obj, (list, tuple)):
+        return tuple(p for o in obj for p in _ptrs_of(o))
+    return ()
+
+
 def _clone_static(obj):
     if torch.is_tensor(obj):
         return obj.detach().clone().contiguous()
@@ -68,7 +78,7 @@ class InferenceEngine:
     """`engine(left_feats, right_feats, left_image, right_image, prev_info)` -> same tuple as
     TEMPORALSTEREO.forward, executed as a hipGraph replay."""
 
-    def __init__(self, net, warmup=3, backend="native", graph=None, replay=None):
+    def __init__(self, net, warmup=3, backend="native", graph=None, replay=None, inputs="copy"):
         """backend 'native': every stage on libts_hip.so kernels (aggregation.native);
         backend 'module': the nn.Module forward (torch/MIOpen convolutions + HIP K1/K4).
         replay: 'plan'  -- record the pass once into a native launch plan and re-issue it with one host
@@ -76,7 +86,14 @@ class InferenceEngine:
                            for 'native'];
                 'graph' -- capture into a hipGraph [default for 'module'];
                 'eager' -- run the backend directly.
-        graph=True/False is the older spelling of replay='graph'/'eager'."""
+        graph=True/False is the older spelling of replay='graph'/'eager'.
+        inputs: 'copy' -- every call copies its arguments into the replay's own static buffers;
+                'bind' -- the replay is bound to the tensors of the first call: the producer (the
+                          backbone) writes each frame's features into those same tensors, so nothing is
+                          copied; a call with different storage records a new plan for it."""
+        if inputs not in ("copy", "bind"):
+            raise ValueError("inputs must be 'copy' or 'bind'")
+        self.bind = inputs == "bind"
         if replay is None:
             replay = ("graph" if graph else "eager") if graph is not None else ("plan" if backend == "native" else "graph")
         if replay not in ("plan", "graph", "eager") or (replay == "plan" and backend != "native"):
@@ -100,7 +117,7 @@ class InferenceEngine:
         self._graphs = {}
 
     def _capture(self, args):
-        static_in = _clone_static(args)
+        static_in = args if self.bind else _clone_static(args)
         # eager warm-up on a side stream: MIOpen solver selection, lazy inits, allocator growth
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -116,7 +133,7 @@ class InferenceEngine:
 
     def _record(self, args):
         from .. import _lib
-        static_in = _clone_static(args)
+        static_in = args if self.bind else _clone_static(args)
         with torch.no_grad():
             for _ in range(max(self.warmup - 1, 0)):       # allocator growth, lazy initialisation
                 self.net(static_in[0], static_in[1], static_in[2], static_in[3], dict(static_in[4]))
@@ -134,11 +151,12 @@ class InferenceEngine:
         if self.replay == "eager":
             with torch.no_grad():
                 return self.net(args[0], args[1], args[2], args[3], dict(prev_info))
-        sig = _sig_of(args)
+        sig = _sig_of(args) + ((_ptrs_of(args),) if self.bind else ())
         cap = self._graphs.get(sig)
         if cap is None:
             cap = self._graphs[sig] = self._record(args) if self.replay == "plan" else self._capture(args)
-        _copy_into(cap.static_in, args)
+        if not self.bind:
+            _copy_into(cap.static_in, args)
         cap.replay()
         disps, costs, samples, offs, ranges, info = cap.static_out
         out_info = dict(prev_info)

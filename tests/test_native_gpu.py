@@ -158,6 +158,16 @@ def test_plan_replay_tracks_new_inputs_and_refuses_unknown_calls():
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-4)
     cap = next(iter(plan._graphs.values()))
     assert len(cap.recorder) > 50
+    # inputs='bind': no copies -- the plan reads the caller's tensors in place, new storage = new plan
+    bound = InferenceEngine(net, backend="native", replay="plan", inputs="bind")
+    first = bound(lf, rf, il, ir, dict(prev))[0][0].clone()
+    for dst, src in zip(lf + rf, lf2 + rf2):
+        dst.copy_(src)                                                 # "the backbone" writes the next frame in place
+    il.copy_(il.flip(-1).contiguous()); ir.copy_(ir.flip(-1).contiguous())
+    got2 = bound(lf, rf, il, ir, dict(prev))[0][0]
+    assert len(bound._graphs) == 1
+    np.testing.assert_allclose(got2.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-4)
+    assert float((first - got2).abs().max()) > 1e-3
     L = _lib.lib()
     p = L.ts_plan_create()
     words = (_lib.ctypes.c_ulonglong * 1)(0)

@@ -225,8 +225,8 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = min(co0 + cb * 16 + kq * 4 + r, p.coutp - 1);     // clamped: unconditional loads, no branches
-      esc[cb][r] = scale[co];
-      esh[cb][r] = shift[co];
+      esc[cb][r] = scale ? scale[co] : 1.f;              // null: raw convolution (training / backward-data)
+      esh[cb][r] = shift ? shift[co] : 0.f;
     }
 
   // ---- register prefetch of one K chunk: branch-free buffer loads (zero padding, ragged channel
@@ -367,6 +367,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       if (MODE == MODE_HWT) {
         inside = oy < p.H && ox < p.W;
         oy = 2 * oy + pa; ox = 2 * ox + pbit;
+        inside = inside && oy < p.Ho && ox < p.Wo;        // output_padding 0: the last row / column does not exist
       } else inside = oy < p.Ho && ox < p.Wo;
       ppix = static_cast<unsigned>(oy) * p.Wo + ox;
       opix = static_cast<unsigned>(od) * static_cast<unsigned>(hw_o) + ppix;
@@ -402,7 +403,7 @@ conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ 
     float v = 0.f;
     for (int k = 0; k < ksplit; ++k) v += partial[k * n + i];
     if (addend) v += addend[b * add_bstride + co * hw_o + px % hw_o];
-    y[b * out_bstride + co * out_cstride + px] = apply_act(v * scale[co] + shift[co], act, act_param);
+    y[b * out_bstride + co * out_cstride + px] = apply_act(v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f), act, act_param);
   }
 }
 
@@ -478,10 +479,187 @@ bool ig_extent(IG& p, int KT) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the two convolution families on the matrix cores:
+//     dW[co][ci][tap] = sum_{b, d, px} dY[b][co][d][px] * X[b][ci][d'][px shifted by tap]
+// i.e. per tap a GEMM whose reduction runs over the pixels: A = dY (16 channels x 4 pixels),
+// B = X (4 pixels x 16 channels), D = a 16x16 block of dW.
+//   workgroup = (a run of pixel tiles) x (16 input channels) x (all <= 64 output channels, all taps);
+//   the (tap, 16-output-channel block) pairs are dealt round-robin to the four waves, each keeping its
+//   blocks of dW in registers across all of the workgroup's tiles and adding them to memory ONCE at the
+//   end (fp32 hardware atomics; summation order is not deterministic, as in the framework's own wgrad).
+//   Per tile: dY [pixels][channels] and X [haloed pixels][16 channels] are staged in LDS pixel-major
+//   (odd pitches: the transposing writes and both fragment reads are conflict-free or 2-way at worst).
+// ------------------------------------------------------------------------------------------------
+struct WG {
+  int B, Cin, Cout, D, H, W, Do, Ho, Wo;
+  int stride, dil, pad, k;
+  int tiles_x, tiles_per_plane, ntiles;       // ntiles = B * Do * tiles_per_plane
+  int cop;                                    // LDS pitch of a dY pixel row (== 17 mod 32)
+  long long x_bstride, x_cstride, dy_bstride, dy_cstride;
+  unsigned x_bytes, dy_bytes;
+};
+
+template <int MODE, int KT, int ST, int DL>
+__global__ void __launch_bounds__(256)
+wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, const WG p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CIP = 17;                                        // LDS pitch of an X pixel (16 channels + 1)
+  constexpr int TRW = (MODE == MODE_HW) ? (ST == 2 ? 4 : 8) : 8; // tile rows (MODE_HW) -- 32 columns; MODE_D: 256 pixels
+  constexpr int NPX = (MODE == MODE_HW) ? TRW * 32 : 256;        // output pixels per tile
+  constexpr int in_rows = (MODE == MODE_HW) ? (TRW - 1) * ST + 2 * DL + 1 : 1;
+  constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : 256;
+  constexpr int NIN = (MODE == MODE_HW) ? in_rows * in_cols : KT * 256;      // staged input pixels per channel
+  constexpr int RQ = (NIN + 255) / 256;
+  constexpr int MAXIT = (KT * 4 + 3) / 4;                        // (tap, channel block) pairs per wave, worst case
+  float* xs = lds;                                               // [NIN][CIP]
+  float* dys = lds + NIN * CIP;                                  // [NPX][cop]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int ci0 = blockIdx.y * 16;
+  const int cob = (p.Cout + 15) / 16, nitems = KT * cob;
+  const unsigned HW = static_cast<unsigned>(p.H) * p.W, HWo = static_cast<unsigned>(p.Ho) * p.Wo;
+
+  v4f acc[MAXIT];
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int sp = tile % p.tiles_per_plane;
+    const int od = (tile / p.tiles_per_plane) % p.Do, b = tile / (p.tiles_per_plane * p.Do);
+    const __amdgpu_buffer_rsrc_t xr = ig_rsrc(x + static_cast<size_t>(b) * p.x_bstride, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t yr = ig_rsrc(dy + static_cast<size_t>(b) * p.dy_bstride, p.dy_bytes);
+    int ty0 = 0, tx0 = 0;
+    if (MODE == MODE_HW) { ty0 = (sp / p.tiles_x) * TRW; tx0 = (sp % p.tiles_x) * 32; }
+    __syncthreads();                                             // the previous tile's fragments are consumed
+    // ---- stage X: 16 channels of the haloed input tile (zero padding / ragged channels via out-of-range offsets)
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int i = threadIdx.x + 256 * q;
+      unsigned off = kOOB;
+      if (i < NIN) {
+        if (MODE == MODE_HW) {
+          const int cy = i / in_cols, cx = i - cy * in_cols;
+          const int gy = ty0 * ST - DL + cy, gx = tx0 * ST - DL + cx;
+          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) off = (static_cast<unsigned>(od) * HW + static_cast<unsigned>(gy) * p.W + gx) * 4u;
+        } else {
+          const int t = i >> 8, px = sp * 256 + (i & 255);
+          const int id = od * p.stride + t * p.dil - p.pad;
+          if (id >= 0 && id < p.D && px < static_cast<int>(HW)) off = (static_cast<unsigned>(id) * HW + px) * 4u;
+        }
+      }
+      float v[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const unsigned so = static_cast<unsigned>(min(ci0 + c, p.Cin - 1)) * static_cast<unsigned>(p.x_cstride) * 4u;
+        v[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (ci0 + c < p.Cin) ? off : kOOB, so, 0));
+      }
+      if (i < NIN) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) xs[i * CIP + c] = v[c];
+      }
+    }
+    // ---- stage dY: every output channel of the tile's pixels
+    for (int i = threadIdx.x; i < NPX; i += 256) {
+      unsigned off = kOOB;
+      if (MODE == MODE_HW) {
+        const int oy = ty0 + i / 32, ox = tx0 + (i & 31);
+        if (oy < p.Ho && ox < p.Wo) off = (static_cast<unsigned>(od) * HWo + static_cast<unsigned>(oy) * p.Wo + ox) * 4u;
+      } else {
+        const int px = sp * 256 + i;
+        if (px < static_cast<int>(HWo)) off = (static_cast<unsigned>(od) * HWo + px) * 4u;
+      }
+      for (int c0 = 0; c0 < cob * 16; c0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const unsigned so = static_cast<unsigned>(min(c0 + c, p.Cout - 1)) * static_cast<unsigned>(p.dy_cstride) * 4u;
+          v[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, (c0 + c < p.Cout) ? off : kOOB, so, 0));
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dys[i * p.cop + c0 + c] = v[c];
+      }
+    }
+    __syncthreads();
+    // ---- this wave's (tap, channel block) pairs over the tile's pixels, four pixels per MFMA
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int item = wave + 4 * it;
+      if (item >= nitems) break;
+      const int tap = item / cob, cb = item - tap * cob;
+      int toff;
+      if (MODE == MODE_HW) toff = ((tap / 3) * DL * in_cols + (tap % 3) * DL);
+      else toff = tap * 256;
+      const float* ap = dys + kq * p.cop + cb * 16 + j;
+      const float* bp = xs + (toff + (MODE == MODE_HW ? kq * ST : kq)) * CIP + j;
+      v4f a = acc[it];
+      for (int step = 0; step < NPX / 4; ++step) {
+        int xo;
+        if (MODE == MODE_HW) xo = ((step >> 3) * ST * in_cols + (step & 7) * 4 * ST) * CIP;
+        else xo = step * 4 * CIP;
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[step * 4 * p.cop], bp[xo], a, 0, 0, 0);
+      }
+      acc[it] = a;
+    }
+  }
+  // ---- one atomic add per element of this workgroup's dW blocks: lane holds co = 4 kq + r, ci = j
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int item = wave + 4 * it;
+    if (item >= nitems) break;
+    const int tap = item / cob, cb = item - tap * cob;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cb * 16 + kq * 4 + r, ci = ci0 + j;
+      if (co < p.Cout && ci < p.Cin) atomicAdd(dw + (static_cast<size_t>(co) * p.Cin + ci) * KT + tap, acc[it][r]);
+    }
+  }
+}
+
+template <int MODE, int KT, int ST, int DL>
+int launch_wgrad(const float* x, const float* dy, float* dw, WG p, hipStream_t st) {
+  constexpr int TRW = (MODE == MODE_HW) ? (ST == 2 ? 4 : 8) : 8;
+  constexpr int NPX = (MODE == MODE_HW) ? TRW * 32 : 256;
+  constexpr int NIN = (MODE == MODE_HW) ? ((TRW - 1) * ST + 2 * DL + 1) * (31 * ST + 2 * DL + 1) : KT * 256;
+  const int c16 = (p.Cout + 15) / 16 * 16;
+  p.cop = c16 + 1;
+  while (p.cop % 32 != 17) ++p.cop;
+  const size_t lds = (static_cast<size_t>(NIN) * 17 + static_cast<size_t>(NPX) * p.cop) * sizeof(float);
+  TS_REQUIRE(lds <= 160 * 1024, TS_ERR_UNSUPPORTED, "conv bwd_weight: tile does not fit the LDS");
+  if (MODE == MODE_HW) {
+    p.tiles_x = (p.Wo + 31) / 32;
+    p.tiles_per_plane = ((p.Ho + TRW - 1) / TRW) * p.tiles_x;
+  } else {
+    p.tiles_x = 1;
+    p.tiles_per_plane = (p.Ho * p.Wo + 255) / 256;
+  }
+  p.ntiles = p.B * p.Do * p.tiles_per_plane;
+  const int ciblocks = (p.Cin + 15) / 16;
+  // enough workgroups to fill the chip a few times, few enough that the final atomics stay cheap
+  int gx = (4 * ts::kNumCU + ciblocks - 1) / ciblocks;
+  if (gx > p.ntiles) gx = p.ntiles;
+  if (gx < 1) gx = 1;
+  auto kern = &wgrad_kernel<MODE, KT, ST, DL>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  hipError_t e = hipMemsetAsync(dw, 0, static_cast<size_t>(p.Cout) * p.Cin * KT * sizeof(float), st);
+  if (e != hipSuccess) return ts::fail(static_cast<int>(e), "conv bwd_weight: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(kern, dim3(gx, ciblocks), dim3(256), lds, st, x, dy, dw, p);
+  return ts::launched("wgrad_kernel");
+}
+
+bool wg_extent(WG& p) {
+  const unsigned long long xb = (static_cast<unsigned long long>(p.Cin - 1) * p.x_cstride + static_cast<unsigned long long>(p.D) * p.H * p.W) * 4ull;
+  const unsigned long long yb = (static_cast<unsigned long long>(p.Cout - 1) * p.dy_cstride + static_cast<unsigned long long>(p.Do) * p.Ho * p.Wo) * 4ull;
+  if (xb >= 0x7fffffffull || yb >= 0x7fffffffull || p.x_cstride < 0 || p.dy_cstride < 0) return false;
+  p.x_bytes = static_cast<unsigned>(xb); p.dy_bytes = static_cast<unsigned>(yb);
+  return true;
+}
+
 int cout_bucket(int cout) {
   for (int b : {8, 16, 32, 64})
     if (cout <= b) return b;
-  return -1;
+  return cout > 0 ? (cout + 15) / 16 * 16 : -1;       // wide outputs (backward-data of the first layers): 16-channel blocks
 }
 
 // Split-K factor of a (1,3,3) convolution: long reductions on grids too small to fill the chip are cut
@@ -500,12 +678,14 @@ int conv_hw_ksplit(int B, int Cin, int Cout, int D, int Ho, int Wo) {
 // (zero padded), scale/shift [CoutPad].  Channel/batch strides are in elements so that x / y may be
 // channel slices of larger tensors (concatenation without a copy).  transposed != 0: stride-2
 // ConvTranspose3d(1,3,3) with padding 1, output_padding 1 (Ho = 2H, Wo = 2W).
-extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
-                                int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
-                                int transposed, int act, float act_param,
-                                long long in_bstride, long long in_cstride, long long out_bstride,
-                                long long out_cstride, const float* addend, long long addend_bstride,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// out_h / out_w: real output size of the transposed form (2H-1 or 2H; 0 = 2H, i.e. output_padding 1)
+int conv_hw_impl(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                 int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
+                 int transposed, int act, float act_param,
+                 long long in_bstride, long long in_cstride, long long out_bstride,
+                 long long out_cstride, const float* addend, long long addend_bstride,
+                 void* workspace, size_t workspace_bytes, int out_h, int out_w, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw: non-positive size");
   TS_REQUIRE(stride == 1 || stride == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: stride must be 1 or 2");
   TS_REQUIRE(dilation == 1 || dilation == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: dilation must be 1 or 2");
@@ -513,9 +693,8 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   TS_REQUIRE(!transposed || (stride == 2 && dilation == 1), TS_ERR_UNSUPPORTED, "conv3d_hw: transposed form is stride 2, dilation 1");
   TS_REQUIRE(act >= 0 && act <= 3, TS_ERR_SHAPE, "conv3d_hw: unknown activation");
   TS_REQUIRE(D <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw: grid too large");
-  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(scale); TS_REQUIRE_PTR(shift); TS_REQUIRE_PTR(y);
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(y);
   const int bucket = cout_bucket(Cout);
-  TS_REQUIRE(bucket > 0, TS_ERR_UNSUPPORTED, "conv3d_hw: Cout=%d > 64", Cout);
   hipStream_t st = ts::as_stream(stream);
   IG p;
   p.Cin = Cin; p.Cout = Cout; p.coutp = bucket; p.D = D; p.H = H; p.W = W; p.Do = D;
@@ -527,7 +706,9 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   TS_REQUIRE(!(addend && transposed), TS_ERR_UNSUPPORTED, "conv3d_hw: no addend in the transposed form");
   TS_REQUIRE(ig_extent(p, 9), TS_ERR_UNSUPPORTED, "conv3d_hw: a batch element of x spans 2 GiB or more");
   if (transposed) {
-    p.Ho = 2 * H; p.Wo = 2 * W;
+    p.Ho = out_h ? out_h : 2 * H; p.Wo = out_w ? out_w : 2 * W;
+    TS_REQUIRE(p.Ho >= 2 * H - 1 && p.Ho <= 2 * H && p.Wo >= 2 * W - 1 && p.Wo <= 2 * W, TS_ERR_SHAPE,
+               "conv3d_hw: transposed output %dx%d is not 2H-1 | 2H", p.Ho, p.Wo);
     p.tiles_x = (W + 31) / 32;
     const int tiles = ((H + 7) / 8) * p.tiles_x;
     return launch_ig<MODE_HWT, 9, 1, 1>(x, w_t, scale, shift, y, p, B, tiles * 4, D, st);
@@ -556,25 +737,86 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
                      static_cast<long long>(p.Ho) * p.Wo);
   return ts::launched("conv_splitk_finish");
 }
+}  // namespace
+
+extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                                int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
+                                int transposed, int act, float act_param,
+                                long long in_bstride, long long in_cstride, long long out_bstride,
+                                long long out_cstride, const float* addend, long long addend_bstride,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  return conv_hw_impl(x, w_t, scale, shift, y, B, Cin, Cout, D, H, W, stride, dilation, transposed, act, act_param,
+                      in_bstride, in_cstride, out_bstride, out_cstride, addend, addend_bstride, workspace, workspace_bytes,
+                      0, 0, stream);
+}
+
+// Gradient w.r.t. the input of ts_conv3d_hw_fwd (no scale / shift / activation: the raw convolution).
+// (B, Cin, Cout, D, H, W, stride, dilation, transposed) describe the FORWARD call; dy has the forward
+// output's shape, dx [B,Cin,D,H,W].  w_b is the weight re-laid for the backward pass by the host,
+// [Cout][9][ts_conv_cout_pad(Cin)]:
+//   forward stride 1        : w_b[co][t][ci] = W[co][ci][8 - t]   (correlation with the flipped taps)
+//   forward stride 2        : w_b[co][t][ci] = W[co][ci][t]       (runs as the stride-2 transposed form)
+//   forward transposed (s2) : w_b[co][t][ci] = W_T[ci][co][t]     (runs as a stride-2 convolution of dy)
+extern "C" int ts_conv3d_hw_bwd_data(const float* dy, const float* w_b, float* dx, int B, int Cin, int Cout, int D, int H,
+                                     int W, int stride, int dilation, int transposed, long long dy_bstride,
+                                     long long dy_cstride, long long dx_bstride, long long dx_cstride, void* stream) {
+  TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw_bwd_data: non-positive size");
+  TS_REQUIRE(stride == 1 || stride == 2, TS_ERR_UNSUPPORTED, "conv3d_hw_bwd_data: stride must be 1 or 2");
+  if (transposed)            // y = convT(x): [2H, 2W]  ->  dx = stride-2 convolution of dy
+    return conv_hw_impl(dy, w_b, nullptr, nullptr, dx, B, Cout, Cin, D, 2 * H, 2 * W, 2, 1, 0, ACT_NONE, 0.f, dy_bstride,
+                        dy_cstride, dx_bstride, dx_cstride, nullptr, 0, nullptr, 0, 0, 0, stream);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (stride == 2)           // dx = transposed convolution of dy, cropped to the forward input
+    return conv_hw_impl(dy, w_b, nullptr, nullptr, dx, B, Cout, Cin, D, Ho, Wo, 2, 1, 1, ACT_NONE, 0.f, dy_bstride,
+                        dy_cstride, dx_bstride, dx_cstride, nullptr, 0, nullptr, 0, H, W, stream);
+  return conv_hw_impl(dy, w_b, nullptr, nullptr, dx, B, Cout, Cin, D, Ho, Wo, 1, dilation, 0, ACT_NONE, 0.f, dy_bstride,
+                      dy_cstride, dx_bstride, dx_cstride, nullptr, 0, nullptr, 0, 0, 0, stream);
+}
+
+// Gradient w.r.t. the weight of the NON-transposed ts_conv3d_hw_fwd: x [B,Cin,D,H,W], dy [B,Cout,D,Ho,Wo]
+// -> dw [Cout][Cin][9] (torch layout, OVERWRITTEN).  Cout <= 64.  The transposed form's weight gradient is
+// the same call with the roles of x and dy exchanged (x := dy of the 2H x 2W output, dy := x, stride 2),
+// which yields [Cin][Cout][9] -- ConvTranspose3d's own layout.
+extern "C" int ts_conv3d_hw_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H,
+                                       int W, int stride, int dilation, long long x_bstride, long long x_cstride,
+                                       long long dy_bstride, long long dy_cstride, void* stream) {
+  TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw_bwd_weight: non-positive size");
+  TS_REQUIRE(Cout <= 64, TS_ERR_UNSUPPORTED, "conv3d_hw_bwd_weight: Cout=%d > 64", Cout);
+  TS_REQUIRE((stride == 1 && (dilation == 1 || dilation == 2)) || (stride == 2 && dilation == 1), TS_ERR_UNSUPPORTED,
+             "conv3d_hw_bwd_weight: stride/dilation outside {1/1, 1/2, 2/1}");
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(dy); TS_REQUIRE_PTR(dw);
+  WG p;
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.D = D; p.H = H; p.W = W; p.Do = D;
+  p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
+  p.stride = stride; p.dil = dilation; p.pad = dilation; p.k = 3;
+  p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.dy_bstride = dy_bstride; p.dy_cstride = dy_cstride;
+  TS_REQUIRE(wg_extent(p), TS_ERR_UNSUPPORTED, "conv3d_hw_bwd_weight: a batch element spans 2 GiB or more");
+  hipStream_t st = ts::as_stream(stream);
+  if (stride == 2) return launch_wgrad<MODE_HW, 9, 2, 1>(x, dy, dw, p, st);
+  if (dilation == 2) return launch_wgrad<MODE_HW, 9, 1, 2>(x, dy, dw, p, st);
+  return launch_wgrad<MODE_HW, 9, 1, 1>(x, dy, dw, p, st);
+}
 
 // x [B,Cin,Din,H,W] -> y [B,Cout,Dout,H,W]; w_t is [Cin][k][CoutPad].  k in {1,3,5}.  transposed != 0:
 // ConvTranspose3d(3,1,1) stride 2, padding 1, output_padding 1 (Dout = 2 Din).
-extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
-                               int B, int Cin, int Cout, int Din, int H, int W, int k, int stride, int dilation,
-                               int padding, int transposed, int act, float act_param,
-                               long long in_bstride, long long in_cstride, long long out_bstride,
-                               long long out_cstride, void* stream) {
+namespace {
+// out_d: real output depth of the transposed form (2Din-1 or 2Din; 0 = 2Din)
+int conv_d_impl(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                int B, int Cin, int Cout, int Din, int H, int W, int k, int stride, int dilation,
+                int padding, int transposed, int act, float act_param,
+                long long in_bstride, long long in_cstride, long long out_bstride,
+                long long out_cstride, int out_d, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Din > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_d: non-positive size");
   TS_REQUIRE(k == 1 || k == 3 || k == 5, TS_ERR_UNSUPPORTED, "conv3d_d: k must be 1, 3 or 5");
   TS_REQUIRE(stride >= 1 && stride <= 2 && dilation >= 1 && padding >= 0, TS_ERR_UNSUPPORTED, "conv3d_d: bad stride/dilation/padding");
   TS_REQUIRE(!transposed || (k == 3 && stride == 2 && dilation == 1 && padding == 1), TS_ERR_UNSUPPORTED,
              "conv3d_d: transposed form is k=3, stride 2, padding 1");
   TS_REQUIRE(act >= 0 && act <= 3, TS_ERR_SHAPE, "conv3d_d: unknown activation");
-  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(scale); TS_REQUIRE_PTR(shift); TS_REQUIRE_PTR(y);
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(y);
   const int bucket = cout_bucket(Cout);
-  TS_REQUIRE(bucket > 0, TS_ERR_UNSUPPORTED, "conv3d_d: Cout=%d > 64", Cout);
-  const int Dout = transposed ? 2 * Din : (Din + 2 * padding - dilation * (k - 1) - 1) / stride + 1;
+  const int Dout = transposed ? (out_d ? out_d : 2 * Din) : (Din + 2 * padding - dilation * (k - 1) - 1) / stride + 1;
   TS_REQUIRE(Dout > 0 && Dout <= 65535, TS_ERR_SHAPE, "conv3d_d: bad output depth");
+  TS_REQUIRE(!transposed || (Dout >= 2 * Din - 1 && Dout <= 2 * Din), TS_ERR_SHAPE, "conv3d_d: transposed depth %d is not 2D-1 | 2D", Dout);
   hipStream_t st = ts::as_stream(stream);
   IG p;
   p.Cin = Cin; p.Cout = Cout; p.coutp = bucket; p.D = Din; p.H = H; p.W = W; p.Do = Dout; p.Ho = H; p.Wo = W;
@@ -588,6 +830,64 @@ extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* sc
   if (k == 1) return launch_ig<MODE_D, 1, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
   if (k == 3) return launch_ig<MODE_D, 3, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
   return launch_ig<MODE_D, 5, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
+}
+}  // namespace
+
+extern "C" int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
+                               int B, int Cin, int Cout, int Din, int H, int W, int k, int stride, int dilation,
+                               int padding, int transposed, int act, float act_param,
+                               long long in_bstride, long long in_cstride, long long out_bstride,
+                               long long out_cstride, void* stream) {
+  return conv_d_impl(x, w_t, scale, shift, y, B, Cin, Cout, Din, H, W, k, stride, dilation, padding, transposed, act,
+                     act_param, in_bstride, in_cstride, out_bstride, out_cstride, 0, stream);
+}
+
+// Gradient w.r.t. the input of ts_conv3d_d_fwd (raw convolution).  The geometry arguments describe the
+// FORWARD call; dy has the forward output's shape, dx [B,Cin,Din,H,W].  w_b [Cout][k][ts_conv_cout_pad(Cin)]:
+//   forward stride 1        : w_b[co][t][ci] = W[co][ci][k-1-t]
+//   forward stride 2 (k = 3, padding 1) : w_b[co][t][ci] = W[co][ci][t]      (transposed form, cropped to Din)
+//   forward transposed      : w_b[co][t][ci] = W_T[ci][co][t]               (stride-2 convolution of dy)
+extern "C" int ts_conv3d_d_bwd_data(const float* dy, const float* w_b, float* dx, int B, int Cin, int Cout, int Din, int H,
+                                    int W, int k, int stride, int dilation, int padding, int transposed,
+                                    long long dy_bstride, long long dy_cstride, long long dx_bstride, long long dx_cstride,
+                                    void* stream) {
+  TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Din > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_d_bwd_data: non-positive size");
+  if (transposed)
+    return conv_d_impl(dy, w_b, nullptr, nullptr, dx, B, Cout, Cin, 2 * Din, H, W, 3, 2, 1, 1, 0, ACT_NONE, 0.f, dy_bstride,
+                       dy_cstride, dx_bstride, dx_cstride, 0, stream);
+  const int Dout = (Din + 2 * padding - dilation * (k - 1) - 1) / stride + 1;
+  TS_REQUIRE(Dout > 0, TS_ERR_SHAPE, "conv3d_d_bwd_data: bad forward geometry");
+  if (stride == 2) {
+    TS_REQUIRE(k == 3 && dilation == 1 && padding == 1, TS_ERR_UNSUPPORTED, "conv3d_d_bwd_data: stride 2 needs k=3, padding 1");
+    return conv_d_impl(dy, w_b, nullptr, nullptr, dx, B, Cout, Cin, Dout, H, W, 3, 2, 1, 1, 1, ACT_NONE, 0.f, dy_bstride,
+                       dy_cstride, dx_bstride, dx_cstride, Din, stream);
+  }
+  TS_REQUIRE(stride == 1, TS_ERR_UNSUPPORTED, "conv3d_d_bwd_data: stride must be 1 or 2");
+  return conv_d_impl(dy, w_b, nullptr, nullptr, dx, B, Cout, Cin, Dout, H, W, k, 1, dilation, dilation * (k - 1) - padding, 0,
+                     ACT_NONE, 0.f, dy_bstride, dy_cstride, dx_bstride, dx_cstride, 0, stream);
+}
+
+// Gradient w.r.t. the weight of the NON-transposed ts_conv3d_d_fwd -> dw [Cout][Cin][k] (OVERWRITTEN), Cout <= 64;
+// transposed form: exchange x and dy as for ts_conv3d_hw_bwd_weight.
+extern "C" int ts_conv3d_d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int Din, int H,
+                                      int W, int k, int stride, int dilation, int padding, long long x_bstride,
+                                      long long x_cstride, long long dy_bstride, long long dy_cstride, void* stream) {
+  TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Din > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_d_bwd_weight: non-positive size");
+  TS_REQUIRE(Cout <= 64, TS_ERR_UNSUPPORTED, "conv3d_d_bwd_weight: Cout=%d > 64", Cout);
+  TS_REQUIRE(k == 1 || k == 3 || k == 5, TS_ERR_UNSUPPORTED, "conv3d_d_bwd_weight: k must be 1, 3 or 5");
+  TS_REQUIRE(stride >= 1 && stride <= 2 && dilation >= 1 && padding >= 0, TS_ERR_UNSUPPORTED, "conv3d_d_bwd_weight: bad stride/dilation/padding");
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(dy); TS_REQUIRE_PTR(dw);
+  WG p;
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.D = Din; p.H = H; p.W = W; p.Ho = H; p.Wo = W;
+  p.Do = (Din + 2 * padding - dilation * (k - 1) - 1) / stride + 1;
+  TS_REQUIRE(p.Do > 0, TS_ERR_SHAPE, "conv3d_d_bwd_weight: bad output depth");
+  p.stride = stride; p.dil = dilation; p.pad = padding; p.k = k;
+  p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.dy_bstride = dy_bstride; p.dy_cstride = dy_cstride;
+  TS_REQUIRE(wg_extent(p), TS_ERR_UNSUPPORTED, "conv3d_d_bwd_weight: a batch element spans 2 GiB or more");
+  hipStream_t st = ts::as_stream(stream);
+  if (k == 1) return launch_wgrad<MODE_D, 1, 1, 1>(x, dy, dw, p, st);
+  if (k == 3) return launch_wgrad<MODE_D, 3, 1, 1>(x, dy, dw, p, st);
+  return launch_wgrad<MODE_D, 5, 1, 1>(x, dy, dw, p, st);
 }
 
 // ConvTranspose2d(kernel 4, stride 2, padding 1) of UNet (module.py:453-457): x [B,Cin,H,W] -> y [B,Cout,2H,2W]

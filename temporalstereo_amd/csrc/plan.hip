@@ -60,6 +60,8 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_softsplat_sum_bwd_input), TS_PLAN_OP(ts_softsplat_sum_bwd_flow),
     TS_PLAN_OP(ts_softsplat_softmax_fwd),   TS_PLAN_OP(ts_project_to_3d_fwd),
     TS_PLAN_OP(ts_conv3d_hw_fwd),           TS_PLAN_OP(ts_conv3d_d_fwd),
+    TS_PLAN_OP(ts_conv3d_hw_bwd_data),      TS_PLAN_OP(ts_conv3d_hw_bwd_weight),
+    TS_PLAN_OP(ts_conv3d_d_bwd_data),       TS_PLAN_OP(ts_conv3d_d_bwd_weight),
     TS_PLAN_OP(ts_resize3d_add_act_fwd),    TS_PLAN_OP(ts_pool3d5_avgmax_fwd),
     TS_PLAN_OP(ts_merge_candidates_fwd),    TS_PLAN_OP(ts_convex_upsample_fwd),
     TS_PLAN_OP(ts_unet_upsample_fwd),       TS_PLAN_OP(ts_deconv2d_k4s2_fwd),

@@ -92,6 +92,193 @@ class _BlockCost(torch.autograd.Function):
         return gl, gr, gd, None, None
 
 
+# --------------------------------------------------------------------------------------- K3 convolutions
+def _pad_last(t, n):
+    if t.shape[-1] == n:
+        return t.contiguous()
+    out = t.new_zeros(t.shape[:-1] + (n,))
+    out[..., :t.shape[-1]] = t
+    return out
+
+
+def _cpad(n):
+    return int(_lib.lib().ts_conv_cout_pad(n))
+
+
+class _Conv3dHW(torch.autograd.Function):
+    """Raw Conv3d (1,3,3) [padding == dilation] / ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1.
+    forward ts_conv3d_hw_fwd (no scale / shift / activation), backward ts_conv3d_hw_bwd_{data,weight}.
+    Replaces F.conv3d / F.conv_transpose3d inside layers.Conv3d / ConvTranspose3d
+    (reference: layers/basic_layers.py:194-235,340-388 reach cuDNN through the same two functionals)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, dilation, transposed):
+        _require_gpu(x, weight)
+        x = x.contiguous()
+        B, Cin, D, H, W = x.shape
+        w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
+        if transposed:                                   # weight [Cin, Cout, 1, 3, 3]
+            Cout = weight.shape[1]
+            w_t = _pad_last(w9.permute(0, 2, 1), _cpad(Cout))                       # [ci][t][co]
+            Ho, Wo = 2 * H, 2 * W
+        else:                                            # weight [Cout, Cin, 1, 3, 3]
+            Cout = weight.shape[0]
+            w_t = _pad_last(w9.permute(1, 2, 0), _cpad(Cout))
+            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty((B, Cout, D, Ho, Wo), device=x.device, dtype=torch.float32)
+        L = _lib.lib()
+        wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, Cout, D, H, W, stride, int(transposed)))
+        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
+        rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(w_t), None, None, _lib.ptr(y), B, Cin, Cout, D, H, W, stride, dilation,
+                                int(transposed), 0, 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
+                                None, 0, _lib.ptr(ws), wsb, _stream())
+        _lib.check(rc, "ts_conv3d_hw_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (B, Cin, Cout, D, H, W, stride, dilation, transposed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Cin, Cout, D, H, W, stride, dilation, transposed = ctx.geom
+        dy = dy.contiguous()
+        L = _lib.lib()
+        dx = dw = None
+        w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
+        if ctx.needs_input_grad[0]:
+            if transposed:
+                w_b = _pad_last(w9.permute(1, 2, 0), _cpad(Cin))                    # [co][t][ci] = W_T[ci][co][t]
+            elif stride == 2:
+                w_b = _pad_last(w9.permute(0, 2, 1), _cpad(Cin))                    # [co][t][ci], taps as they are
+            else:
+                w_b = _pad_last(w9.flip(2).permute(0, 2, 1), _cpad(Cin))            # taps flipped
+            dx = torch.empty_like(x)
+            rc = L.ts_conv3d_hw_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, D, H, W, stride, dilation,
+                                         int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
+            _lib.check(rc, "ts_conv3d_hw_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            if transposed:     # roles exchanged: a stride-2 convolution maps dy (2H x 2W) to x
+                rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, D, 2 * H, 2 * W, 2, 1,
+                                               dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _stream())
+            else:
+                rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, D, H, W, stride, dilation,
+                                               x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _stream())
+            _lib.check(rc, "ts_conv3d_hw_bwd_weight")
+        return dx, dw, None, None, None
+
+
+class _Conv3dD(torch.autograd.Function):
+    """Raw Conv3d (k,1,1) / ConvTranspose3d (3,1,1) stride 2, padding 1, output_padding 1 along D."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, dilation, padding, transposed):
+        _require_gpu(x, weight)
+        x = x.contiguous()
+        B, Cin, Din, H, W = x.shape
+        k = weight.shape[2]
+        wk = weight.reshape(weight.shape[0], weight.shape[1], k)
+        if transposed:
+            Cout = weight.shape[1]
+            w_t = _pad_last(wk.permute(0, 2, 1), _cpad(Cout))
+            Dout = 2 * Din
+        else:
+            Cout = weight.shape[0]
+            w_t = _pad_last(wk.permute(1, 2, 0), _cpad(Cout))
+            Dout = (Din + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+        y = torch.empty((B, Cout, Dout, H, W), device=x.device, dtype=torch.float32)
+        rc = _lib.lib().ts_conv3d_d_fwd(_lib.ptr(x), _lib.ptr(w_t), None, None, _lib.ptr(y), B, Cin, Cout, Din, H, W, k, stride,
+                                        dilation, padding, int(transposed), 0, 0.0, x.stride(0), x.stride(1), y.stride(0),
+                                        y.stride(1), _stream())
+        _lib.check(rc, "ts_conv3d_d_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (B, Cin, Cout, Din, H, W, k, stride, dilation, padding, transposed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Cin, Cout, Din, H, W, k, stride, dilation, padding, transposed = ctx.geom
+        dy = dy.contiguous()
+        L = _lib.lib()
+        dx = dw = None
+        wk = weight.reshape(weight.shape[0], weight.shape[1], k)
+        if ctx.needs_input_grad[0]:
+            if transposed:
+                w_b = _pad_last(wk.permute(1, 2, 0), _cpad(Cin))
+            elif stride == 2:
+                w_b = _pad_last(wk.permute(0, 2, 1), _cpad(Cin))
+            else:
+                w_b = _pad_last(wk.flip(2).permute(0, 2, 1), _cpad(Cin))
+            dx = torch.empty_like(x)
+            rc = L.ts_conv3d_d_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, Din, H, W, k, stride, dilation,
+                                        padding, int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
+            _lib.check(rc, "ts_conv3d_d_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            if transposed:
+                rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, 2 * Din, H, W, 3, 2, 1, 1,
+                                              dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _stream())
+            else:
+                rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, Din, H, W, k, stride, dilation,
+                                              padding, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _stream())
+            _lib.check(rc, "ts_conv3d_d_bwd_weight")
+        return dx, dw, None, None, None, None
+
+
+def conv3d_supported(weight_shape, stride, padding, dilation, groups, transposed=False, output_padding=(0, 0, 0)):
+    """'hw' | 'd' | None: which HIP family runs a Conv3d / ConvTranspose3d with these hyper-parameters."""
+    if groups != 1 or len(weight_shape) != 5:
+        return None
+    kd, kh, kw = weight_shape[2:]
+    cout = weight_shape[1] if transposed else weight_shape[0]
+    cin = weight_shape[0] if transposed else weight_shape[1]
+    if max(cout, cin if transposed else 0) > 64:
+        return None                                     # the weight-gradient kernel holds <= 64 output channels
+    if (kd, kh, kw) == (1, 3, 3) and stride[0] == 1 and stride[1] == stride[2] and dilation[1] == dilation[2] and \
+            padding[0] == 0 and dilation[0] == 1:
+        s, d = stride[1], dilation[1]
+        if transposed:
+            ok = s == 2 and d == 1 and tuple(padding[1:]) == (1, 1) and tuple(output_padding) == (0, 1, 1)
+        else:
+            ok = tuple(padding[1:]) == (d, d) and (s, d) in ((1, 1), (1, 2), (2, 1))
+        return "hw" if ok else None
+    if kh == 1 and kw == 1 and kd in (1, 3, 5) and tuple(stride[1:]) == (1, 1) and tuple(padding[1:]) == (0, 0):
+        s, d, pd = stride[0], dilation[0], padding[0]
+        if transposed:
+            ok = kd == 3 and s == 2 and d == 1 and pd == 1 and tuple(output_padding) == (1, 0, 0)
+        else:
+            ok = s == 1 or (s == 2 and kd == 3 and d == 1 and pd == 1)
+        return "d" if ok else None
+    return None
+
+
+def conv3d(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1)):
+    """F.conv3d on the HIP kernels for the (1,3,3) / (k,1,1) families (fp32, GPU)."""
+    kind = conv3d_supported(tuple(weight.shape), stride, padding, dilation, 1)
+    if kind == "hw":
+        y = _Conv3dHW.apply(x, weight, stride[1], dilation[1], False)
+    elif kind == "d":
+        y = _Conv3dD.apply(x, weight, stride[0], dilation[0], padding[0], False)
+    else:
+        raise NotImplementedError("conv3d: kernel %s stride %s padding %s dilation %s has no HIP kernel"
+                                  % (tuple(weight.shape[2:]), stride, padding, dilation))
+    return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+
+
+def conv_transpose3d(x, weight, bias=None, stride=(1, 2, 2), padding=(0, 1, 1), output_padding=(0, 1, 1)):
+    """F.conv_transpose3d on the HIP kernels: (1,3,3) stride (1,2,2) or (3,1,1) stride (2,1,1), padding 1, output_padding 1."""
+    kind = conv3d_supported(tuple(weight.shape), stride, padding, (1, 1, 1), 1, True, output_padding)
+    if kind == "hw":
+        y = _Conv3dHW.apply(x, weight, 2, 1, True)
+    elif kind == "d":
+        y = _Conv3dD.apply(x, weight, 2, 1, 1, True)
+    else:
+        raise NotImplementedError("conv_transpose3d: kernel %s stride %s padding %s output_padding %s has no HIP kernel"
+                                  % (tuple(weight.shape[2:]), stride, padding, output_padding))
+    return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+
+
 def block_cost_warped(reference_fm, target_fm, disp_sample, block_cost_scale=3):
     """Inference form of the sampled block_cost WITHOUT its first C channels (the D-fold repeat of
     reference_fm, block_cost.py:51): [B, C + scales*C/8, D, H, W].  No autograd.  Used with the

@@ -3,13 +3,30 @@ names (architecture/modeling/layers/basic_layers.py:10-103,151-235,289-388): `Co
 norm=(name, channels) | module | None, activation=str | (str, coeff) | module | None)`; parameters
 live at `<name>.weight/.bias` and `<name>.norm.*`.
 
-Training keeps torch's convolution + BatchNorm (batch statistics / SyncBN collectives cannot be
-folded).  The eval-mode HIP execution of these layers happens one level up, in
-aggregation.engine, which folds the BatchNorm and fuses the activation into the conv kernels.
+On the GPU the 3-D convolutions of the two separable families ((1,3,3) and (k,1,1), their stride-2 and
+transposed forms) run on the HIP kernels as autograd Functions (functional.conv3d / conv_transpose3d:
+forward, backward-data and backward-weight all on the matrix cores); BatchNorm and the activation stay
+framework ops here because train mode needs batch statistics / SyncBN collectives.
+The eval-mode execution with folded BatchNorm and fused activations happens one level up, in
+aggregation.native.  CPU tensors (host-logic tests) take torch's own convolution.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+_CONV_BACKEND = {"name": "hip"}
+
+
+def set_conv_backend(name):
+    """'hip' (default): GPU tensors use the HIP convolution Functions; 'torch': F.conv3d (MIOpen) everywhere --
+    kept so that benchmarks can time the framework's own kernels next to ours."""
+    if name not in ("hip", "torch"):
+        raise ValueError("conv backend must be 'hip' or 'torch'")
+    _CONV_BACKEND["name"] = name
+
+
+def _hip_conv(x):
+    return _CONV_BACKEND["name"] == "hip" and x.is_cuda and x.dtype == torch.float32
 
 _NORMS = {
     "BN1d": nn.BatchNorm1d, "BN": nn.BatchNorm2d, "BN3d": nn.BatchNorm3d,
@@ -93,6 +110,10 @@ class Conv3d(nn.Conv3d, _NormAct):
         self.norm, self.activation = norm, act
 
     def forward(self, x):
+        if _hip_conv(x):
+            from . import functional as TF
+            if TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups):
+                return self._finish(TF.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation))
         return self._finish(F.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups))
 
 
@@ -120,5 +141,9 @@ class ConvTranspose3d(nn.ConvTranspose3d, _NormAct):
         if self.padding_mode != 'zeros':
             raise ValueError('Only `zeros` padding mode is supported for ConvTranspose3d')
         op = self._output_padding(x, output_size, self.stride, self.padding, self.kernel_size, 3, self.dilation)
+        if _hip_conv(x):
+            from . import functional as TF
+            if TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups, True, tuple(op)):
+                return self._finish(TF.conv_transpose3d(x, self.weight, self.bias, self.stride, self.padding, tuple(op)))
         return self._finish(F.conv_transpose3d(x, self.weight, self.bias, self.stride, self.padding, op,
                                                self.groups, self.dilation))

@@ -142,7 +142,11 @@ class K1Probe:
     def measure(self, iters):
         self.timing = True
         with torch.no_grad():
+            calls = dict(self.calls)
             for key, (fn, l, r, d, sc) in self.calls.items():
+                if key[5] == "warped":     # also time the complete op on the same tensors: SURVEY.md section 8(d)'s
+                    calls.setdefault(key[:5] + (True,), (self._orig["block_cost"], l, r, d, sc))   # unfused-boundary figure
+            for key, (fn, l, r, d, sc) in calls.items():
                 for _ in range(3):
                     fn(l, r, d, sc)
                 self.records = [rec for rec in self.records if rec[0] != key]
@@ -193,10 +197,13 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (config 2: 1)")
-    ap.add_argument("--mode", default="native", choices=["native", "native-eager", "native-graph", "module", "module-graph"],
+    ap.add_argument("--mode", default="native",
+                    choices=["native", "native-eager", "native-graph", "module", "module-graph", "module-hip"],
                     help="native: all-HIP inference path (aggregation.native) replayed from a recorded native "
                          "launch plan; native-eager: the same, issued op by op from Python; module: nn.Module "
-                         "forward (torch/MIOpen convolutions); -graph: replayed as one hipGraph")
+                         "forward with the framework's own (MIOpen) convolutions; module-hip: nn.Module forward "
+                         "with the HIP convolution Functions (unfused BatchNorm / activation); -graph: replayed "
+                         "as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -222,7 +229,11 @@ def main():
 
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     mode = a.mode
-    replay = {"native": "plan", "native-eager": "eager", "native-graph": "graph", "module": "eager", "module-graph": "graph"}[mode]
+    replay = {"native": "plan", "native-eager": "eager", "native-graph": "graph", "module": "eager", "module-graph": "graph",
+              "module-hip": "eager"}[mode]
+    if mode in ("module", "module-graph"):
+        from temporalstereo_amd import layers
+        layers.set_conv_backend("torch")
     # inputs='bind': the features stay where the (out-of-scope) backbone would write them, resident in HBM
     runner = InferenceEngine(net, backend=mode.split("-")[0], replay=replay, inputs="bind")
 
@@ -258,15 +269,17 @@ def main():
     if rank == 0:
         pairs = world * a.batch * a.steps
         # dominant cost-volume launch: the 1/4-resolution (precise) sampled build
+        # The judged figure is the complete op at its unfused boundary; the native
+        # pipeline itself runs the variant without the repeated left half, reported next to it.
         pkey = (a.batch, 2 * DIMS['precise']['in_planes'], RUN_H // 4, RUN_W // 4, 5, True)
-        if pkey not in k1_times:      # the native path builds the volume without the repeated left half
-            pkey = pkey[:5] + ("warped",)
+        wkey = pkey[:5] + ("warped",)
         roofline = None
         if pkey in k1_times:
             nbytes = k1_algorithmic_bytes(*pkey)
             ach = nbytes / k1_times[pkey]
-            all_b = sum(k1_algorithmic_bytes(*k) for k in k1_times)
-            all_t = sum(k1_times.values())
+            used = [k for k in k1_times if not (k[5] is True and k[:5] + ("warped",) in k1_times)]   # what the pipeline launched
+            all_b = sum(k1_algorithmic_bytes(*k) for k in used)
+            all_t = sum(k1_times[k] for k in used)
             traffic = None
             try:    # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected in-process)
                 with open(os.path.join(ROOT, "profiles", "r01_k1_hbm_traffic_pmc.json")) as fh:
@@ -279,10 +292,16 @@ def main():
                             traffic=traffic,
                             measured="HIP events on the launch stream around the C-ABI call, %d back-to-back "
                                      "launches on the pipeline's own tensors right after the timed steps" % max(a.steps, 20),
-                            kernel="%s (block_cost_fast + block_cost_upsample) on [%d,%d,%d,%d] x %d candidates"
-                                   % (("ts_block_cost_sampled_warped_fwd" if pkey[5] == "warped" else "ts_block_cost_sampled_fwd",) + pkey[:5]),
+                            kernel="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample_direct) on "
+                                   "[%d,%d,%d,%d] x %d candidates" % pkey[:5],
                             algorithmic_bytes=nbytes, mean_us=k1_times[pkey] * 1e6,
                             frac_of_measured_copy_ceiling=ach / 6.29e12,
+                            pipeline_variant=(dict(kernel="ts_block_cost_sampled_warped_fwd (volume without the D-fold repeat of "
+                                                          "the left features; what the native pipeline launches)",
+                                                   algorithmic_bytes=k1_algorithmic_bytes(*wkey), mean_us=k1_times[wkey] * 1e6,
+                                                   achieved=k1_algorithmic_bytes(*wkey) / k1_times[wkey] / 1e9,
+                                                   frac=k1_algorithmic_bytes(*wkey) / k1_times[wkey] / HBM_PEAK)
+                                              if wkey in k1_times else None),
                             all_levels=dict(algorithmic_bytes=all_b, mean_us=all_t * 1e6,
                                             achieved=all_b / all_t / 1e9, frac=all_b / all_t / HBM_PEAK))
         result = dict(metric="stereo pairs/sec, FlyingThings3D 540x960 D=192 (aggregation hot path)",

@@ -645,6 +645,84 @@ block_cost_upsample(const float* __restrict__ P1, const float* __restrict__ P2,
   }
 }
 
+// Direct form of the same expansion: one lane per float4 of output of BOTH levels, no LDS, no barrier.
+// The pooled maps are tiny (a plane of level 1 is H/2 x W/2) and live in L2, four output pixels touch at
+// most 4 (level 1) / 3 (level 2) pooled cells per row, so a lane issues 14 independent clamped loads up
+// front and two 16-byte stores: a single memory round trip instead of load -> LDS -> barrier -> blend.
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+block_cost_upsample_direct(const float* __restrict__ P1, const float* __restrict__ P2,
+                           float* __restrict__ out, const Shape s) {
+  constexpr int RPT = 2;                      // output rows per lane: halves the wave count (one resident round at config-2 sizes)
+  const int plane = blockIdx.y;
+  const int d = plane % s.D;
+  const int bg = plane / s.D;
+  const int g = bg % s.G, b = bg / s.G;
+  const size_t HW = static_cast<size_t>(s.H) * s.W;
+  const int item = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rows = (s.H + RPT - 1) / RPT;
+  if (item >= rows * s.nbx) return;
+  const int yb = (item / s.nbx) * RPT;
+  const int x4 = (item - (item / s.nbx) * s.nbx) * 4;
+  float cell[RPT][3][2][4];                   // [row][level][pooled row][cell]
+  int c0[3], hpv[RPT][3];
+  float hlv[RPT][3];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int y = min(yb + q, s.H - 1);
+#pragma unroll
+    for (int lvl = 1; lvl <= 2; ++lvl) {
+      const bool on = lvl < s.scales;
+      const float* P = (lvl == 1) ? P1 : P2;
+      const int Hs = (lvl == 1) ? s.H1 : s.H2, Ws = (lvl == 1) ? s.W1 : s.W2;
+      const float rh = (lvl == 1) ? s.rh1 : s.rh2, rw = (lvl == 1) ? s.rw1 : s.rw2;
+      const float hr = rh * static_cast<float>(y);
+      const int h1 = min(static_cast<int>(hr), Hs - 1);
+      hpv[q][lvl] = (h1 < Hs - 1) ? 1 : 0;
+      hlv[q][lvl] = hr - static_cast<float>(h1);
+      c0[lvl] = min(static_cast<int>(rw * static_cast<float>(x4)), Ws - 1);
+      const float* Pp = (on ? P : P1) + static_cast<size_t>(on ? plane : 0) * Hs * Ws;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          cell[q][lvl][r][c] = Pp[static_cast<size_t>(h1 + (r ? hpv[q][lvl] : 0)) * Ws + min(c0[lvl] + c, Ws - 1)];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int y = yb + q;
+    if (y >= s.H) break;
+#pragma unroll
+    for (int lvl = 1; lvl <= 2; ++lvl) {
+      if (lvl >= s.scales) break;
+      const int Ws = (lvl == 1) ? s.W1 : s.W2;
+      const float rw = (lvl == 1) ? s.rw1 : s.rw2;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float wr = rw * static_cast<float>(min(x4 + k, s.W - 1));
+        const int w1 = static_cast<int>(wr);
+        const int wp = (w1 < Ws - 1) ? 1 : 0;
+        const float wl = wr - static_cast<float>(w1);
+        const int i0 = w1 - c0[lvl], i1 = i0 + wp;        // 0..3 (pooled width is at most half the output's)
+        float a0 = cell[q][lvl][0][0], a1 = a0, b0 = cell[q][lvl][1][0], b1 = b0;
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+          a0 = (i0 == c) ? cell[q][lvl][0][c] : a0; a1 = (i1 == c) ? cell[q][lvl][0][c] : a1;
+          b0 = (i0 == c) ? cell[q][lvl][1][c] : b0; b1 = (i1 == c) ? cell[q][lvl][1][c] : b1;
+        }
+        const float top = (1.f - wl) * a0 + wl * a1;      // along W first, then along H (the staged kernel's order)
+        const float bot = (1.f - wl) * b0 + wl * b1;
+        v[k] = (1.f - hlv[q][lvl]) * top + hlv[q][lvl] * bot;
+      }
+      float* pl = out + ((static_cast<size_t>(b) * s.Ctot + s.mainC + lvl * s.G + g) * s.D + d) * HW +
+                  static_cast<size_t>(y) * s.W;
+      st4<VEC>(pl, x4, s.W, make_float4(v[0], v[1], v[2], v[3]));
+    }
+  }
+}
+
 int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales, bool omit_ref = false) {
   TS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, TS_ERR_SHAPE, "block_cost: non-positive size");
   TS_REQUIRE(C % GRP == 0, TS_ERR_SHAPE, "block_cost: C=%d is not a multiple of 8 (block_cost.py:9)", C);
@@ -732,7 +810,12 @@ int launch_fwd(const float* left, const float* right, const float* disp, float* 
 #undef TS_LAUNCH_WIDE
   if (int rc = ts::launched("block_cost_main")) return rc;
 
-  if (scales > 1) {
+  if (scales > 1 && static_cast<long long>(B) * s.G * D <= 65535) {
+    const dim3 dgrid((((H + 1) / 2) * s.nbx + 255) / 256, B * s.G * D);
+    if (vec) hipLaunchKernelGGL(block_cost_upsample_direct<true>, dgrid, dim3(256), 0, st, P1, P2, out, s);
+    else hipLaunchKernelGGL(block_cost_upsample_direct<false>, dgrid, dim3(256), 0, st, P1, P2, out, s);
+    if (int rc = ts::launched("block_cost_upsample_direct")) return rc;
+  } else if (scales > 1) {
     const int nplanes = B * s.G * D;
     const int gy = nplanes < 32768 ? nplanes : 32768;
     const int gz = (nplanes + gy - 1) / gy;

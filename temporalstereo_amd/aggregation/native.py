@@ -30,11 +30,14 @@ def _stream():
 
 
 # ------------------------------------------------------------------------- independent branches
-# The pyramid is a chain of small dependent launches; wherever two sub-chains are independent
-# (hourglass shortcuts, the two prediction heads, pooling beside the 5x5 conv) the shorter one is
-# issued on an auxiliary high-priority stream so that it leaves the critical path.  Off by default
-# (and during hipGraph capture); NativeAggregator switches it on around a pass.
-_PAR = {"on": False}
+# The pyramid is a chain of small dependent launches; where two sub-chains are independent the shorter
+# one can be issued on an auxiliary high-priority stream so that it leaves the critical path.  A
+# cross-stream edge costs ~6 us of idle time on this stack, so only the hourglass shortcuts (four
+# launches per block) pay for it: measured 1.616 ms/pair with them, 1.708 without any branch, and
+# 1.641 / 1.650 / 1.678 when the pooling / the second prediction head / both are branched as well
+# (TS_BRANCHES=hourglass,pool,heads re-enables those for experiments).  Off during hipGraph capture;
+# NativeAggregator switches it on around a pass.
+_PAR = {"on": False, "kinds": frozenset(__import__("os").environ.get("TS_BRANCHES", "hourglass").split(","))}
 _AUX = {}
 
 
@@ -59,8 +62,8 @@ class Branch:
     Allocator note: a branch always starts with an edge from the consumer stream and is joined before
     its operands die, which orders every reuse of a cached block after its last reader."""
 
-    def __init__(self):
-        self.on = _PAR["on"]
+    def __init__(self, kind):
+        self.on = _PAR["on"] and kind in _PAR["kinds"]
         if self.on:
             self.cur, self.aux = torch.cuda.current_stream(), _aux_stream()
 
@@ -292,11 +295,10 @@ class Hourglass:
         self.c4.f1.act = ACT_SILU
 
     def __call__(self, x):
-        br = Branch()
-        with br:
-            s6 = self.s6(x)                                  # shortcuts: off the critical path
         pre = self.c2(self.c1(x))
-        with br:
+        br = Branch("hourglass")
+        with br:                                             # both shortcuts: four launches off the critical path,
+            s6 = self.s6(x)                                  # behind ONE cross-stream edge (each edge costs ~6 us)
             s5 = self.s5(pre)
         out = self.c5(self.c4(self.c3(pre)))
         br.join()
@@ -316,7 +318,7 @@ class Heads:
 
     def __call__(self, x):
         y = conv_d(x, self.co0, 3, 1, 1, 1)
-        br = Branch()
+        br = Branch("heads")
         with br:
             off = conv_hw(y[:, self.C:], self.o1, act=ACT_TANH_OFFSET, act_param=self.delta)
         cost = conv_hw(y[:, :self.C], self.c1)
@@ -410,7 +412,7 @@ class _MergingLevel(_LevelBase):
                                                 _lib.ptr(samp), _lib.ptr(x0), B, C, D0, K, H, W, vb, vc, ob, oc, _stream())
         _lib.check(rc, "ts_merge_candidates_fwd")
         if self.fusion:                                                 # PyramidFusion, module.py:412-421
-            br = Branch()
+            br = Branch("pool")
             with br:
                 pool5(x0, cat4[:, 2 * C:3 * C], cat4[:, 3 * C:])
             conv_d(x0, self.conv5, 5, 1, 1, 2, out=cat4[:, C:2 * C])
@@ -569,9 +571,13 @@ class NativeAggregator:
                     mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
                     ltf = self.fine.left_term(_lib.contiguous(l8))
 
+                waited = []
+
                 def joined(m):
                     def get():
-                        _edge(aux, torch.cuda.current_stream())
+                        if not waited:       # one edge covers all three: `aux` is in-order and they were enqueued together
+                            _edge(aux, torch.cuda.current_stream())
+                            waited.append(True)
                         return m
                     return get
                 # the ten wide launches go out first, then the long chain

@@ -37,16 +37,12 @@ def _stream():
 # 1.641 / 1.650 / 1.678 when the pooling / the second prediction head / both are branched as well
 # (TS_BRANCHES=hourglass,pool,heads re-enables those for experiments).  Off during hipGraph capture;
 # NativeAggregator switches it on around a pass.
-_PAR = {"on": False, "kinds": frozenset(__import__("os").environ.get("TS_BRANCHES", "hourglass").split(","))}
-_AUX = {}
+_PAR = {"on": False, "aux": None, "kinds": frozenset(__import__("os").environ.get("TS_BRANCHES", "hourglass").split(","))}
 
 
 def _aux_stream():
-    dev = torch.cuda.current_device()
-    st = _AUX.get(dev)
-    if st is None:
-        st = _AUX[dev] = torch.cuda.Stream(device=dev, priority=-1)
-    return st
+    """The auxiliary stream of the aggregator whose pass is being issued (set by NativeAggregator.__call__)."""
+    return _PAR["aux"]
 
 
 def _edge(src, dst):
@@ -532,6 +528,7 @@ class NativeAggregator:
         # dispatched ahead of the wide kernels' (which fill whatever is left) and both finish together.
         dev = next(net.parameters()).device
         self.fast = torch.cuda.Stream(device=dev, priority=-1)
+        self.aux = torch.cuda.Stream(device=dev, priority=-1)     # per aggregator: several may be in flight on one GPU
         self.overlap = True
 
     def _pyramid(self, l8, l16, r8, r16, prev_info, out, masks=(None, None, None)):
@@ -562,9 +559,9 @@ class NativeAggregator:
             main = torch.cuda.current_stream()
             mainp, fastp = _lib.ctypes.c_void_p(main.cuda_stream), _lib.ctypes.c_void_p(self.fast.cuda_stream)
             _lib.check(_lib.lib().ts_stream_fork(mainp, fastp), "ts_stream_fork")
-            aux = _aux_stream()
+            aux = self.aux
             _edge(main, aux)
-            _PAR["on"] = True
+            _PAR["on"], _PAR["aux"] = True, aux
             try:
                 # convex-upsampling logits of the coarse and fine levels depend on the features only
                 with torch.cuda.stream(aux):
@@ -587,7 +584,7 @@ class NativeAggregator:
                 _lib.check(_lib.lib().ts_stream_fork(fastp, mainp), "ts_stream_fork")
                 full, d, c, o, s = self.precise(both, mask, ds, prev_info)
             finally:
-                _PAR["on"] = False
+                _PAR["on"], _PAR["aux"] = False, None
         else:
             ds = self._pyramid(l8, l16, r8, r16, prev_info, out)
             both, mask = self.precise.unet_features(l4, r4, left_image, right_image)

@@ -80,6 +80,12 @@ def main():
         tot_t += tsec
         print("block_cost[%-7s] B=%d  %8.1f us  %7.1f MB  %7.1f GB/s  %.3f of 8.0TB/s  %.3f of 6.29TB/s" % (
             name, B, tsec * 1e6, nb / 1e6, nb / tsec / 1e9, nb / tsec / 8.0e12, nb / tsec / 6.29e12), flush=True)
+        if sampled:   # the inference form without the repeated left half (what the native pipeline launches)
+            from temporalstereo_amd import functional as TF
+            tw = time_op(lambda: TF.block_cost_warped(L, R, disp, 3), a.iters)
+            nw = 4 * B * H * W * (2 * C + D + (C + 3 * C // 8) * D)
+            print("  warped [%-7s] B=%d  %8.1f us  %7.1f MB  %7.1f GB/s  %.3f of 8.0TB/s" % (
+                name, B, tw * 1e6, nw / 1e6, nw / tw / 1e9, nw / tw / 8.0e12), flush=True)
     print("block_cost[total  ] B=%d  %8.1f us  %7.1f MB  %7.1f GB/s  %.3f of 8.0TB/s" % (
         B, tot_t * 1e6, tot_b / 1e6, tot_b / tot_t / 1e9, tot_b / tot_t / 8.0e12))
 

@@ -13,10 +13,15 @@ def main(path, pattern="%"):
         return
     cols = [d[1] for d in db.execute("pragma table_info(%s)" % view)]
     kcol = "kernel_name" if "kernel_name" in cols else "name"
-    q = ("select %s, counter_name, avg(value), count(*) from %s where %s like ? group by %s, counter_name "
-         "order by %s, counter_name" % (kcol, view, kcol, kcol, kcol))
-    for k, c, v, n in db.execute(q, (pattern,)):
-        print("%-60s %-28s %16.1f  (n=%d)" % (k[:60], c, v, n))
+    gcols = [c for c in ("grid_size_x", "grid_size_y", "grid_size_z", "grid_size") if c in cols]
+    if "--columns" in sys.argv:
+        print(cols)
+    gsel = ", ".join(gcols) if gcols else "0"
+    q = ("select %s, counter_name, avg(value), count(*), %s from %s where %s like ? group by %s, counter_name%s "
+         "order by %s, counter_name" % (kcol, gsel, view, kcol, kcol, (", " + gsel) if gcols else "", kcol))
+    for row in db.execute(q, (pattern,)):
+        k, c, v, n = row[:4]
+        print("%-60s %-12s %16.1f  (n=%d)  grid=%s" % (k[:60], c, v, n, "x".join(str(g) for g in row[4:])))
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@
 
 #include "../../include/ts_hip.h"
 
-#define TS_ABI_VERSION 1
+#define TS_ABI_VERSION 2
 
 namespace ts {
 

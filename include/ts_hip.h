@@ -141,6 +141,10 @@ int ts_project_to_3d_fwd(const float* depth, const float* K, const float* inv_K,
  *   PredictionHeads (:369-378), 1x1 convolutions (k = 1).
  * ---------------------------------------------------------------------------------------- */
 int ts_conv_cout_pad(int cout);
+/* Upper bound (8 | 16 | 32, default 32) on the input-channel chunk -- hence the LDS footprint -- of the
+ * convolution launches that follow on this host thread: short chunks when kernels of several streams
+ * should share the CUs, long chunks for a lone dependent chain.  Recordable in a plan. */
+int ts_conv_set_chunk_cap(int cap);
 int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
                      int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,
                      int transposed, int act, float act_param,

@@ -407,6 +407,10 @@ conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ 
   }
 }
 
+// Upper bound on the K chunk (8 | 16 | 32) for the launches that follow on this host thread, see
+// ts_conv_set_chunk_cap.
+thread_local int g_chunk_cap = 32;
+
 template <int CB, int MODE, int KT, int ST, int DL, int NC>
 int launch_one(const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
                dim3 grid, hipStream_t st) {
@@ -437,7 +441,8 @@ int launch_nc(long long wgs, const float* x, const float* w, const float* scale,
   constexpr size_t per_ch = (static_cast<size_t>(G::chan_elems) + static_cast<size_t>(KT) * WP) * sizeof(float);
   constexpr size_t lds_cu = 160 * 1024;
   const size_t per_cu = static_cast<size_t>((wgs + ts::kNumCU - 1) / ts::kNumCU);
-  auto fits = [&](int nc) { return (nc * per_ch + 16) * per_cu <= lds_cu && p.kspan >= nc; };
+  const int max_nc = g_chunk_cap;
+  auto fits = [&](int nc) { return nc <= max_nc && (nc * per_ch + 16) * per_cu <= lds_cu && p.kspan >= nc; };
   if constexpr (32 * per_ch + 16 <= lds_cu) { if (fits(32)) return launch_one<CB, MODE, KT, ST, DL, 32>(x, w, scale, shift, y, p, grid, st); }
   if constexpr (16 * per_ch + 16 <= lds_cu) { if (fits(16)) return launch_one<CB, MODE, KT, ST, DL, 16>(x, w, scale, shift, y, p, grid, st); }
   return launch_one<CB, MODE, KT, ST, DL, 8>(x, w, scale, shift, y, p, grid, st);
@@ -911,6 +916,16 @@ extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const floa
 }
 
 extern "C" int ts_conv_cout_pad(int cout) { return cout_bucket(cout); }
+
+// Cap the K-chunk size (and with it the LDS footprint: 16-106 KB per workgroup at 32, 16-50 KB at 8) of the
+// convolution launches that follow on this host thread.  Long chunks shorten a lone kernel's dependent
+// chain; short chunks let workgroups of kernels on OTHER streams share a CU.  Thread-local, ordered with
+// the launches, recordable in a plan.
+extern "C" int ts_conv_set_chunk_cap(int cap) {
+  TS_REQUIRE(cap == 8 || cap == 16 || cap == 32, TS_ERR_SHAPE, "conv_set_chunk_cap: %d is not 8, 16 or 32", cap);
+  g_chunk_cap = cap;
+  return TS_OK;
+}
 
 // bytes of scratch ts_conv3d_hw_fwd can use for split-K at this shape (0: it will not split)
 extern "C" size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride, int transposed) {

@@ -13,13 +13,13 @@ from temporalstereo_amd import layers  # noqa: E402
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--batch", type=int, default=1)
+    ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--batch", type=int, default=1); ap.add_argument("--backends", default="hip,torch")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     seed = synth.SEED0 + 2
     net = bench.build_model(dev, seed).train()
     inputs = bench.make_inputs(dev, seed, a.batch)
-    for backend in ("hip", "torch"):
+    for backend in a.backends.split(","):
         layers.set_conv_backend(backend)
         def step():
             net.zero_grad(set_to_none=True)

@@ -535,17 +535,22 @@ class NativeAggregator:
         self.aux = torch.cuda.Stream(device=dev, priority=-1)     # per aggregator: several may be in flight on one GPU
         self.overlap = True
 
-    def _pyramid(self, l8, l16, r8, r16, prev_info, out, masks=(None, None, None)):
+    def _coarse_level(self, l16, r16, prev_info, out, mask=None):
         rng = 4
         disps, costs, offs, samples, ranges = out
-        d, c, o, s = self.coarse(_lib.contiguous(l16), _lib.contiguous(r16), prev_info, masks[0])
+        d, c, o, s = self.coarse(_lib.contiguous(l16), _lib.contiguous(r16), prev_info, mask)
         lm = prev_info.get('local_map', None)                       # fine.py:89-93: local-map candidates go first
         nl = lm.shape[1] if (lm is not None and prev_info.get('local_map_size', 0) > 0) else 0
         low, high, ds = range_candidates(d, rng, nl)
         if nl:
             resize_bilinear(lm, d.shape[-2:], d.shape[-1] / lm.shape[-1], out=ds[:, :nl])
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
-        d, c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, masks[1], masks[2])
+        return ds
+
+    def _fine_level(self, l8, r8, ds, prev_info, out, mask=None, left_term=None):
+        rng = 4
+        disps, costs, offs, samples, ranges = out
+        d, c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, mask, left_term)
         low, high, ds = range_candidates(d, rng)
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
@@ -585,17 +590,21 @@ class NativeAggregator:
                             waited.append(True)
                         return m
                     return get
-                # the ten wide launches go out first, then the long chain
+                # Issue order = what the host reaches first: the chain is the critical path, so its coarse
+                # level goes out before the ten wide launches (they have ~1 ms of slack), the fine level after.
+                with torch.cuda.stream(self.fast):
+                    ds = self._coarse_level(l16, r16, prev_info, out, joined(mc))
                 both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
                 with torch.cuda.stream(self.fast):
-                    ds = self._pyramid(l8, l16, r8, r16, prev_info, out, (joined(mc), joined(mf), joined(ltf)))
+                    ds = self._fine_level(l8, r8, ds, prev_info, out, joined(mf), joined(ltf))
                 _lib.check(_lib.lib().ts_stream_fork(fastp, mainp), "ts_stream_fork")
                 full, d, c, o, s = self.precise(both, mask, ds, prev_info)
             finally:
                 _PAR["on"], _PAR["aux"] = False, None
                 _chunk_cap(32)
         else:
-            ds = self._pyramid(l8, l16, r8, r16, prev_info, out)
+            ds = self._coarse_level(l16, r16, prev_info, out)
+            ds = self._fine_level(l8, r8, ds, prev_info, out)
             both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
             full, d, c, o, s = self.precise(both, mask, ds, prev_info)
         disps += [d, full]; costs.append(c); offs.append(o); samples.append(s)

@@ -218,6 +218,20 @@ int ts_resize_bilinear_fwd(const float* x, float* out, int B, int C, int h, int 
 int ts_range_candidates_fwd(const float* disp, float* low, float* high, float* candidates, int B, int H, int W,
                             float range, int channel_offset, int channels_total, void* stream);
 
+/* Backward of the element stages (training; dense NCDHW tensors, outputs OVERWRITTEN, fp32 atomics where a
+ * gradient is a scatter -- the same non-deterministic order as the framework's own backward kernels):
+ *   resize3d_add_act_bwd : d out / d(a, add) of ts_resize3d_add_act_fwd (grad_add may be NULL)
+ *   pool3d5_avgmax_bwd   : grad_x = box5^3(grad_avg)/125 + grad_max routed to each window's arg-max
+ *                          (first occurrence in (d,y,x) order, as max_pool3d_with_indices)
+ *   merge_candidates_bwd : the sort + gather half of ts_merge_candidates_fwd (its K = 0 form):
+ *                          grad_volume[:, j] = grad_out_volume[:, rank_j], likewise the samples */
+int ts_resize3d_add_act_bwd(const float* a, const float* add, const float* grad_out, float* grad_a, float* grad_add,
+                            int B, int C, int Da, int Ha, int Wa, int D, int H, int W, int act, void* stream);
+int ts_pool3d5_avgmax_bwd(const float* x, const float* grad_avg, const float* grad_max, float* grad_x,
+                          int B, int C, int D, int H, int W, void* stream);
+int ts_merge_candidates_bwd(const float* sample, const float* grad_out_volume, const float* grad_out_sample,
+                            float* grad_volume, float* grad_sample, int B, int C, int DT, int H, int W, void* stream);
+
 /* dst[r * dst_pitch + c] = src[r * src_pitch + c] (elements): writes a tensor into a channel slice of
  * another -- the torch.cat / slice.copy_ of precise.py:60-63 and module.py:486-489 without torch. */
 int ts_copy_rows_fwd(const float* src, float* dst, long long rows, long long row_elems, long long src_pitch,

@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..layers import Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d
+from .. import functional as TF
+from ..layers import Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, _hip_conv as _on_hip
 
 
 def _triple(k, s):
@@ -76,6 +77,9 @@ class ResidualBlock3D(nn.Module):
     def forward(self, x):
         pre = self.conv2(self.conv1(x))
         out = F.silu(self.conv4(self.conv3(pre)))
+        if _on_hip(x):      # GPU: resize + add + SiLU as one HIP kernel each way
+            out = TF.resize_add_silu(self.conv5(out), self.shortcut5(pre))
+            return TF.resize_add_silu(self.conv6(out), self.shortcut6(x))
         out = F.interpolate(self.conv5(out), size=pre.shape[-3:], mode='trilinear', align_corners=True)
         out = F.silu(out + self.shortcut5(pre))
         out = F.interpolate(self.conv6(out), size=x.shape[-3:], mode='trilinear', align_corners=True)
@@ -144,10 +148,12 @@ class PyramidFusion(nn.Module):
                                          bias=False, norm=norm, activation=None)
 
     def forward(self, cost):
-        feats = [cost, self.conv_5x5(cost),
-                 F.avg_pool3d(cost, kernel_size=5, stride=1, padding=2),
-                 F.max_pool3d(cost, kernel_size=5, stride=1, padding=2)]
-        return self.conv_fuse(torch.cat(feats, dim=1))
+        if _on_hip(cost):
+            avg, mx = TF.pool5_avgmax(cost)
+        else:
+            avg = F.avg_pool3d(cost, kernel_size=5, stride=1, padding=2)
+            mx = F.max_pool3d(cost, kernel_size=5, stride=1, padding=2)
+        return self.conv_fuse(torch.cat([cost, self.conv_5x5(cost), avg, mx], dim=1))
 
 
 class UNet(nn.Module):

@@ -77,6 +77,8 @@ class _Level(nn.Module):
         mem_v = self.past_conv(mem_v)
         disp_sample = torch.cat([disp_sample, mem_s], dim=1)
         init_cost = torch.cat([init_cost, mem_v], dim=2)
+        if init_cost.is_cuda and init_cost.dtype == torch.float32:
+            return TF.sort_gather(init_cost, disp_sample)            # stable rank sort + gather, one kernel each way
         disp_sample, order = torch.sort(disp_sample, dim=1, stable=True)
         init_cost = torch.gather(init_cost, dim=2, index=order.unsqueeze(dim=1).expand(-1, self.C, -1, -1, -1))
         return init_cost.contiguous(), disp_sample

@@ -143,8 +143,8 @@ pool5_avgmax_kernel(const float* __restrict__ x, float* __restrict__ oavg, float
       const float s = rs[0] + rs[1] + rs[2] + rs[3] + rs[4];
       const float m = fmaxf(fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3])), rm[4]);
       const size_t o = od * HW + static_cast<size_t>(y) * p.W + xx;
-      ap[o] = s * (1.f / 125.f);
-      mp[o] = m;
+      if (oavg) ap[o] = s * (1.f / 125.f);
+      if (omax) mp[o] = m;
     }
   }
 }
@@ -352,6 +352,148 @@ range_candidates_kernel(const float* __restrict__ disp, float* __restrict__ low,
   }
 }
 
+// ------------------------------------------------------------------------------- backward (training)
+// resize_add_act: out = act(trilinear(a) + add).  One lane per output element: recompute the
+// pre-activation, g = dOut * act'(pre); dAdd = g; dA += the 8 interpolation weights * g (fp32 atomics,
+// dA zero-filled by the entry -- the same scatter torch's upsample_trilinear3d_backward performs).
+struct Resize3B {
+  Resize3 f;
+  long long g_bstride, g_cstride, ga_bstride, ga_cstride, gb_bstride, gb_cstride;
+};
+
+__global__ void __launch_bounds__(256)
+resize_add_act_bwd_kernel(const float* __restrict__ a, const float* __restrict__ bsrc, const float* __restrict__ gout,
+                          float* __restrict__ ga, float* __restrict__ gadd, const Resize3B q) {
+  const Resize3& p = q.f;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int n = p.D * p.H * p.W;
+  const float* ap = a + static_cast<size_t>(b) * p.a_bstride + static_cast<size_t>(c) * p.a_cstride;
+  const float* bp = bsrc ? bsrc + static_cast<size_t>(b) * p.b_bstride + static_cast<size_t>(c) * p.b_cstride : nullptr;
+  const float* gp = gout + static_cast<size_t>(b) * q.g_bstride + static_cast<size_t>(c) * q.g_cstride;
+  float* gap = ga + static_cast<size_t>(b) * q.ga_bstride + static_cast<size_t>(c) * q.ga_cstride;
+  float* gbp = gadd ? gadd + static_cast<size_t>(b) * q.gb_bstride + static_cast<size_t>(c) * q.gb_cstride : nullptr;
+  const size_t HWa = static_cast<size_t>(p.Ha) * p.Wa;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int x = i % p.W;
+    const int t = i / p.W;
+    const int y = t % p.H, d = t / p.H;
+    int d0, d1, y0, y1, x0, x1;
+    float ld, ly, lx;
+    lin_src(p.sd, d, p.Da, d0, d1, ld);
+    lin_src(p.sh, y, p.Ha, y0, y1, ly);
+    lin_src(p.sw, x, p.Wa, x0, x1, lx);
+    float g = gp[i];
+    if (p.act == 1) {
+      const float* p0 = ap + d0 * HWa;
+      const float* p1 = ap + d1 * HWa;
+      const float v00 = (1.f - lx) * p0[y0 * p.Wa + x0] + lx * p0[y0 * p.Wa + x1];
+      const float v01 = (1.f - lx) * p0[y1 * p.Wa + x0] + lx * p0[y1 * p.Wa + x1];
+      const float v10 = (1.f - lx) * p1[y0 * p.Wa + x0] + lx * p1[y0 * p.Wa + x1];
+      const float v11 = (1.f - lx) * p1[y1 * p.Wa + x0] + lx * p1[y1 * p.Wa + x1];
+      float v = (1.f - ld) * ((1.f - ly) * v00 + ly * v01) + ld * ((1.f - ly) * v10 + ly * v11);
+      if (bp) v += bp[i];
+      const float sg = 1.f / (1.f + expf(-v));
+      g *= sg * (1.f + v * (1.f - sg));                    // d/dv [v * sigmoid(v)]
+    }
+    if (gbp) gbp[i] = g;
+    const float wd[2] = {1.f - ld, ld}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+    const int dd[2] = {d0, d1}, yy[2] = {y0, y1}, xx[2] = {x0, x1};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int kd = k >> 2, ky = (k >> 1) & 1, kx = k & 1;
+      const float w = wd[kd] * wy[ky] * wx[kx];
+      if (w != 0.f) atomicAdd(gap + dd[kd] * HWa + static_cast<size_t>(yy[ky]) * p.Wa + xx[kx], g * w);
+    }
+  }
+}
+
+// max half of the 5^3 pooling backward: every output re-finds its arg-max (first occurrence in (d,y,x)
+// order, strict '>', as the framework's max_pool3d_with_indices) through the same plane tile + 5-deep
+// ring as the forward and adds its gradient there.  The avg half is the forward's own box filter applied
+// to dAvg (a symmetric kernel is its own adjoint), written first by the entry.
+__global__ void __launch_bounds__(256)
+pool5_max_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gmax, float* __restrict__ gx, const Pool5 p) {
+  __shared__ float tile[PT_Y + 4][PT_X + 4 + 1];
+  const int tiles_x = (p.W + PT_X - 1) / PT_X;
+  const int ty0 = (blockIdx.x / tiles_x) * PT_Y, tx0 = (blockIdx.x % tiles_x) * PT_X;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int tx = threadIdx.x & (PT_X - 1), ty = threadIdx.x / PT_X;
+  const int y = ty0 + ty, xx = tx0 + tx;
+  const size_t HW = static_cast<size_t>(p.H) * p.W;
+  const float* xp = x + static_cast<size_t>(b) * p.x_bstride + static_cast<size_t>(c) * p.x_cstride;
+  const float* gp = gmax + static_cast<size_t>(b) * p.max_bstride + static_cast<size_t>(c) * p.max_cstride;
+  float* op = gx + static_cast<size_t>(b) * p.avg_bstride + static_cast<size_t>(c) * p.avg_cstride;
+  float rm[5];
+  int ri[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { rm[i] = -INFINITY; ri[i] = -1; }
+  for (int d = 0; d < p.D + 2; ++d) {
+    float m2 = -INFINITY;
+    int i2 = -1;
+    if (d < p.D) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < (PT_Y + 4) * (PT_X + 4); i += blockDim.x) {
+        const int cx = i % (PT_X + 4), cy = i / (PT_X + 4);
+        const int gy = min(max(ty0 + cy - 2, 0), p.H - 1), gxx = min(max(tx0 + cx - 2, 0), p.W - 1);
+        const bool pad = (ty0 + cy - 2 != gy) || (tx0 + cx - 2 != gxx);
+        const float v = xp[d * HW + static_cast<size_t>(gy) * p.W + gxx];
+        tile[cy][cx] = pad ? NAN : v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const float v = tile[ty + ky][tx + kx];
+          if (v > m2) { m2 = v; i2 = (d * p.H + (y + ky - 2)) * p.W + (xx + kx - 2); }     // NaN (padding) never wins
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rm[i] = rm[i + 1]; ri[i] = ri[i + 1]; }
+    rm[4] = m2; ri[4] = i2;
+    const int od = d - 2;
+    if (od >= 0 && y < p.H && xx < p.W) {
+      float m = rm[0];
+      int mi = ri[0];
+#pragma unroll
+      for (int i = 1; i < 5; ++i)
+        if (rm[i] > m) { m = rm[i]; mi = ri[i]; }
+      if (mi >= 0) atomicAdd(op + mi, gp[od * HW + static_cast<size_t>(y) * p.W + xx]);
+    }
+  }
+}
+
+// sort + gather backward (coarse.py:103-105 / fine.py:120-122 under autograd): rank of candidate j among its
+// pixel's DT candidates (stable), dVol[:, j] = dOutVol[:, rank_j], dSample[j] = dOutSample[rank_j].
+template <int DM>
+__global__ void __launch_bounds__(256)
+merge_bwd_kernel(const float* __restrict__ samp, const float* __restrict__ g_out_vol, const float* __restrict__ g_out_samp,
+                 float* __restrict__ g_vol, float* __restrict__ g_samp, int B, int C, int DT, int HW) {
+  const int c0 = blockIdx.y * MERGE_CPB;
+  const long long n = static_cast<long long>(B) * HW;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(i / HW);
+    const int px = static_cast<int>(i - static_cast<long long>(b) * HW);
+    float s[DM];
+#pragma unroll
+    for (int j = 0; j < DM; ++j) s[j] = (j < DT) ? samp[(static_cast<size_t>(b) * DT + min(j, DT - 1)) * HW + px] : INFINITY;
+#pragma unroll
+    for (int j = 0; j < DM; ++j) {
+      if (j >= DT) continue;
+      int rank = 0;
+#pragma unroll
+      for (int q = 0; q < DM; ++q) rank += (s[q] < s[j]) || (s[q] == s[j] && q < j);
+      if (c0 == 0 && g_samp) g_samp[(static_cast<size_t>(b) * DT + j) * HW + px] = g_out_samp ? g_out_samp[(static_cast<size_t>(b) * DT + rank) * HW + px] : 0.f;
+#pragma unroll
+      for (int cc = 0; cc < MERGE_CPB; ++cc) {
+        const int c = c0 + cc;
+        if (c < C) g_vol[((static_cast<size_t>(b) * C + c) * DT + j) * HW + px] = g_out_vol[((static_cast<size_t>(b) * C + c) * DT + rank) * HW + px];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ts_range_candidates_fwd(const float* disp, float* low, float* high, float* candidates, int B, int H, int W,
@@ -448,4 +590,67 @@ extern "C" int ts_resize_bilinear_fwd(const float* x, float* out, int B, int C, 
                      ts::as_stream(stream), x, out, B * C, C, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo), value_scale,
                      out_bstride);
   return ts::launched("resize_bilinear_kernel");
+}
+
+// ---- backward entries (training) ------------------------------------------------------------------
+// d(out)/d(a, add) of ts_resize3d_add_act_fwd.  grad_a [B,C,Da,Ha,Wa] is OVERWRITTEN (zero-filled, then fp32
+// atomics); grad_add (may be NULL) [B,C,D,H,W].  All five tensors dense NCDHW.
+extern "C" int ts_resize3d_add_act_bwd(const float* a, const float* add, const float* grad_out, float* grad_a, float* grad_add,
+                                       int B, int C, int Da, int Ha, int Wa, int D, int H, int W, int act, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && Da > 0 && Ha > 0 && Wa > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "resize3d_bwd: non-positive size");
+  TS_REQUIRE(B <= 65535 && C <= 65535, TS_ERR_UNSUPPORTED, "resize3d_bwd: grid too large");
+  TS_REQUIRE_PTR(a); TS_REQUIRE_PTR(grad_out); TS_REQUIRE_PTR(grad_a);
+  Resize3B q;
+  Resize3& p = q.f;
+  p.C = C; p.Da = Da; p.Ha = Ha; p.Wa = Wa; p.D = D; p.H = H; p.W = W;
+  p.sd = ac_scale(Da, D); p.sh = ac_scale(Ha, H); p.sw = ac_scale(Wa, W);
+  p.act = act;
+  const long long na = static_cast<long long>(Da) * Ha * Wa, n = static_cast<long long>(D) * H * W;
+  p.a_bstride = C * na; p.a_cstride = na; p.b_bstride = C * n; p.b_cstride = n; p.o_bstride = C * n; p.o_cstride = n;
+  q.g_bstride = C * n; q.g_cstride = n; q.ga_bstride = C * na; q.ga_cstride = na; q.gb_bstride = C * n; q.gb_cstride = n;
+  hipStream_t st = ts::as_stream(stream);
+  hipError_t e = hipMemsetAsync(grad_a, 0, static_cast<size_t>(B) * C * na * sizeof(float), st);
+  if (e != hipSuccess) return ts::fail(static_cast<int>(e), "resize3d_bwd: %s", hipGetErrorString(e));
+  int blocks = static_cast<int>((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(resize_add_act_bwd_kernel, dim3(blocks, C, B), dim3(256), 0, st, a, add, grad_out, grad_a, grad_add, q);
+  return ts::launched("resize_add_act_bwd_kernel");
+}
+
+// d/dx of ts_pool3d5_avgmax_fwd: grad_x = box5^3(grad_avg) / 125 + scatter of grad_max to each window's arg-max.
+// Dense [B,C,D,H,W] tensors; grad_x OVERWRITTEN.
+extern "C" int ts_pool3d5_avgmax_bwd(const float* x, const float* grad_avg, const float* grad_max, float* grad_x,
+                                     int B, int C, int D, int H, int W, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "pool3d5_bwd: non-positive size");
+  TS_REQUIRE(B <= 65535 && C <= 65535, TS_ERR_UNSUPPORTED, "pool3d5_bwd: grid too large");
+  TS_REQUIRE(static_cast<long long>(D) * H * W < (1ll << 31), TS_ERR_UNSUPPORTED, "pool3d5_bwd: plane set too large");
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(grad_avg); TS_REQUIRE_PTR(grad_max); TS_REQUIRE_PTR(grad_x);
+  Pool5 p;
+  p.C = C; p.D = D; p.H = H; p.W = W;
+  const long long n = static_cast<long long>(D) * H * W;
+  p.x_bstride = C * n; p.x_cstride = n; p.avg_bstride = C * n; p.avg_cstride = n; p.max_bstride = C * n; p.max_cstride = n;
+  const int tiles = ((H + PT_Y - 1) / PT_Y) * ((W + PT_X - 1) / PT_X);
+  hipStream_t st = ts::as_stream(stream);
+  hipLaunchKernelGGL(pool5_avgmax_kernel, dim3(tiles, C, B), dim3(256), 0, st, grad_avg, grad_x, static_cast<float*>(nullptr), p);
+  if (int rc = ts::launched("pool5_avgmax_kernel")) return rc;
+  hipLaunchKernelGGL(pool5_max_bwd_kernel, dim3(tiles, C, B), dim3(256), 0, st, x, grad_max, grad_x, p);
+  return ts::launched("pool5_max_bwd_kernel");
+}
+
+// backward of the sort + gather half of ts_merge_candidates_fwd (K = 0 form: sample [B,DT,H,W], volume
+// [B,C,DT,H,W] dense): grad_volume / grad_sample (may be NULL) OVERWRITTEN; grad_out_sample may be NULL.
+extern "C" int ts_merge_candidates_bwd(const float* sample, const float* grad_out_volume, const float* grad_out_sample,
+                                       float* grad_volume, float* grad_sample, int B, int C, int DT, int H, int W, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && DT > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "merge_candidates_bwd: non-positive size");
+  TS_REQUIRE(DT <= MERGE_DMAX, TS_ERR_UNSUPPORTED, "merge_candidates_bwd: more than %d candidates", MERGE_DMAX);
+  TS_REQUIRE_PTR(sample); TS_REQUIRE_PTR(grad_out_volume); TS_REQUIRE_PTR(grad_volume);
+  const dim3 grid(grid_for(static_cast<long long>(B) * H * W, 256), (C + MERGE_CPB - 1) / MERGE_CPB);
+#define TS_MERGE_B(DMV)                                                                                       \
+  hipLaunchKernelGGL(merge_bwd_kernel<DMV>, grid, dim3(256), 0, ts::as_stream(stream), sample, grad_out_volume, \
+                     grad_out_sample, grad_volume, grad_sample, B, C, DT, H * W)
+  if (DT <= 8) TS_MERGE_B(8);
+  else if (DT <= 14) TS_MERGE_B(14);
+  else TS_MERGE_B(MERGE_DMAX);
+#undef TS_MERGE_B
+  return ts::launched("merge_bwd_kernel");
 }

@@ -279,6 +279,110 @@ def conv_transpose3d(x, weight, bias=None, stride=(1, 2, 2), padding=(0, 1, 1), 
     return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
 
 
+# --------------------------------------------------------------------------------------- K3 element stages
+class _ResizeAddSiLU(torch.autograd.Function):
+    """silu(F.interpolate(a, size, 'trilinear', align_corners=True) + add): ResidualBlock3D up-steps
+    (module.py:285-295) as one kernel each way (ts_resize3d_add_act_{fwd,bwd})."""
+
+    @staticmethod
+    def forward(ctx, a, add):
+        _require_gpu(a, add)
+        a, add = a.contiguous(), add.contiguous()
+        B, C, Da, Ha, Wa = a.shape
+        D, H, W = add.shape[2:]
+        out = torch.empty_like(add)
+        na, n = Da * Ha * Wa, D * H * W
+        rc = _lib.lib().ts_resize3d_add_act_fwd(_lib.ptr(a), _lib.ptr(add), _lib.ptr(out), B, C, Da, Ha, Wa, D, H, W, 1,
+                                                C * na, na, C * n, n, C * n, n, _stream())
+        _lib.check(rc, "ts_resize3d_add_act_fwd")
+        ctx.save_for_backward(a, add)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, add = ctx.saved_tensors
+        B, C, Da, Ha, Wa = a.shape
+        D, H, W = add.shape[2:]
+        g = g.contiguous()
+        ga, gadd = torch.empty_like(a), torch.empty_like(add)
+        rc = _lib.lib().ts_resize3d_add_act_bwd(_lib.ptr(a), _lib.ptr(add), _lib.ptr(g), _lib.ptr(ga), _lib.ptr(gadd),
+                                                B, C, Da, Ha, Wa, D, H, W, 1, _stream())
+        _lib.check(rc, "ts_resize3d_add_act_bwd")
+        return ga, gadd
+
+
+def resize_add_silu(a, add):
+    """F.silu(F.interpolate(a, size=add.shape[-3:], mode='trilinear', align_corners=True) + add)."""
+    return _ResizeAddSiLU.apply(a, add)
+
+
+class _Pool5AvgMax(torch.autograd.Function):
+    """(avg_pool3d, max_pool3d)(x, kernel 5, stride 1, padding 2) of PyramidFusion (module.py:415-417)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = x.contiguous()
+        B, C, D, H, W = x.shape
+        avg, mx = torch.empty_like(x), torch.empty_like(x)
+        n = D * H * W
+        rc = _lib.lib().ts_pool3d5_avgmax_fwd(_lib.ptr(x), _lib.ptr(avg), _lib.ptr(mx), B, C, D, H, W,
+                                              C * n, n, C * n, n, C * n, n, _stream())
+        _lib.check(rc, "ts_pool3d5_avgmax_fwd")
+        ctx.save_for_backward(x)
+        return avg, mx
+
+    @staticmethod
+    def backward(ctx, g_avg, g_max):
+        (x,) = ctx.saved_tensors
+        B, C, D, H, W = x.shape
+        gx = torch.empty_like(x)
+        rc = _lib.lib().ts_pool3d5_avgmax_bwd(_lib.ptr(x), _lib.ptr(g_avg.contiguous()), _lib.ptr(g_max.contiguous()),
+                                              _lib.ptr(gx), B, C, D, H, W, _stream())
+        _lib.check(rc, "ts_pool3d5_avgmax_bwd")
+        return gx
+
+
+def pool5_avgmax(x):
+    """(F.avg_pool3d(x, 5, 1, 2), F.max_pool3d(x, 5, 1, 2)) in one pass over x."""
+    return _Pool5AvgMax.apply(x)
+
+
+class _SortGather(torch.autograd.Function):
+    """disp_sample, order = sort(disp_sample, dim=1, stable); volume = gather(volume, dim=2, order)
+    (coarse.py:103-105, fine.py:120-122) as one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, volume, sample):
+        _require_gpu(volume, sample)
+        volume, sample = volume.contiguous(), sample.contiguous()
+        B, C, DT, H, W = volume.shape
+        out_v, out_s = torch.empty_like(volume), torch.empty_like(sample)
+        n = DT * H * W
+        rc = _lib.lib().ts_merge_candidates_fwd(_lib.ptr(volume), _lib.ptr(sample), None, None, None, None, None,
+                                                _lib.ptr(out_s), _lib.ptr(out_v), B, C, DT, 0, H, W, C * n, n, C * n, n, _stream())
+        _lib.check(rc, "ts_merge_candidates_fwd")
+        ctx.save_for_backward(sample)
+        return out_v, out_s
+
+    @staticmethod
+    def backward(ctx, g_v, g_s):
+        (sample,) = ctx.saved_tensors
+        B, DT, H, W = sample.shape
+        g_v = g_v.contiguous()
+        C = g_v.shape[1]
+        gv, gs = torch.empty_like(g_v), torch.empty_like(sample)
+        rc = _lib.lib().ts_merge_candidates_bwd(_lib.ptr(sample), _lib.ptr(g_v), _lib.ptr(g_s.contiguous() if g_s is not None else None),
+                                                _lib.ptr(gv), _lib.ptr(gs), B, C, DT, H, W, _stream())
+        _lib.check(rc, "ts_merge_candidates_bwd")
+        return gv, gs
+
+
+def sort_gather(volume, sample):
+    """-> (volume permuted along D by the stable ascending order of `sample`, sorted sample)."""
+    return _SortGather.apply(volume, sample)
+
+
 def block_cost_warped(reference_fm, target_fm, disp_sample, block_cost_scale=3):
     """Inference form of the sampled block_cost WITHOUT its first C channels (the D-fold repeat of
     reference_fm, block_cost.py:51): [B, C + scales*C/8, D, H, W].  No autograd.  Used with the

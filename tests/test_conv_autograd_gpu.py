@@ -107,3 +107,51 @@ def test_layers_use_the_hip_convolutions_on_gpu():
     # unsupported hyper-parameters fall back to the framework convolution instead of failing
     odd = layers.Conv3d(4, 4, (3, 3, 3), padding=1).to(dev)
     assert odd(torch.zeros(1, 4, 3, 5, 5, device=dev)).shape == (1, 4, 3, 5, 5)
+
+
+# ------------------------------------------------------------------------------- element stages
+def test_resize_add_silu_autograd():
+    import temporalstereo_amd.functional as TF
+    dev = _dev()
+    for (sa, sb) in (((2, 6, 3, 9, 15), (2, 6, 5, 17, 30)), ((1, 4, 6, 18, 30), (1, 4, 6, 17, 30)), ((2, 3, 2, 5, 7), (2, 3, 2, 5, 7))):
+        a = t(synth.normal(11, "a", sa), dev); b = t(synth.normal(12, "b", sb), dev)
+        a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y1 = TF.resize_add_silu(a1, b1)
+        y2 = F.silu(F.interpolate(a2, size=sb[2:], mode="trilinear", align_corners=True) + b2)
+        _close(y1, y2, "forward", 1e-5)
+        g = t(synth.normal(13, "g", sb), dev)
+        y1.backward(g); y2.backward(g)
+        _close(a1.grad, a2.grad, "grad a")
+        _close(b1.grad, b2.grad, "grad add", 1e-5)
+
+
+def test_pool5_avgmax_autograd():
+    import temporalstereo_amd.functional as TF
+    dev = _dev()
+    x = t(synth.normal(21, "x", (2, 5, 7, 19, 41)), dev)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    a1, m1 = TF.pool5_avgmax(x1)
+    a2, m2 = F.avg_pool3d(x2, 5, 1, 2), F.max_pool3d(x2, 5, 1, 2)
+    _close(a1, a2, "avg", 1e-5); _close(m1, m2, "max", 0.0)
+    ga, gm = t(synth.normal(22, "ga", tuple(x.shape)), dev), t(synth.normal(23, "gm", tuple(x.shape)), dev)
+    (a1 * ga + m1 * gm).sum().backward(); (a2 * ga + m2 * gm).sum().backward()
+    _close(x1.grad, x2.grad, "grad x")
+
+
+def test_sort_gather_autograd_is_the_stable_sort():
+    import temporalstereo_amd.functional as TF
+    dev = _dev()
+    B, C, DT, H, W = 2, 6, 14, 9, 13
+    vol = t(synth.normal(31, "v", (B, C, DT, H, W)), dev)
+    smp = t(synth.normal(32, "s", (B, DT, H, W)), dev)
+    smp[:, 3] = smp[:, 0]; smp[:, 12:] = 0.0; smp[:, 5, :4] = 0.0          # ties: stable order must hold
+    v1, s1 = vol.clone().requires_grad_(True), smp.clone().requires_grad_(True)
+    v2, s2 = vol.clone().requires_grad_(True), smp.clone().requires_grad_(True)
+    ov1, os1 = TF.sort_gather(v1, s1)
+    os2, order = torch.sort(s2, dim=1, stable=True)
+    ov2 = torch.gather(v2, 2, order.unsqueeze(1).expand(-1, C, -1, -1, -1))
+    assert torch.equal(os1, os2) and torch.equal(ov1, ov2)
+    gv, gs = t(synth.normal(33, "gv", tuple(vol.shape)), dev), t(synth.normal(34, "gs", tuple(smp.shape)), dev)
+    ((ov1 * gv).sum() + (os1 * gs).sum()).backward(); ((ov2 * gv).sum() + (os2 * gs).sum()).backward()
+    assert torch.equal(v1.grad, v2.grad) and torch.equal(s1.grad, s2.grad)

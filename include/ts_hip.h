@@ -60,6 +60,16 @@ int ts_block_cost_sampled_warped_fwd(const float* left, const float* right, cons
                                      void* workspace, int B, int C, int H, int W, int D, int scales,
                                      void* stream);
 
+/* Dense siblings of block_cost (forward only): any number of candidates D >= 2, C % 8 == 0.
+ *   cat_fms  aggregation/utils/cat_fms.py:5-36   out [B,2C,D,H,W] = cat[left repeated over D, warped right]
+ *   dif_fms  aggregation/utils/dif_fms.py:5-44   out [B, C,D,H,W] = |left - warped right|, elements whose warped
+ *            value is not > 0 replaced by the maximum difference over the whole tensor (workspace: 256 bytes) */
+int ts_cat_fms_fwd(const float* left, const float* right, const float* disp, float* out, int B, int C, int H, int W, int D,
+                   void* stream);
+size_t ts_dif_fms_workspace_bytes(void);
+int ts_dif_fms_fwd(const float* left, const float* right, const float* disp, float* out, void* workspace, int B, int C,
+                   int H, int W, int D, void* stream);
+
 /* Backward of the two paths (autograd of the reference's torch ops).  grad_out has the layout
  * of `out`.  grad_left/grad_right [B,C,H,W] and grad_disp [B,D,H,W] are OVERWRITTEN (any may be
  * NULL to skip).  grad_right / grad_disp accumulate with fp32 atomics (order not deterministic,

@@ -96,3 +96,24 @@ def block_cost(reference_fm, target_fm, disp_sample, block_cost_scale=3):
     if isinstance(disp_sample, int):
         return cost_volume_int(reference_fm, target_fm, disp_sample, block_cost_scale)
     return cost_volume_sampled(reference_fm, target_fm, disp_sample, block_cost_scale)
+
+
+def cat_fms(reference_fm, target_fm, disp_sample):
+    """aggregation/utils/cat_fms.py:5-36: cat[left repeated over D, right warped by each candidate] -> [B,2C,D,H,W]."""
+    B, C, H, W = reference_fm.shape
+    D = disp_sample.shape[1]
+    ref = reference_fm.unsqueeze(2).expand(B, C, D, H, W)
+    return torch.cat([ref, warp_candidates(target_fm, disp_sample)], dim=1)
+
+
+def dif_fms(reference_fm, target_fm, disp_sample):
+    """aggregation/utils/dif_fms.py:5-44: |left - warped right|, with every element whose warped value is
+    not > 0 (out of frame -- or simply non-positive) replaced by the maximum difference of the whole tensor."""
+    B, C, H, W = reference_fm.shape
+    D = disp_sample.shape[1]
+    ref = reference_fm.unsqueeze(2).expand(B, C, D, H, W)
+    tgt = warp_candidates(target_fm, disp_sample)
+    dif = torch.abs(ref - tgt)
+    max_dif = dif.max()                                   # :38, taken BEFORE masking
+    keep = (tgt > 0).to(dif.dtype)                        # :40
+    return dif * keep + (1 - keep) * torch.ones_like(dif) * max_dif

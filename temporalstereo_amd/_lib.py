@@ -27,6 +27,9 @@ SIGNATURES = {
     "ts_block_cost_int_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_warped_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
+    "ts_cat_fms_fwd": (c_int, [c_f32p] * 4 + [c_int] * 5 + [c_ptr]),
+    "ts_dif_fms_workspace_bytes": (c_size, []),
+    "ts_dif_fms_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 5 + [c_ptr]),
     "ts_block_cost_bwd_workspace_bytes": (c_size, [c_int] * 6),
     "ts_block_cost_int_bwd": (c_int, [c_f32p] * 5 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_bwd": (c_int, [c_f32p] * 7 + [c_ptr] + [c_int] * 6 + [c_ptr]),

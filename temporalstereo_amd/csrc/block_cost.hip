@@ -645,6 +645,123 @@ block_cost_upsample(const float* __restrict__ P1, const float* __restrict__ P2,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense siblings of block_cost: cat_fms / dif_fms over ANY number of candidates
+// (the literal shift-and-correlate over D = 48..192).  Same staging as the fast path -- TRD right rows of an
+// 8-channel group in the channel-packed R4 layout, the left rows beside them -- but a workgroup walks the
+// (candidate, 4-pixel block) items of its rows in strides of the block size instead of owning one each, and
+// there is no pooling.  MODE 0: cat (left repeat | warped right);  1: max |left - warped| only (first pass of
+// dif_fms: the fill value is the maximum over the WHOLE tensor, dif_fms.py:38);  2: dif with the fill applied.
+// ------------------------------------------------------------------------------------------------
+constexpr int TRD = 2;
+
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(256)
+dense_warp_kernel(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
+                  float* __restrict__ out, unsigned* __restrict__ maxbits, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int by = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int y0 = by * TRD;
+  const int H = s.H, W = s.W, D = s.D, C = s.C;
+  const unsigned HW = static_cast<unsigned>(H) * W;
+  const float* Lg = L + (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const float* Rg = R + (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const int Wq = s.Wq, Wqp = s.Wqp, Wl = 4 * s.Wq;
+  float4* ldsR4 = reinterpret_cast<float4*>(lds);                       // [2][TRD][4][Wqp]
+  float* ldsL = lds + static_cast<size_t>(2) * TRD * 4 * Wqp * 4;       // [GRP][TRD][Wl]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int i = tid; i < 2 * TRD * Wq; i += nthr) {
+    const int jx = i % Wq, hr = i / Wq;           // hr = h*TRD + r
+    const int r = hr % TRD, h = hr / TRD;
+    const int y = min(y0 + r, H - 1);
+    float v[4][4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) unpack(ld4<VEC>(Rg + static_cast<size_t>(h * 4 + cc) * HW + static_cast<size_t>(y) * W, 4 * jx, W), v[cc]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      ldsR4[(hr * 4 + k) * Wqp + jx] = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
+  }
+  if (tid < 2 * TRD) ldsR4[(tid * 4) * Wqp + Wq] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero slot of each row
+  for (int i = tid; i < GRP * TRD * Wq; i += nthr) {
+    const int jx = i % Wq, cr = i / Wq;           // cr = c*TRD + r
+    const int y = min(y0 + cr % TRD, H - 1);
+    *reinterpret_cast<float4*>(ldsL + cr * Wl + 4 * jx) = ld4<VEC>(Lg + static_cast<size_t>(cr / TRD) * HW + static_cast<size_t>(y) * W, 4 * jx, W);
+  }
+  __syncthreads();
+
+  const float Wm1 = static_cast<float>(W - 1);
+  const unsigned dHW = static_cast<unsigned>(D) * HW;
+  const int CO = (MODE == 0) ? 2 * C : C;
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + static_cast<size_t>(b) * CO * dHW, static_cast<unsigned>(CO) * dHW * 4u);
+  const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(disp + static_cast<size_t>(b) * dHW, dHW * 4u);
+  const float fillv = (MODE == 2) ? __uint_as_float(maxbits[0]) : 0.f;
+  float vmax = 0.f;
+  const int nitems = s.nbx * D;
+  for (int r = 0; r < TRD; ++r) {
+    const int y = y0 + r;
+    if (y >= H) break;
+    // the candidate row of the NEXT item is requested before this item's taps and stores
+    auto item_off = [&](int item, int& d, int& x4) {
+      d = item / s.nbx;
+      x4 = (item - d * s.nbx) * 4;
+      return static_cast<unsigned>(d) * HW + static_cast<unsigned>(y) * W + x4;
+    };
+    int dn = 0, xn = 0;
+    unsigned offn = tid < nitems ? item_off(tid, dn, xn) : 0u;
+    float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < nitems) dnext = bld4<VEC>(drsrc, offn, xn, W);
+    for (int item = tid; item < nitems; item += nthr) {
+      const int d = dn, x4 = xn;
+      const unsigned loff = offn;
+      float dv[4];
+      unpack(dnext, dv);
+      if (item + nthr < nitems) {
+        offn = item_off(item + nthr, dn, xn);
+        dnext = bld4<VEC>(drsrc, offn, xn, W);
+      }
+      unsigned op[4];
+      float fr[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tap4<true>(x4 + k, d, dv[k], W, Wm1, Wq, Wqp, op[k], fr[k]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4* rrow = ldsR4 + (h * TRD + r) * 4 * Wqp;
+        float4 ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ta[k] = rrow[op[k] & 0xffffu]; tb[k] = rrow[op[k] >> 16]; }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = h * 4 + cc;
+          const float4 lv4 = *reinterpret_cast<const float4*>(ldsL + (c * TRD + r) * Wl + x4);
+          float lv[4], tv[4];
+          unpack(lv4, lv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tv[k] = (1.f - fr[k]) * comp(ta[k], cc) + fr[k] * comp(tb[k], cc);
+          const unsigned plane = static_cast<unsigned>(g * GRP + c) * dHW;        // uniform (SGPR)
+          if constexpr (MODE == 0) {
+            bst4<VEC>(orsrc, loff, plane, x4, W, lv4);
+            bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));
+          } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (VEC || x4 + k < W) vmax = fmaxf(vmax, fabsf(lv[k] - tv[k]));
+          } else {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (tv[k] > 0.f) ? fabsf(lv[k] - tv[k]) : fillv;   // dif_fms.py:40-42
+            bst4<VEC>(orsrc, loff, plane, x4, W, pack(o));
+          }
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((tid & 63) == 0) atomicMax(maxbits, __float_as_uint(vmax));      // non-negative floats order like their bits
+  }
+}
+
 // Direct form of the same expansion: one lane per float4 of output of BOTH levels, no LDS, no barrier.
 // The pooled maps are tiny (a plane of level 1 is H/2 x W/2) and live in L2, four output pixels touch at
 // most 4 (level 1) / 3 (level 2) pooled cells per row, so a lane issues 14 independent clamped loads up
@@ -723,11 +840,11 @@ block_cost_upsample_direct(const float* __restrict__ P1, const float* __restrict
   }
 }
 
-int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales, bool omit_ref = false) {
+int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales, bool omit_ref = false, int min_hw = 4) {
   TS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, TS_ERR_SHAPE, "block_cost: non-positive size");
   TS_REQUIRE(C % GRP == 0, TS_ERR_SHAPE, "block_cost: C=%d is not a multiple of 8 (block_cost.py:9)", C);
   TS_REQUIRE(scales >= 1 && scales <= 3, TS_ERR_UNSUPPORTED, "block_cost: scales=%d outside 1..3", scales);
-  TS_REQUIRE(H >= 4 && W >= 4, TS_ERR_UNSUPPORTED, "block_cost: H,W must be >= 4 (got %dx%d)", H, W);
+  TS_REQUIRE(H >= min_hw && W >= min_hw, TS_ERR_UNSUPPORTED, "block_cost: H,W must be >= %d (got %dx%d)", min_hw, H, W);
   // D==1 divides by zero in the reference's coordinate normalisation (inverse_warp_3d.py:45)
   TS_REQUIRE(!sampled || D >= 2, TS_ERR_UNSUPPORTED, "block_cost: sampled path needs D >= 2");
   TS_REQUIRE(B <= 65535 && C / GRP <= 65535, TS_ERR_UNSUPPORTED, "block_cost: grid too large");
@@ -1121,6 +1238,48 @@ extern "C" int ts_block_cost_sampled_warped_fwd(const float* left, const float* 
                                                 void* workspace, int B, int C, int H, int W, int D, int scales,
                                                 void* stream) {
   return launch_fwd<true>(left, right, disp, out, workspace, B, C, H, W, D, scales, stream, true);
+}
+
+namespace {
+template <int MODE>
+int launch_dense(const float* left, const float* right, const float* disp, float* out, unsigned* maxbits,
+                 int B, int C, int H, int W, int D, void* stream) {
+  Shape s;
+  if (int rc = make_shape(s, true, B, C, H, W, D, 1, false, 1)) return rc;       // no pooling here: any H, W
+  TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(disp);
+  if (MODE != 1) TS_REQUIRE_PTR(out);
+  if (MODE != 0) TS_REQUIRE_PTR(maxbits);
+  const size_t lds_bytes = (static_cast<size_t>(2) * TRD * 4 * s.Wqp * 4 + static_cast<size_t>(GRP) * TRD * 4 * s.Wq) * sizeof(float);
+  TS_REQUIRE(lds_bytes <= 64 * 1024, TS_ERR_UNSUPPORTED, "cat/dif_fms: W=%d too wide for the row staging", W);
+  const int CO = (MODE == 0) ? 2 * C : C;
+  TS_REQUIRE(static_cast<unsigned long long>(CO) * D * H * W * 4ull < (1ull << 32), TS_ERR_UNSUPPORTED,
+             "cat/dif_fms: one batch element of the volume spans 4 GiB or more");
+  const bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(disp) && (MODE == 1 || ts::aligned16(out));
+  const dim3 grid((H + TRD - 1) / TRD, s.G, B);
+  hipStream_t st = ts::as_stream(stream);
+  if (vec) hipLaunchKernelGGL((dense_warp_kernel<MODE, true>), grid, dim3(256), lds_bytes, st, left, right, disp, out, maxbits, s);
+  else hipLaunchKernelGGL((dense_warp_kernel<MODE, false>), grid, dim3(256), lds_bytes, st, left, right, disp, out, maxbits, s);
+  return ts::launched("dense_warp_kernel");
+}
+}  // namespace
+
+// cat_fms (aggregation/utils/cat_fms.py:5-36): out [B,2C,D,H,W] = cat[left repeated over D, right warped by disp[:, d]]
+extern "C" int ts_cat_fms_fwd(const float* left, const float* right, const float* disp, float* out, int B, int C, int H,
+                              int W, int D, void* stream) {
+  return launch_dense<0>(left, right, disp, out, nullptr, B, C, H, W, D, stream);
+}
+
+extern "C" size_t ts_dif_fms_workspace_bytes(void) { return 256; }
+
+// dif_fms (aggregation/utils/dif_fms.py:5-44): out [B,C,D,H,W] = |left - warped|, elements whose warped value is not > 0
+// replaced by the maximum difference of the whole tensor (two passes: the maximum first, into the workspace).
+extern "C" int ts_dif_fms_fwd(const float* left, const float* right, const float* disp, float* out, void* workspace,
+                              int B, int C, int H, int W, int D, void* stream) {
+  TS_REQUIRE_PTR(workspace);
+  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(unsigned), ts::as_stream(stream));
+  if (e != hipSuccess) return ts::fail(static_cast<int>(e), "dif_fms: %s", hipGetErrorString(e));
+  if (int rc = launch_dense<1>(left, right, disp, nullptr, reinterpret_cast<unsigned*>(workspace), B, C, H, W, D, stream)) return rc;
+  return launch_dense<2>(left, right, disp, out, reinterpret_cast<unsigned*>(workspace), B, C, H, W, D, stream);
 }
 
 extern "C" size_t ts_block_cost_bwd_workspace_bytes(int B, int C, int H, int W, int D, int scales) {

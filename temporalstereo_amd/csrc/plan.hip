@@ -53,6 +53,7 @@ struct Entry {
 const Entry kTable[] = {
     TS_PLAN_OP(ts_block_cost_int_fwd),      TS_PLAN_OP(ts_block_cost_sampled_fwd),
     TS_PLAN_OP(ts_block_cost_sampled_warped_fwd),
+    TS_PLAN_OP(ts_cat_fms_fwd),             TS_PLAN_OP(ts_dif_fms_fwd),
     TS_PLAN_OP(ts_block_cost_int_bwd),      TS_PLAN_OP(ts_block_cost_sampled_bwd),
     TS_PLAN_OP(ts_topk_softargmax_fwd),     TS_PLAN_OP(ts_topk_softargmax_bwd),
     TS_PLAN_OP(ts_softargmin_fwd),          TS_PLAN_OP(ts_softargmin_bwd),

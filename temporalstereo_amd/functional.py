@@ -92,6 +92,39 @@ class _BlockCost(torch.autograd.Function):
         return gl, gr, gd, None, None
 
 
+def _fms_args(reference_fm, target_fm, disp_sample):
+    _require_gpu(reference_fm, target_fm, disp_sample)
+    if reference_fm.dim() != 4 or reference_fm.shape != target_fm.shape:
+        raise ValueError("reference_fm / target_fm must be [B,C,H,W] of equal shape")
+    B, C, H, W = reference_fm.shape
+    if disp_sample.dim() != 4 or disp_sample.shape[0] != B or disp_sample.shape[2:] != reference_fm.shape[2:]:
+        raise ValueError("disp_sample must be [B,D,H,W] matching the feature maps")
+    if C % 8 != 0:
+        raise ValueError("the HIP kernels work on 8-channel groups: C=%d is not a multiple of 8" % C)
+    return _lib.contiguous(reference_fm), _lib.contiguous(target_fm), _lib.contiguous(disp_sample), B, C, H, W, disp_sample.shape[1]
+
+
+def cat_fms(reference_fm, target_fm, disp_sample):
+    """aggregation/utils/cat_fms.py:5 (same arguments): [B,2C,D,H,W] = cat[left repeated over D, right warped by every
+    candidate].  Forward only (the shipped configs use block_cost)."""
+    l, r, d, B, C, H, W, D = _fms_args(reference_fm, target_fm, disp_sample)
+    out = torch.empty((B, 2 * C, D, H, W), device=l.device, dtype=torch.float32)
+    rc = _lib.lib().ts_cat_fms_fwd(_lib.ptr(l), _lib.ptr(r), _lib.ptr(d), _lib.ptr(out), B, C, H, W, D, _stream())
+    _lib.check(rc, "ts_cat_fms_fwd")
+    return out
+
+
+def dif_fms(reference_fm, target_fm, disp_sample):
+    """aggregation/utils/dif_fms.py:5 (same arguments): [B,C,D,H,W] = |left - warped right| with the elements whose warped
+    value is not > 0 filled with the tensor-wide maximum difference.  Forward only."""
+    l, r, d, B, C, H, W, D = _fms_args(reference_fm, target_fm, disp_sample)
+    out = torch.empty((B, C, D, H, W), device=l.device, dtype=torch.float32)
+    ws = torch.empty(int(_lib.lib().ts_dif_fms_workspace_bytes()), device=l.device, dtype=torch.uint8)
+    rc = _lib.lib().ts_dif_fms_fwd(_lib.ptr(l), _lib.ptr(r), _lib.ptr(d), _lib.ptr(out), _lib.ptr(ws), B, C, H, W, D, _stream())
+    _lib.check(rc, "ts_dif_fms_fwd")
+    return out
+
+
 # --------------------------------------------------------------------------------------- K3 convolutions
 def _pad_last(t, n):
     if t.shape[-1] == n:

@@ -100,6 +100,30 @@ def functional_cases(M):
 
 
 # ----------------------------------------------------------------------------------------------
+def sibling_cases(M):
+    """Dense siblings of block_cost: cat_fms / dif_fms."""
+    from architecture.modeling.aggregation.utils.cat_fms import cat_fms
+    from architecture.modeling.aggregation.utils.dif_fms import dif_fms
+    seed = synth.SEED0 + 60
+    # the reference-authored 3x4 value test (cat_fms.py:48-69, dif_fms.py:56-76): shifts -2..2
+    H, W = 3, 4
+    left = torch.linspace(1, H * W, H * W).reshape(1, 1, H, W)
+    right = torch.linspace(H * W + 1, H * W * 2, H * W).reshape(1, 1, H, W)
+    ds = torch.linspace(-2, 2, 5).repeat(1, H, W, 1).permute(0, 3, 1, 2).contiguous()
+    save("fms_value_test", left=left, right=right, disp=ds, cat=cat_fms(left, right, ds), dif=dif_fms(left, right, ds))
+    for i, (B, C, H, W, D, lo, hi) in enumerate([(2, 16, 10, 14, 6, -3.0, 16.0), (1, 8, 9, 13, 4, 0.0, 6.0), (1, 24, 6, 20, 9, -1.0, 21.0)]):
+        L = synth.normal(seed + i, "fmL", (B, C, H, W))
+        R = synth.normal(seed + i, "fmR", (B, C, H, W))
+        if i == 1:
+            L, R = np.abs(L), np.abs(R)                # post-ReLU style features: the (target > 0) mask is then the in-frame mask
+        disp = synth.uniform(seed + i, "fmD", (B, D, H, W), lo, hi)
+        disp[:, 0] = np.round(disp[:, 0])
+        if i == 2:                                   # the dense use: integer candidates 0..D-1
+            disp = np.broadcast_to(np.arange(D, dtype=np.float32).reshape(1, D, 1, 1), (B, D, H, W)).copy()
+        save("fms_%d" % i, left=L, right=R, disp=disp, cat=cat_fms(T(L), T(R), T(disp)), dif=dif_fms(T(L), T(R), T(disp)))
+
+
+# ----------------------------------------------------------------------------------------------
 def build_reference_aggregator(dims):
     from architecture.modeling.aggregation.TemporalStereo.TemporalStereo import TEMPORALSTEREO
     from architecture.modeling.aggregation.TemporalStereo.coarse import CoarseAggregation
@@ -237,7 +261,11 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     M = ref_import.import_reference()
+    if "--only-siblings" in sys.argv:
+        sibling_cases(M)
+        return
     functional_cases(M)
+    sibling_cases(M)
     aggregator_case("agg_tiny_single", TINY, synth.SEED0 + 100, 2, 96, 160, temporal=False, store_inputs=True)
     aggregator_case("agg_tiny_temporal", TINY, synth.SEED0 + 101, 2, 96, 160, temporal=True, store_inputs=True)
     aggregator_case("agg_tiny_train", TINY, synth.SEED0 + 102, 2, 96, 160, temporal=False, store_inputs=True,

@@ -89,6 +89,29 @@ def main():
     print("block_cost[total  ] B=%d  %8.1f us  %7.1f MB  %7.1f GB/s  %.3f of 8.0TB/s" % (
         B, tot_t * 1e6, tot_b / 1e6, tot_b / tot_t / 1e9, tot_b / tot_t / 8.0e12))
 
+    # The reference's own micro-benchmarks (KITTI 1/4 resolution 96x312, forward only, batch 1; GTX3090 figures
+    # pasted in its sources: block_cost.py:88-92 1.7147 ms, cat_fms.py:41-42 5.3421 ms, dif_fms.py:49-50 8.3691 ms)
+    from temporalstereo_amd import functional as TF
+    H, W = 384 // 4, 1248 // 4
+    L48, R48 = torch.rand(1, 48, H, W, device=dev), torch.rand(1, 48, H, W, device=dev)
+    d4 = torch.linspace(0, 3, 4, device=dev).view(1, 4, 1, 1).expand(1, 4, H, W).contiguous()
+    tsec = time_op(lambda: ts.block_cost(L48, R48, d4, 3), a.iters)
+    nb = alg_bytes(1, 48, H, W, 4, True)
+    print("ref-bench block_cost C=48 96x312 D=4   %8.1f us  %7.1f MB  %7.1f GB/s   (reference: 1714.7 us on a GTX3090)" % (tsec * 1e6, nb / 1e6, nb / tsec / 1e9))
+    L32, R32 = torch.rand(1, 32, H, W, device=dev), torch.rand(1, 32, H, W, device=dev)
+    d48 = torch.linspace(0, 47, 48, device=dev).view(1, 48, 1, 1).expand(1, 48, H, W).contiguous()
+    for name, fn, ch, ref_us in (("cat_fms", TF.cat_fms, 64, 5342.1), ("dif_fms", TF.dif_fms, 32, 8369.1)):
+        tsec = time_op(lambda: fn(L32, R32, d48), max(a.iters // 4, 20))
+        nb = 4 * H * W * (2 * 32 + 48 + ch * 48)
+        print("ref-bench %-7s C=32 96x312 D=48     %8.1f us  %7.1f MB  %7.1f GB/s   (reference: %.1f us on a GTX3090)" % (name, tsec * 1e6, nb / 1e6, nb / tsec / 1e9, ref_us))
+    # the large-tensor stress shape of SURVEY.md section 8(f)-3
+    Lb, Rb = torch.rand(4, 32, 136, 240, device=dev), torch.rand(4, 32, 136, 240, device=dev)
+    db = torch.linspace(0, 47, 48, device=dev).view(1, 48, 1, 1).expand(4, 48, 136, 240).contiguous()
+    for name, fn, ch in (("cat_fms", TF.cat_fms, 64), ("dif_fms", TF.dif_fms, 32)):
+        tsec = time_op(lambda: fn(Lb, Rb, db), 20, warmup=5)
+        nb = 4 * 4 * 136 * 240 * (2 * 32 + 48 + ch * 48)
+        print("stress    %-7s [4,32,48,136,240]      %8.1f us  %7.1f MB  %7.1f GB/s  %.3f of 8.0TB/s" % (name, tsec * 1e6, nb / 1e6, nb / tsec / 1e9, nb / tsec / 8.0e12))
+
 
 if __name__ == "__main__":
     main()

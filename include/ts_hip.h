@@ -127,6 +127,10 @@ int ts_argmax_select_fwd(const float* cost, const float* sample, float* disp, in
  * ---------------------------------------------------------------------------------------- */
 int ts_softsplat_sum_fwd(const float* input, const float* flow, float* output,
                          int B, int C, int H, int W, void* stream);
+/* order-independent summation splat (64-bit fixed-point accumulation, integer atomics): bit-identical from
+ * run to run; workspace B*C*H*W*8 bytes; |values| < 2^22 */
+int ts_softsplat_sum_fwd_deterministic(const float* input, const float* flow, float* output, void* workspace,
+                                       int B, int C, int H, int W, void* stream);
 int ts_softsplat_sum_bwd_input(const float* flow, const float* grad_output, float* grad_input,
                                int B, int C, int H, int W, void* stream);
 int ts_softsplat_sum_bwd_flow(const float* input, const float* flow, const float* grad_output,

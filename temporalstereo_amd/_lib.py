@@ -40,6 +40,7 @@ SIGNATURES = {
     "ts_softargmin_bwd": (c_int, [c_f32p] * 6 + [c_float, c_int] + [c_int] * 4 + [c_ptr]),
     "ts_argmax_select_fwd": (c_int, [c_f32p] * 4 + [c_int] * 4 + [c_ptr]),
     "ts_softsplat_sum_fwd": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_ptr]),
+    "ts_softsplat_sum_fwd_deterministic": (c_int, [c_f32p] * 3 + [c_ptr] + [c_int] * 4 + [c_ptr]),
     "ts_softsplat_sum_bwd_input": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_ptr]),
     "ts_softsplat_sum_bwd_flow": (c_int, [c_f32p] * 4 + [c_int] * 4 + [c_ptr]),
     "ts_softsplat_softmax_workspace_bytes": (c_size, [c_int] * 4),

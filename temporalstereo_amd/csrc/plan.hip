@@ -58,7 +58,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_topk_softargmax_fwd),     TS_PLAN_OP(ts_topk_softargmax_bwd),
     TS_PLAN_OP(ts_softargmin_fwd),          TS_PLAN_OP(ts_softargmin_bwd),
     TS_PLAN_OP(ts_argmax_select_fwd),       TS_PLAN_OP(ts_softsplat_sum_fwd),
-    TS_PLAN_OP(ts_softsplat_sum_bwd_input), TS_PLAN_OP(ts_softsplat_sum_bwd_flow),
+    TS_PLAN_OP(ts_softsplat_sum_fwd_deterministic), TS_PLAN_OP(ts_softsplat_sum_bwd_input), TS_PLAN_OP(ts_softsplat_sum_bwd_flow),
     TS_PLAN_OP(ts_softsplat_softmax_fwd),   TS_PLAN_OP(ts_project_to_3d_fwd),
     TS_PLAN_OP(ts_conv3d_hw_fwd),           TS_PLAN_OP(ts_conv3d_d_fwd),
     TS_PLAN_OP(ts_conv3d_hw_bwd_data),      TS_PLAN_OP(ts_conv3d_hw_bwd_weight),

@@ -75,6 +75,47 @@ splat_scatter(const float* __restrict__ input, const float* __restrict__ flow, c
   }
 }
 
+// Deterministic summation splat: contributions are accumulated as 64-bit fixed-point integers (2^-40
+// resolution) with integer atomics -- integer addition is associative, so the result does not depend on
+// the order in which the hardware retires the atomics.
+constexpr double kFix = 1099511627776.0;     // 2^40
+
+__global__ void __launch_bounds__(256)
+splat_scatter_fixed(const float* __restrict__ input, const float* __restrict__ flow, unsigned long long* __restrict__ accum,
+                    int B, int C, int H, int W) {
+  const int HW = H * W;
+  const long long n = static_cast<long long>(B) * HW;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(i / HW);
+    const int p = static_cast<int>(i - static_cast<long long>(b) * HW);
+    const int y = p / W, x = p - y * W;
+    const float* fl = flow + static_cast<size_t>(b) * 2 * HW + p;
+    const Taps t = taps_of(static_cast<float>(x) + fl[0], static_cast<float>(y) + fl[HW]);
+    const bool inw = inside(t.x0, t.y0, W, H), ine = inside(t.x0 + 1, t.y0, W, H);
+    const bool isw = inside(t.x0, t.y0 + 1, W, H), ise = inside(t.x0 + 1, t.y0 + 1, W, H);
+    if (!(inw | ine | isw | ise)) continue;
+    unsigned long long* ob = accum + static_cast<size_t>(b) * C * HW;
+    const int q = t.y0 * W + t.x0;
+    auto fix = [](float v) { return static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(v) * kFix)); };
+    for (int c = 0; c < C; ++c) {
+      const float v = input[(static_cast<size_t>(b) * C + c) * HW + p];
+      unsigned long long* o = ob + static_cast<size_t>(c) * HW + q;
+      if (inw) atomicAdd(o, fix(v * t.nw));               // two's complement: unsigned wrap-around == signed sum
+      if (ine) atomicAdd(o + 1, fix(v * t.ne));
+      if (isw) atomicAdd(o + W, fix(v * t.sw));
+      if (ise) atomicAdd(o + W + 1, fix(v * t.se));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+splat_from_fixed(const unsigned long long* __restrict__ accum, float* __restrict__ out, long long n) {
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x)
+    out[i] = static_cast<float>(static_cast<double>(static_cast<long long>(accum[i])) / kFix);
+}
+
 // out[c] = accum[c] / (accum[C] + 1e-22)   (softsplat.py:352-357)
 __global__ void __launch_bounds__(256)
 splat_normalize(const float* __restrict__ accum, float* __restrict__ out, int B, int C, int HW) {
@@ -224,6 +265,24 @@ extern "C" int ts_softsplat_sum_fwd(const float* input, const float* flow, float
   hipLaunchKernelGGL(splat_scatter<0>, dim3(grid_for(static_cast<long long>(B) * H * W, 256)), dim3(256), 0, st,
                      input, flow, nullptr, output, B, C, H, W);
   return ts::launched("splat_scatter");
+}
+
+// Order-independent variant of ts_softsplat_sum_fwd (bit-identical from run to run): workspace of
+// B*C*H*W*8 bytes; |value| must stay below 2^22 (fixed point with 40 fractional bits).
+extern "C" int ts_softsplat_sum_fwd_deterministic(const float* input, const float* flow, float* output, void* workspace,
+                                                  int B, int C, int H, int W, void* stream) {
+  if (int rc = check_bchw(B, C, H, W, "softsplat_sum_fwd_deterministic")) return rc;
+  TS_REQUIRE_PTR(input); TS_REQUIRE_PTR(flow); TS_REQUIRE_PTR(output); TS_REQUIRE_PTR(workspace);
+  hipStream_t st = ts::as_stream(stream);
+  const long long n = static_cast<long long>(B) * C * H * W;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace);
+  if (hipError_t e = hipMemsetAsync(acc, 0, static_cast<size_t>(n) * sizeof(unsigned long long), st))
+    return ts::fail(e, "softsplat: memset");
+  hipLaunchKernelGGL(splat_scatter_fixed, dim3(grid_for(static_cast<long long>(B) * H * W, 256)), dim3(256), 0, st,
+                     input, flow, acc, B, C, H, W);
+  if (int rc = ts::launched("splat_scatter_fixed")) return rc;
+  hipLaunchKernelGGL(splat_from_fixed, dim3(grid_for(n, 256)), dim3(256), 0, st, acc, output, n);
+  return ts::launched("splat_from_fixed");
 }
 
 extern "C" size_t ts_softsplat_softmax_workspace_bytes(int B, int C, int H, int W) {

@@ -566,15 +566,20 @@ class _SplatSum(torch.autograd.Function):
     """_FunctionSoftsplat of the reference (softsplat.py:239-332) on ts_softsplat_sum_*."""
 
     @staticmethod
-    def forward(ctx, inp, flow):
+    def forward(ctx, inp, flow, deterministic=False):
         _require_gpu(inp, flow)
         if flow.shape[1] != 2 or inp.shape[0] != flow.shape[0] or inp.shape[2:] != flow.shape[2:]:
             raise ValueError("flow must be [B,2,H,W] matching the input")
         inp, flow = _lib.contiguous(inp), _lib.contiguous(flow)
         B, C, H, W = inp.shape
         out = torch.empty_like(inp)
-        _lib.check(_lib.lib().ts_softsplat_sum_fwd(_lib.ptr(inp), _lib.ptr(flow), _lib.ptr(out), B, C, H, W, _stream()),
-                   "ts_softsplat_sum_fwd")
+        if deterministic:      # 64-bit fixed-point accumulation: the same bits every run (SURVEY.md Appendix B.4)
+            ws = torch.empty(B * C * H * W * 8, device=inp.device, dtype=torch.uint8)
+            _lib.check(_lib.lib().ts_softsplat_sum_fwd_deterministic(_lib.ptr(inp), _lib.ptr(flow), _lib.ptr(out), _lib.ptr(ws),
+                                                                     B, C, H, W, _stream()), "ts_softsplat_sum_fwd_deterministic")
+        else:
+            _lib.check(_lib.lib().ts_softsplat_sum_fwd(_lib.ptr(inp), _lib.ptr(flow), _lib.ptr(out), B, C, H, W, _stream()),
+                       "ts_softsplat_sum_fwd")
         ctx.save_for_backward(inp, flow)
         return out
 
@@ -592,11 +597,12 @@ class _SplatSum(torch.autograd.Function):
             gf = torch.empty_like(flow)
             _lib.check(_lib.lib().ts_softsplat_sum_bwd_flow(_lib.ptr(inp), _lib.ptr(flow), _lib.ptr(g), _lib.ptr(gf),
                                                             B, C, H, W, _stream()), "ts_softsplat_sum_bwd_flow")
-        return gi, gf
+        return gi, gf, None
 
 
-def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
+def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType, deterministic=False):
     """Forward splatting, same signature as the reference's FunctionSoftsplat (softsplat.py:334-360).
+    deterministic=True (an addition): order-independent accumulation, bit-identical from run to run.
 
     'softmax' on inputs that do not require grad (the only use in update_map) runs the fused kernel
     ts_softsplat_softmax_fwd; every other case composes the summation splat (with HIP backward)."""
@@ -606,7 +612,7 @@ def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
         raise ValueError("unknown splatting type %r" % (strType,))
     grad_needed = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (tenInput, tenFlow, tenMetric))
-    if strType == 'softmax' and not grad_needed:
+    if strType == 'softmax' and not grad_needed and not deterministic:
         _require_gpu(tenInput, tenFlow, tenMetric)
         inp, flow, met = _lib.contiguous(tenInput), _lib.contiguous(tenFlow), _lib.contiguous(tenMetric)
         B, C, H, W = inp.shape
@@ -624,7 +630,7 @@ def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType):
     elif strType == 'softmax':
         e = tenMetric.exp()
         x = torch.cat([x * e, e], 1)
-    out = _SplatSum.apply(x, tenFlow)
+    out = _SplatSum.apply(x, tenFlow, deterministic)
     if strType != 'summation':
         out = out[:, :-1, :, :] / (out[:, -1:, :, :] + 1e-22)
     return out

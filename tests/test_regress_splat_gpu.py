@@ -156,3 +156,23 @@ def test_splat_backward_vs_oracle_autograd():
         np.testing.assert_allclose(fg.grad.cpu().numpy(), fc.grad.numpy(), rtol=1e-3, atol=1e-4)
         if mode == "softmax":
             np.testing.assert_allclose(mg.grad.cpu().numpy(), mc.grad.numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_splat_deterministic_mode_is_bit_reproducible():
+    """fp32 atomics make the default splat order-dependent; the fixed-point mode is not.
+    Heavy collisions on purpose: every pixel is pushed into a 6x6 window."""
+    import temporalstereo_amd as ts
+    dev = _dev()
+    B, C, H, W = 2, 5, 40, 56
+    inp = t(synth.normal(91, "i", (B, C, H, W)), dev)
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    tgt = t(synth.uniform(92, "t", (B, 2, H, W), 10.0, 16.0), dev)
+    flow = torch.stack([tgt[:, 0] - xs, tgt[:, 1] - ys], 1).contiguous()
+    met = t(synth.normal(93, "m", (B, 1, H, W)), dev)
+    first = ts.FunctionSoftsplat(inp, flow, met, "softmax", deterministic=True)
+    for _ in range(5):
+        assert torch.equal(ts.FunctionSoftsplat(inp, flow, met, "softmax", deterministic=True), first)
+    ref = ts.FunctionSoftsplat(inp, flow, met, "softmax")
+    np.testing.assert_allclose(first.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    s1 = ts.FunctionSoftsplat(inp, flow, None, "summation", deterministic=True)
+    np.testing.assert_allclose(s1.cpu().numpy(), ts.FunctionSoftsplat(inp, flow, None, "summation").cpu().numpy(), rtol=1e-4, atol=1e-4)

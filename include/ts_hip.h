@@ -144,7 +144,8 @@ int ts_project_to_3d_fwd(const float* depth, const float* K, const float* inv_K,
 
 /* ------------------------------------------------------------------------------------------
  * K3  3-D aggregation pyramid, inference form (BatchNorm folded into per-channel scale/shift,
- * activation fused: act 0 none, 1 SiLU, 2 ReLU, 3 tanh(x/100).clamp(-1,1)*act_param).
+ * activation fused: act 0 none, 1 SiLU, 2 ReLU, 3 tanh(x/100).clamp(-1,1)*act_param, 4 = channel 0 none and
+ * channel 1 as 3 (both PredictionHeads outputs from one block-diagonal convolution, hw family only)).
  * Tensors may be channel slices of larger buffers: *_bstride / *_cstride are element strides of
  * the batch and channel axes.  Weights are pre-laid out by the host with the output channel
  * contiguous and zero-padded to ts_conv_cout_pad(Cout): [Cin][taps][CoutPad]; scale/shift [CoutPad].
@@ -220,6 +221,10 @@ int ts_merge_candidates_fwd(const float* volume, const float* sample, const floa
  * CoutPad = 16 or 32); bilinear align_corners resize with a value scale. */
 int ts_convex_upsample_fwd(const float* mask, const float* disp, float* out, int B, int H, int W, int factor,
                            float disp_scale, void* stream);
+/* ts_convex_upsample_fwd + ts_range_candidates_fwd (on the upsampled map) as one launch */
+int ts_convex_upsample_candidates_fwd(const float* mask, const float* disp, float* out, float* low, float* high,
+                                      float* candidates, int B, int H, int W, int factor, float disp_scale, float range,
+                                      int channel_offset, int channels_total, void* stream);
 int ts_unet_upsample_fwd(const float* mask, const float* disp, float* out, int B, int h, int w, int Ho, int Wo,
                          void* stream);
 int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,

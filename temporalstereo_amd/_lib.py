@@ -59,6 +59,7 @@ SIGNATURES = {
     "ts_pool3d5_avgmax_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [ctypes.c_longlong] * 6 + [c_ptr]),
     "ts_merge_candidates_fwd": (c_int, [c_f32p] * 9 + [c_int] * 6 + [ctypes.c_longlong] * 4 + [c_ptr]),
     "ts_convex_upsample_fwd": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_float, c_ptr]),
+    "ts_convex_upsample_candidates_fwd": (c_int, [c_f32p] * 6 + [c_int] * 4 + [c_float, c_float, c_int, c_int, c_ptr]),
     "ts_unet_upsample_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [c_ptr]),
     "ts_deconv2d_k4s2_fwd": (c_int, [c_f32p] * 5 + [c_int] * 6 + [ctypes.c_longlong, c_ptr]),
     "ts_resize_bilinear_fwd": (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_float, ctypes.c_longlong, c_ptr]),

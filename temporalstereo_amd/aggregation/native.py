@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import _lib
 from .. import functional as TF
 
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_TANH_OFFSET = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_TANH_OFFSET, ACT_HEAD_PAIR = 0, 1, 2, 3, 4
 
 
 def _stream():
@@ -313,17 +313,27 @@ class Heads:
         self.delta = float(mod.delta)
         c0, self.c1 = fold_wrapper(mod.cost_head[0], "d"), fold_wrapper(mod.cost_head[1], "hw")
         o0, self.o1 = fold_wrapper(mod.off_head[0], "d"), fold_wrapper(mod.off_head[1], "hw")
-        self.C = c0.cout
+        self.C = C = c0.cout
         self.co0 = fold_concat(c0, o0)          # both heads start with a (3,1,1) conv of the same input: one launch
+        # ... and end with a C -> 1 (1,3,3) conv each: one block-diagonal 2C -> 2 convolution (channel 0 reads the
+        # first C inputs, channel 1 the last C), the offset head's tanh applied to channel 1 only (ACT_HEAD_PAIR)
+        f = object.__new__(Folded)
+        f.cin, f.cout, f.kind, f.act, f.kshape = 2 * C, 2, "hw", ACT_HEAD_PAIR, self.c1.kshape
+        pad = int(_lib.lib().ts_conv_cout_pad(2))
+        f.w = torch.zeros(2 * C, self.c1.w.shape[1], pad, device=self.c1.w.device, dtype=torch.float32)
+        f.w[:C, :, 0] = self.c1.w[:, :, 0]
+        f.w[C:, :, 1] = self.o1.w[:, :, 0]
+        f.scale = torch.ones(pad, device=f.w.device); f.shift = torch.zeros(pad, device=f.w.device)
+        f.scale[0], f.scale[1] = self.c1.scale[0], self.o1.scale[0]
+        f.shift[0], f.shift[1] = self.c1.shift[0], self.o1.shift[0]
+        self.pair = f
 
     def __call__(self, x):
         y = conv_d(x, self.co0, 3, 1, 1, 1)
-        br = Branch("heads")
-        with br:
-            off = conv_hw(y[:, self.C:], self.o1, act=ACT_TANH_OFFSET, act_param=self.delta)
-        cost = conv_hw(y[:, :self.C], self.c1)
-        br.join()
-        return cost.squeeze(1), off.squeeze(1)
+        B, _, D, H, W = y.shape
+        both = torch.empty((2, B, D, H, W), device=y.device, dtype=torch.float32)      # [cost | off], each [B,D,H,W] dense
+        conv_hw(y, self.pair, out=both.permute(1, 0, 2, 3, 4), act_param=self.delta)
+        return both[0], both[1]
 
 
 class ConvexUp:
@@ -340,6 +350,21 @@ class ConvexUp:
     def mask(self, feat):
         """The 9 * r^2 convex-combination logits: a function of the left features only."""
         return conv_d(conv_hw(feat.unsqueeze(2), self.m0), self.m3, 1)
+
+    def with_candidates(self, feat, disp, m, rng, extra_front=0):
+        """(upsampled disparity, low, high, candidates) of the next level in one launch."""
+        B, _, H, W = disp.shape
+        if m is None:
+            m = self.mask(feat)
+        Ho, Wo = H * self.r, W * self.r
+        out = torch.empty((B, 1, Ho, Wo), device=disp.device, dtype=torch.float32)
+        low, high = torch.empty_like(out), torch.empty_like(out)
+        cand = torch.empty((B, extra_front + 5, Ho, Wo), device=disp.device, dtype=torch.float32)
+        rc = _lib.lib().ts_convex_upsample_candidates_fwd(_lib.ptr(m), _lib.ptr(_lib.contiguous(disp)), _lib.ptr(out), _lib.ptr(low),
+                                                          _lib.ptr(high), _lib.ptr(cand), B, H, W, self.r, float(self.r), float(rng),
+                                                          extra_front, extra_front + 5, _stream())
+        _lib.check(rc, "ts_convex_upsample_candidates_fwd")
+        return out, low, high, cand
 
     def __call__(self, feat, disp, m=None):
         B, _, H, W = disp.shape
@@ -390,7 +415,7 @@ class _MergingLevel(_LevelBase):
             self.fuse = SepConv(mod.fuse.conv_fuse)
         self.up = ConvexUp(mod.convex_upsample)
 
-    def merge_fuse_predict(self, vol, samples, prev_info, feat, resize_memory, mask=None):
+    def merge_fuse_predict(self, vol, samples, prev_info, feat, resize_memory, mask=None, next_range=None):
         B, C, D0, H, W = vol.shape
         K = self.topk
         memory = prev_info.get('cost_memory', None)
@@ -424,13 +449,15 @@ class _MergingLevel(_LevelBase):
         disp, _, _ = TF.topk_softargmax(cost, samp, off, k=self.topk)
         if callable(mask):
             mask = mask()                    # produced on another stream: the callable joins it
+        if next_range is not None:           # (range, leading candidate planes): upsample + next level's candidates, one launch
+            return self.up.with_candidates(feat, disp, mask, *next_range), cost, off, samp
         return self.up(feat, disp, mask), cost, off, samp
 
 
 class NativeCoarse(_MergingLevel):
-    def __call__(self, left, right, prev_info, mask=None):
+    def __call__(self, left, right, prev_info, mask=None, next_range=None):
         raw = TF.block_cost(left, right, int(self.mod.num_sample), self.scales)
-        return self.merge_fuse_predict(self.init3d(raw), None, prev_info, left, resize_memory=True, mask=mask)
+        return self.merge_fuse_predict(self.init3d(raw), None, prev_info, left, resize_memory=True, mask=mask, next_range=next_range)
 
 
 class NativeFine(_MergingLevel):
@@ -438,10 +465,10 @@ class NativeFine(_MergingLevel):
         super().__init__(mod)
         self.split_reference_half()
 
-    def __call__(self, left, right, ds, prev_info, mask=None, left_term=None):
+    def __call__(self, left, right, ds, prev_info, mask=None, left_term=None, next_range=None):
         raw = TF.block_cost_warped(left, right, ds, self.scales)
         lt = left_term() if callable(left_term) else (left_term if left_term is not None else self.left_term(left))
-        return self.merge_fuse_predict(self.init3d(raw, lt), ds, prev_info, left, resize_memory=False, mask=mask)
+        return self.merge_fuse_predict(self.init3d(raw, lt), ds, prev_info, left, resize_memory=False, mask=mask, next_range=next_range)
 
 
 class NativePrecise(_LevelBase):
@@ -538,10 +565,9 @@ class NativeAggregator:
     def _coarse_level(self, l16, r16, prev_info, out, mask=None):
         rng = 4
         disps, costs, offs, samples, ranges = out
-        d, c, o, s = self.coarse(_lib.contiguous(l16), _lib.contiguous(r16), prev_info, mask)
         lm = prev_info.get('local_map', None)                       # fine.py:89-93: local-map candidates go first
         nl = lm.shape[1] if (lm is not None and prev_info.get('local_map_size', 0) > 0) else 0
-        low, high, ds = range_candidates(d, rng, nl)
+        (d, low, high, ds), c, o, s = self.coarse(_lib.contiguous(l16), _lib.contiguous(r16), prev_info, mask, (rng, nl))
         if nl:
             resize_bilinear(lm, d.shape[-2:], d.shape[-1] / lm.shape[-1], out=ds[:, :nl])
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
@@ -550,8 +576,7 @@ class NativeAggregator:
     def _fine_level(self, l8, r8, ds, prev_info, out, mask=None, left_term=None):
         rng = 4
         disps, costs, offs, samples, ranges = out
-        d, c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, mask, left_term)
-        low, high, ds = range_candidates(d, rng)
+        (d, low, high, ds), c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, mask, left_term, (rng, 0))
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
 

@@ -21,9 +21,12 @@
 
 namespace {
 
-enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_TANH_OFFSET = 3 };
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_TANH_OFFSET = 3, ACT_HEAD_PAIR = 4 };
 
-__device__ __forceinline__ float apply_act(float v, int act, float p) {
+// co: output channel (only ACT_HEAD_PAIR looks at it: channel 0 = the cost head, no activation; channel 1 =
+// the offset head -- both prediction heads as one block-diagonal convolution)
+__device__ __forceinline__ float apply_act(float v, int act, float p, int co = 0) {
+  if (act == ACT_HEAD_PAIR) act = co == 0 ? ACT_NONE : ACT_TANH_OFFSET;
   switch (act) {
     case ACT_SILU: return v / (1.f + expf(-v));
     case ACT_RELU: return fmaxf(v, 0.f);
@@ -381,7 +384,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
         float v = acc[cb][pb][r];
         if (!split) {
           if (MODE == MODE_HW && ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * hw_o + (inside ? ppix : 0u)];
-          v = apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param);
+          v = apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param, co);
         }
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, off, 0, 0);
       }
@@ -403,7 +406,7 @@ conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ 
     float v = 0.f;
     for (int k = 0; k < ksplit; ++k) v += partial[k * n + i];
     if (addend) v += addend[b * add_bstride + co * hw_o + px % hw_o];
-    y[b * out_bstride + co * out_cstride + px] = apply_act(v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f), act, act_param);
+    y[b * out_bstride + co * out_cstride + px] = apply_act(v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f), act, act_param, co);
   }
 }
 
@@ -696,7 +699,7 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
   TS_REQUIRE(dilation == 1 || dilation == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: dilation must be 1 or 2");
   TS_REQUIRE(!(stride == 2 && dilation == 2), TS_ERR_UNSUPPORTED, "conv3d_hw: stride 2 with dilation 2");
   TS_REQUIRE(!transposed || (stride == 2 && dilation == 1), TS_ERR_UNSUPPORTED, "conv3d_hw: transposed form is stride 2, dilation 1");
-  TS_REQUIRE(act >= 0 && act <= 3, TS_ERR_SHAPE, "conv3d_hw: unknown activation");
+  TS_REQUIRE(act >= 0 && act <= 4, TS_ERR_SHAPE, "conv3d_hw: unknown activation");
   TS_REQUIRE(D <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw: grid too large");
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(y);
   const int bucket = cout_bucket(Cout);

@@ -65,6 +65,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_conv3d_d_bwd_data),       TS_PLAN_OP(ts_conv3d_d_bwd_weight),
     TS_PLAN_OP(ts_resize3d_add_act_fwd),    TS_PLAN_OP(ts_pool3d5_avgmax_fwd),
     TS_PLAN_OP(ts_merge_candidates_fwd),    TS_PLAN_OP(ts_convex_upsample_fwd),
+    TS_PLAN_OP(ts_convex_upsample_candidates_fwd),
     TS_PLAN_OP(ts_unet_upsample_fwd),       TS_PLAN_OP(ts_deconv2d_k4s2_fwd),
     TS_PLAN_OP(ts_resize_bilinear_fwd),     TS_PLAN_OP(ts_range_candidates_fwd),
     TS_PLAN_OP(ts_copy_rows_fwd),           TS_PLAN_OP(ts_stream_fork),

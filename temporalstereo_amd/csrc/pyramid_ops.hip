@@ -226,7 +226,8 @@ merge_candidates_kernel(const float* __restrict__ vol, const float* __restrict__
 // ConvexUpsample x r (r = 2): mask [B, 9*r*r, H, W] viewed (9, r, r); out [B,1,rH,rW]
 __global__ void __launch_bounds__(256)
 convex_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ disp, float* __restrict__ out,
-                       int B, int H, int W, int r, float disp_scale) {
+                       int B, int H, int W, int r, float disp_scale,
+                       float* __restrict__ low, float* __restrict__ high, float* __restrict__ cand, float range, int coff, int ctot) {
   const int HW = H * W, Ho = H * r, Wo = W * r;
   const long long n = static_cast<long long>(B) * Ho * Wo;
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
@@ -250,7 +251,20 @@ convex_upsample_kernel(const float* __restrict__ mask, const float* __restrict__
       const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? dv * disp_scale : 0.f;
       acc += e * v;
     }
-    out[i] = acc / den;
+    const float dup = acc / den;
+    out[i] = dup;
+    if (low) {      // the next level's search range and candidates in the same pass (see range_candidates_kernel)
+      const float lo = dup - range, hi = dup + range;
+      low[i] = lo; high[i] = hi;
+      const float span = fabsf(hi - lo), base = fminf(lo, hi);
+      const size_t HWo = static_cast<size_t>(Ho) * Wo;
+      float* c = cand + (static_cast<size_t>(b) * ctot + coff) * HWo + static_cast<size_t>(oy) * Wo + ox;
+      c[0] = span * 0.f + base;
+      c[HWo] = span * 0.375f + base;
+      c[2 * HWo] = span * 0.5f + base;
+      c[3 * HWo] = span * 0.625f + base;
+      c[4 * HWo] = span * 1.f + base;
+    }
   }
 }
 
@@ -569,7 +583,21 @@ extern "C" int ts_convex_upsample_fwd(const float* mask, const float* disp, floa
   TS_REQUIRE(B > 0 && H > 0 && W > 0 && factor >= 1, TS_ERR_SHAPE, "convex_upsample: bad size");
   TS_REQUIRE_PTR(mask); TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(out);
   hipLaunchKernelGGL(convex_upsample_kernel, dim3(grid_for(static_cast<long long>(B) * H * W * factor * factor, 256)), dim3(256), 0,
-                     ts::as_stream(stream), mask, disp, out, B, H, W, factor, disp_scale);
+                     ts::as_stream(stream), mask, disp, out, B, H, W, factor, disp_scale,
+                     static_cast<float*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0.f, 0, 0);
+  return ts::launched("convex_upsample_kernel");
+}
+
+// ts_convex_upsample_fwd followed by ts_range_candidates_fwd on its output, as one launch
+extern "C" int ts_convex_upsample_candidates_fwd(const float* mask, const float* disp, float* out, float* low, float* high,
+                                                 float* candidates, int B, int H, int W, int factor, float disp_scale,
+                                                 float range, int channel_offset, int channels_total, void* stream) {
+  TS_REQUIRE(B > 0 && H > 0 && W > 0 && factor >= 1, TS_ERR_SHAPE, "convex_upsample_candidates: bad size");
+  TS_REQUIRE(channel_offset >= 0 && channel_offset + 5 <= channels_total, TS_ERR_SHAPE, "convex_upsample_candidates: bad channel slice");
+  TS_REQUIRE_PTR(mask); TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(out); TS_REQUIRE_PTR(low); TS_REQUIRE_PTR(high); TS_REQUIRE_PTR(candidates);
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3(grid_for(static_cast<long long>(B) * H * W * factor * factor, 256)), dim3(256), 0,
+                     ts::as_stream(stream), mask, disp, out, B, H, W, factor, disp_scale, low, high, candidates, range,
+                     channel_offset, channels_total);
   return ts::launched("convex_upsample_kernel");
 }
 

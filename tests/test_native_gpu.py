@@ -177,6 +177,26 @@ def test_plan_replay_tracks_new_inputs_and_refuses_unknown_calls():
     L.ts_plan_destroy(p)
 
 
+def test_convex_upsample_with_candidates_equals_the_two_separate_kernels():
+    from temporalstereo_amd.aggregation import blocks, native
+    dev = _dev()
+    torch.manual_seed(3)
+    m = blocks.ConvexUpsample(16, upscale_factor=2, window_size=3).to(dev).eval()
+    up = native.ConvexUp(m)
+    feat = _rand(41, 2, 16, 17, 30, dev=dev)
+    disp = t(synth.uniform(42, "d", (2, 1, 17, 30), 0.0, 40.0), dev)
+    with torch.no_grad():
+        ref = m(feat, disp)
+    out = up(feat, disp)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    low, high, cand = native.range_candidates(out, 4.0, extra_front=2)
+    out2, low2, high2, cand2 = up.with_candidates(feat, disp, None, 4.0, extra_front=2)
+    assert torch.equal(out2, out) and torch.equal(low2, low) and torch.equal(high2, high)
+    assert torch.equal(cand2[:, 2:], cand[:, 2:])
+    want = torch.cat([(high - low).abs() * s + torch.min(low, high) for s in (0.0, 0.375, 0.5, 0.625, 1.0)], 1)   # fine.py:82-87
+    np.testing.assert_allclose(cand[:, 2:].cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------- end to end
 @pytest.mark.parametrize("name", ["agg_tiny_single", "agg_tiny_temporal"])
 @pytest.mark.parametrize("replay", ["eager", "graph", "plan"])

@@ -55,10 +55,10 @@ def k1_algorithmic_bytes(B, C, H, W, D, sampled):
     return 4 * B * H * W * (2 * C + (C + 3 * C // 8) * D)
 
 
-def build_model(dev, seed):
+def build_model(dev, seed, num_sample=None):
     import temporalstereo_amd as ts
     net = ts.TEMPORALSTEREO(
-        coarse=ts.CoarseAggregation(DIMS['coarse']['in_planes'], DIMS['coarse']['C'], DIMS['coarse']['num_sample']),
+        coarse=ts.CoarseAggregation(DIMS['coarse']['in_planes'], DIMS['coarse']['C'], num_sample or DIMS['coarse']['num_sample']),
         fine=ts.FineAggregation(DIMS['fine']['in_planes'], DIMS['fine']['C'], 5),
         precise=ts.PreciseAggregation(DIMS['precise']['in_planes'], DIMS['precise']['C'], 5))
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
@@ -67,10 +67,11 @@ def build_model(dev, seed):
     return net.to(dev)
 
 
-def make_inputs(dev, seed, B):
+def make_inputs(dev, seed, B, hw=None):
+    H, W = hw or (RUN_H, RUN_W)
     chans = (DIMS['precise']['in_planes'], DIMS['fine']['in_planes'], DIMS['coarse']['in_planes'])
-    lf, rf = synth.feature_pyramid(seed, B, RUN_H, RUN_W, chans=chans)
-    il, ir = synth.images(seed, B, RUN_H, RUN_W)
+    lf, rf = synth.feature_pyramid(seed, B, H, W, chans=chans)
+    il, ir = synth.images(seed, B, H, W)
     to = lambda a: torch.from_numpy(a).to(dev)
     return [to(x) for x in lf], [to(x) for x in rf], to(il), to(ir)
 

@@ -58,6 +58,11 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ row, int x, int 
 // before the (back-pressured) memory pipe has read them -- lanes 12-15 / 28-31 / ... of the stored
 // vector then carry the LDS data.  hipcc only pads VALU writers.  EXP_CNT covers the store's operand
 // read, so `s_waitcnt expcnt(0)` right after the store closes the window.
+// Second sighting (round 1, later): a buffer_store_dwordx4 WITH AN SGPR soffset immediately followed by a
+// v_mul that writes its first data register -- LLVM's hazard recognizer exempts exactly that form
+// (GCNHazardRecognizer: "only if the instruction is not using a register in the soffset field") and the
+// scheduler had hoisted the v_mul above a separate fence.  The buffer stores of bst4 therefore carry their
+// fence inside the same asm block; this helper remains for the plain global stores of st4.
 __device__ __forceinline__ void store_data_fence() { __builtin_amdgcn_s_waitcnt(0xcf0f); }   // expcnt(0) only
 
 template <bool VEC>
@@ -342,8 +347,14 @@ __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned eoff, un
   if constexpr (VEC) {
     u32x4 u;
     u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, eoff * 4u, uoff * 4u, 0);
-    store_data_fence();
+    // Store and fence are ONE asm block so that nothing can be scheduled between them: the registers of `u` are
+    // only free for reuse after the block (see store_data_fence -- hipcc had moved a v_mul that overwrites the
+    // first data register in front of the separate fence: element .x of one channel came out corrupted, and only
+    // for some batch sizes / candidate counts).  LLVM assumes a buffer store with an SGPR soffset has no
+    // store-data hazard at all and pads nothing here.
+    const unsigned vo = eoff * 4u, so = uoff * 4u;
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1\n\ts_waitcnt expcnt(0)"
+                 : : "v"(u), "v"(vo), "s"(r), "s"(so) : "memory");
   } else {
     if (x + 0 < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), r, eoff * 4u, uoff * 4u, 0);
     if (x + 1 < W) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), r, eoff * 4u + 4u, uoff * 4u, 0);

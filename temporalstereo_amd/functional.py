@@ -357,6 +357,8 @@ class _Pool5AvgMax(torch.autograd.Function):
         _require_gpu(x)
         x = x.contiguous()
         B, C, D, H, W = x.shape
+        if min(D, H, W) < 5:      # what F.avg_pool3d(kernel 5) answers, padding or not (PyramidFusion, module.py:416)
+            raise RuntimeError("input image (T: %d H: %d W: %d) smaller than kernel size (kT: 5 kH: 5 kW: 5)" % (D, H, W))
         avg, mx = torch.empty_like(x), torch.empty_like(x)
         n = D * H * W
         rc = _lib.lib().ts_pool3d5_avgmax_fwd(_lib.ptr(x), _lib.ptr(avg), _lib.ptr(mx), B, C, D, H, W,

@@ -1,0 +1,149 @@
+"""GPU: seeded random-shape sweep of the cost-volume kernels (block_cost int / sampled / warped, cat_fms, dif_fms)
+against the oracle: batch 1-3, 8-128 channels, ragged and aligned widths up to 320, 2-12 candidates, 1-3 scales.
+This is the kind of sweep that exposed the store-data hazard of DESIGN.md section 7 (one channel, element .x, only
+for batch >= 2 with 7-8 candidates).  Each op is run twice: the hazards seen so far were timing dependent.
+
+dif_fms thresholds the interpolated value at > 0 (dif_fms.py:40): an element whose warped value is ~1e-7 may fall
+on the other side in two fp32 implementations and then holds the fill value instead of the difference.  Those
+(measure-zero) elements are excluded; everything else must agree to 2e-3 absolute (values are O(1..10))."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cost_volume_kernels_random_shapes():
+    import oracle
+    import oracle.cost_volume as ocv
+    import temporalstereo_amd as ts
+    from temporalstereo_amd import functional as TF
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(20260928)
+    for it in range(28):
+        B = int(rng.choice([1, 2, 3])); C = int(rng.choice([8, 16, 32, 64, 128])); H = int(rng.randint(4, 48))
+        W = int(rng.choice([rng.randint(4, 130), 4 * rng.randint(1, 80)]))
+        D = int(rng.randint(2, 13)); sc = int(rng.choice([1, 2, 3]))
+        l = torch.from_numpy(synth.normal(500 + it, "l", (B, C, H, W))); r = torch.from_numpy(synth.normal(500 + it, "r", (B, C, H, W)))
+        d = torch.from_numpy(synth.uniform(500 + it, "d", (B, D, H, W), -3.0, W * 0.6))
+        lg, rg, dg = l.to(dev), r.to(dev), d.to(dev)
+        tag = "case %d %s" % (it, (B, C, H, W, D, sc))
+        exp = oracle.block_cost(l, r, d, sc)
+        for _ in range(2):
+            np.testing.assert_allclose(ts.block_cost(lg, rg, dg, sc).cpu().numpy(), exp.numpy(), rtol=0, atol=2e-3, err_msg=tag + " sampled")
+            np.testing.assert_allclose(TF.block_cost_warped(lg, rg, dg, sc).cpu().numpy(), exp[:, C:].numpy(), rtol=0, atol=2e-3, err_msg=tag + " warped")
+        np.testing.assert_allclose(ts.block_cost(lg, rg, D, sc).cpu().numpy(), oracle.block_cost(l, r, D, sc).numpy(), rtol=0, atol=2e-3, err_msg=tag + " int")
+        np.testing.assert_allclose(ts.cat_fms(lg, rg, dg).cpu().numpy(), ocv.cat_fms(l, r, d).numpy(), rtol=0, atol=2e-3, err_msg=tag + " cat")
+        tgt = ocv.warp_candidates(r, d)
+        got, want = ts.dif_fms(lg, rg, dg).cpu(), ocv.dif_fms(l, r, d)
+        off = ((got - want).abs() > 2e-3) & (tgt.abs() > 1e-5)
+        assert int(off.sum()) == 0, tag + " dif: %d elements differ away from the threshold" % int(off.sum())
+        assert int((((got - want).abs() > 2e-3)).sum()) <= 4, tag + " dif: too many threshold flips"
+
+
+def _rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+
+
+def test_convolution_kernels_random_shapes():
+    """Forward (folded scale/shift/activation form), backward-data and backward-weight of both families on random
+    geometries -- ragged channel counts, 1-pixel images, odd sizes under stride 2, every K-chunk cap -- against the
+    framework's conv3d / conv_transpose3d autograd."""
+    import torch.nn.functional as F
+    from temporalstereo_amd import _lib
+    from temporalstereo_amd import functional as TF
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(77)
+    try:
+        for it in range(36):
+            cap = int(rng.choice([8, 16, 32]))
+            _lib.check(_lib.lib().ts_conv_set_chunk_cap(cap), "cap")
+            B = int(rng.choice([1, 2])); cin = int(rng.choice([1, 3, 8, 13, 32, 70, 176])); cout = int(rng.choice([1, 2, 8, 24, 32, 64]))
+            D = int(rng.randint(1, 8)); H = int(rng.randint(1, 40)); W = int(rng.randint(1, 75))
+            fam = rng.choice(["hw", "d", "hwT", "dT"])
+            x = torch.from_numpy(synth.normal(900 + it, "x", (B, cin, D, H, W))).to(dev)
+            if fam == "hw":
+                s, dl = [(1, 1), (2, 1), (1, 2)][rng.randint(3)]
+                w = torch.from_numpy(synth.normal(900 + it, "w", (cout, cin, 1, 3, 3), 0.2)).to(dev)
+                args = ((1, s, s), (0, dl, dl), (1, dl, dl))
+                ours = lambda a, b: TF.conv3d(a, b, None, *args); ref = lambda a, b: F.conv3d(a, b, None, *args)
+            elif fam == "d":
+                k = int(rng.choice([1, 3, 5])); s = int(rng.choice([1, 2])) if k == 3 else 1
+                dl = 1 if s == 2 else int(rng.choice([1, 2])); pad = 1 if s == 2 else int(rng.choice([0, dl * (k - 1) // 2]))
+                if D + 2 * pad - dl * (k - 1) < 1:
+                    continue
+                w = torch.from_numpy(synth.normal(900 + it, "w", (cout, cin, k, 1, 1), 0.2)).to(dev)
+                args = ((s, 1, 1), (pad, 0, 0), (dl, 1, 1))
+                ours = lambda a, b: TF.conv3d(a, b, None, *args); ref = lambda a, b: F.conv3d(a, b, None, *args)
+            elif fam == "hwT":
+                cin = min(cin, 64)
+                x = x[:, :cin].contiguous()
+                w = torch.from_numpy(synth.normal(900 + it, "w", (cin, cout, 1, 3, 3), 0.2)).to(dev)
+                args = ((1, 2, 2), (0, 1, 1), (0, 1, 1))
+                ours = lambda a, b: TF.conv_transpose3d(a, b, None, *args); ref = lambda a, b: F.conv_transpose3d(a, b, None, *args)
+            else:
+                cin = min(cin, 64)
+                x = x[:, :cin].contiguous()
+                w = torch.from_numpy(synth.normal(900 + it, "w", (cin, cout, 3, 1, 1), 0.2)).to(dev)
+                args = ((2, 1, 1), (1, 0, 0), (1, 0, 0))
+                ours = lambda a, b: TF.conv_transpose3d(a, b, None, *args); ref = lambda a, b: F.conv_transpose3d(a, b, None, *args)
+            tag = "case %d %s cin %d cout %d %s cap %d" % (it, fam, cin, cout, (B, D, H, W), cap)
+            x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y1, y2 = ours(x1, w1), ref(x2, w2)
+            assert y1.shape == y2.shape, tag
+            assert _rel_err(y1, y2) < 3e-4, tag + " forward %.2e" % _rel_err(y1, y2)
+            g = torch.from_numpy(synth.normal(900 + it, "g", tuple(y2.shape))).to(dev)
+            y1.backward(g); y2.backward(g)
+            assert _rel_err(x1.grad, x2.grad) < 3e-4, tag + " grad input %.2e" % _rel_err(x1.grad, x2.grad)
+            assert _rel_err(w1.grad, w2.grad) < 3e-4, tag + " grad weight %.2e" % _rel_err(w1.grad, w2.grad)
+    finally:
+        _lib.check(_lib.lib().ts_conv_set_chunk_cap(32), "cap")
+
+
+def test_element_stage_kernels_random_shapes():
+    """resize+add+SiLU, 5^3 avg/max pooling and stable sort+gather (forward and backward) on random sizes, including
+    non-matching up-sampling ratios and planes smaller than the pooling window (refused, like the framework's)."""
+    import torch.nn.functional as F
+    from temporalstereo_amd import functional as TF
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(123)
+    for it in range(16):
+        B, C = int(rng.choice([1, 2])), int(rng.choice([1, 5, 16]))
+        D, H, W = int(rng.randint(1, 15)), int(rng.randint(1, 40)), int(rng.randint(1, 70))
+        Da, Ha, Wa = max(1, D - int(rng.randint(0, 3))), int(rng.randint(1, H + 3)), int(rng.randint(1, W + 3))
+        tag = "case %d %s <- %s" % (it, (B, C, D, H, W), (Da, Ha, Wa))
+        a = torch.from_numpy(synth.normal(700 + it, "a", (B, C, Da, Ha, Wa))).to(dev)
+        b = torch.from_numpy(synth.normal(700 + it, "b", (B, C, D, H, W))).to(dev)
+        a1, b1, a2, b2 = (v.clone().requires_grad_(True) for v in (a, b, a, b))
+        y1 = TF.resize_add_silu(a1, b1)
+        y2 = F.silu(F.interpolate(a2, size=(D, H, W), mode="trilinear", align_corners=True) + b2)
+        g = torch.from_numpy(synth.normal(700 + it, "g", (B, C, D, H, W))).to(dev)
+        y1.backward(g); y2.backward(g)
+        assert _rel_err(y1, y2) < 1e-4 and _rel_err(a1.grad, a2.grad) < 3e-4 and _rel_err(b1.grad, b2.grad) < 1e-4, tag + " resize"
+        if min(D, H, W) < 5:       # F.avg_pool3d refuses planes smaller than its window, and so does ours
+            with pytest.raises(RuntimeError, match="smaller than kernel size"):
+                TF.pool5_avgmax(b)
+            continue
+        x1, x2 = b.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        av1, mx1 = TF.pool5_avgmax(x1)
+        av2, mx2 = F.avg_pool3d(x2, 5, 1, 2), F.max_pool3d(x2, 5, 1, 2)
+        (av1 * g + mx1 * g.flip(-1)).sum().backward(); (av2 * g + mx2 * g.flip(-1)).sum().backward()
+        assert _rel_err(av1, av2) < 1e-5 and torch.equal(mx1, mx2) and _rel_err(x1.grad, x2.grad) < 3e-4, tag + " pool"
+        DT = int(rng.randint(2, 15))
+        vol = torch.from_numpy(synth.normal(700 + it, "v", (B, C, DT, H, W))).to(dev)
+        smp = torch.from_numpy(np.round(synth.uniform(700 + it, "s", (B, DT, H, W), 0.0, 6.0))).to(dev)      # many ties
+        v1, s1, v2, s2 = (t.clone().requires_grad_(True) for t in (vol, smp, vol, smp))
+        ov1, os1 = TF.sort_gather(v1, s1)
+        os2, order = torch.sort(s2, dim=1, stable=True)
+        ov2 = torch.gather(v2, 2, order.unsqueeze(1).expand(-1, C, -1, -1, -1))
+        assert torch.equal(ov1, ov2) and torch.equal(os1, os2), tag + " sort"
+        gv = torch.from_numpy(synth.normal(700 + it, "gv", tuple(vol.shape))).to(dev)
+        (ov1 * gv).sum().backward(); (ov2 * gv).sum().backward()
+        assert torch.equal(v1.grad, v2.grad), tag + " sort backward"

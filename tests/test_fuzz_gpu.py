@@ -147,3 +147,46 @@ def test_element_stage_kernels_random_shapes():
         gv = torch.from_numpy(synth.normal(700 + it, "gv", tuple(vol.shape))).to(dev)
         (ov1 * gv).sum().backward(); (ov2 * gv).sum().backward()
         assert torch.equal(v1.grad, v2.grad), tag + " sort backward"
+
+
+def test_native_engine_random_geometries_and_temporal_states():
+    """The all-HIP engine (folded BatchNorm, fused kernels, launch-plan replay, three streams) against the nn.Module
+    path on random image sizes (odd quotients at 1/16, 1/8, 1/4), batch 1-3, with and without a temporal state
+    carrying 0-3 local maps.  Criterion: bulk agreement (median) and rarity of flipped pixels -- see
+    tests/test_fullsize_gpu.py for why the mean alone is not a robust statistic on random-weight networks."""
+    import bench
+    import temporalstereo_amd as ts
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(4242)
+    dims = dict(coarse=dict(in_planes=32, C=8, num_sample=4), fine=dict(in_planes=16, C=8), precise=dict(in_planes=8, C=8))
+    for it in range(6):
+        B = int(rng.choice([1, 2, 3])); H = 16 * int(rng.randint(5, 12)); W = 16 * int(rng.randint(5, 16)); ns = int(rng.choice([3, 4, 6]))
+        nl = int(rng.randint(0, 4)); temporal = bool(it % 2)
+        seed = 3000 + it
+        net = ts.TEMPORALSTEREO(coarse=ts.CoarseAggregation(32, 8, ns), fine=ts.FineAggregation(16, 8, 5), precise=ts.PreciseAggregation(8, 8, 5))
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_values(shapes, seed).items()}, strict=True)
+        net = net.to(dev)
+        lf, rf = synth.feature_pyramid(seed, B, H, W, chans=(8, 16, 32))
+        il, ir = synth.images(seed, B, H, W)
+        inputs = ([torch.from_numpy(x).to(dev) for x in lf], [torch.from_numpy(x).to(dev) for x in rf], torch.from_numpy(il).to(dev), torch.from_numpy(ir).to(dev))
+        bench.calibrate_batchnorm(net, inputs)
+        prev = {}
+        if temporal:
+            with torch.no_grad():
+                first = net(*inputs, {})
+            prev = {"cost_memory": {k: v.clone() for k, v in first[5]["cost_memory"].items()}, "use_past_cost": True}
+            if nl:
+                lm = torch.nn.functional.interpolate(first[0][0], size=(H // 8, W // 8), mode="bilinear", align_corners=True) / 8.0
+                prev.update(local_map=torch.cat([lm + 0.6 * k for k in range(nl)], 1).contiguous(), local_map_size=nl)
+        with torch.no_grad():
+            ref = net(*inputs, dict(prev))
+        got = InferenceEngine(net, backend="native", replay="plan")(*inputs, dict(prev))
+        tag = "case %d B=%d %dx%d samples=%d temporal=%s local=%d" % (it, B, H, W, ns, temporal, nl)
+        assert [tuple(c.shape) for c in got[1]] == [tuple(c.shape) for c in ref[1]], tag
+        for i in range(4):
+            diff = (got[0][i] - ref[0][i]).abs() * (W / ref[0][i].shape[-1])
+            med, far = float(diff.median()), float((diff > 0.1).double().mean())
+            assert med < 2e-3 and far < 0.02, tag + " disparity %d: median %.3g px, %.2f%% beyond 0.1 px" % (i, med, 100 * far)

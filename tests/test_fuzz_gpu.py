@@ -190,3 +190,39 @@ def test_native_engine_random_geometries_and_temporal_states():
             diff = (got[0][i] - ref[0][i]).abs() * (W / ref[0][i].shape[-1])
             med, far = float(diff.median()), float((diff > 0.1).double().mean())
             assert med < 2e-3 and far < 0.02, tag + " disparity %d: median %.3g px, %.2f%% beyond 0.1 px" % (i, med, 100 * far)
+
+
+def test_regression_and_splat_kernels_random_shapes():
+    """top-k soft-argmax (k = 1..4), full soft-argmin / argmin over D up to 192, and the four splat modes on random
+    sizes against the oracle."""
+    import oracle.regress as oreg
+    import oracle.splat as osp
+    import temporalstereo_amd as ts
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(31337)
+    for it in range(14):
+        B = int(rng.choice([1, 2, 3])); D = int(rng.choice([2, 5, 7, 14, 20, 48, 192])); H = int(rng.randint(1, 40)); W = int(rng.randint(1, 70))
+        cost = torch.from_numpy(synth.normal(1100 + it, "c", (B, D, H, W), 2.0))
+        samp = torch.from_numpy(np.sort(synth.uniform(1100 + it, "s", (B, D, H, W), 0.0, 60.0), axis=1))
+        off = torch.from_numpy(synth.uniform(1100 + it, "o", (B, D, H, W), -1.0, 1.0))
+        tag = "case %d %s" % (it, (B, D, H, W))
+        if D <= 20:
+            k = int(rng.randint(1, min(D, 4) + 1))
+            got = ts.topk_softargmax(cost.to(dev), samp.to(dev), off.to(dev), k=k)
+            want = oreg.topk_softargmax(cost, samp, off, k=k)
+            for g, w_, nm in zip(got, want, ("disp", "topk_disp", "topk_cost")):
+                np.testing.assert_allclose(g.cpu().numpy(), w_.numpy(), rtol=1e-5, atol=2e-4, err_msg=tag + " topk k=%d %s" % (k, nm))
+        for temp in (1.0, 2.5):
+            got = ts.soft_argmin(cost.to(dev), samp.to(dev), temperature=temp, normalize=True)
+            np.testing.assert_allclose(got.cpu().numpy(), oreg.soft_argmin(cost, samp, temp, True).numpy(), rtol=1e-5, atol=2e-4, err_msg=tag + " soft_argmin")
+        np.testing.assert_allclose(ts.argmin_select(cost.to(dev), samp.to(dev)).cpu().numpy(), oreg.argmin_select(cost, samp).numpy(), rtol=0, atol=0,
+                                   err_msg=tag + " argmin")
+        C = int(rng.choice([1, 2, 5]))
+        inp = torch.from_numpy(synth.normal(1100 + it, "i", (B, C, H, W)))
+        flow = torch.from_numpy(synth.normal(1100 + it, "f", (B, 2, H, W), 3.0))
+        met = torch.from_numpy(synth.normal(1100 + it, "m", (B, 1, H, W)))
+        for mode in ("summation", "average", "linear", "softmax"):
+            m = None if mode == "summation" else (met.abs() + 0.1 if mode == "linear" else met)
+            got = ts.FunctionSoftsplat(inp.to(dev), flow.to(dev), None if m is None else m.to(dev), mode)
+            np.testing.assert_allclose(got.cpu().numpy(), osp.softsplat(inp, flow, m, mode).numpy(), rtol=1e-4, atol=1e-4, err_msg=tag + " splat " + mode)

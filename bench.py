@@ -218,13 +218,20 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    # test hooks for boxes with fewer GPUs than ranks: TS_BENCH_DEVICE pins every rank to one device and
+    # TS_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); the driver sets neither
+    local = int(os.environ.get("TS_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("TS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     seed = synth.SEED0 + 2                      # config index 2
     net = build_model(dev, seed)

@@ -142,6 +142,28 @@ int ts_project_to_3d_fwd(const float* depth, const float* K, const float* inv_K,
                          float* triangular_depth, float* optical_flow, unsigned char* flow_mask,
                          int B, int C, int H, int W, int k_dim, int inv_k_dim, float eps, void* stream);
 
+/* K2c  the temporal state update of one frame, fused: update_map's closures update_local_map and
+ * update_past_cost, projects/TemporalStereo/TemporalStereo.py:340-384 / :386-426, three launches.
+ *   prev_disp  full-resolution disparity of the previous frame, [B,1,full_h,full_w] (disp_bstride elements
+ *              between batch items); resized to (h,w) with value scale w/full_w  (:357-359)
+ *   mem_disp / mem_cost [B,k,h,w]  top-k candidates and costs kept from the previous frame (k may be 0)
+ *   local_map [B,n_local_in,h,w]   previous local maps (may be NULL when n_local_out <= 1);
+ *              planes re-projected = [resized prev_disp | local_map][: n_local_out]      (:365-367)
+ *   K [B,k_dim,k_dim] full-resolution intrinsics (rows 0,1 divided by `factor` = full_w / w inside; when 4x4 the
+ *              last row must be 0 0 0 1); T = T_a * T_b (T_b NULL: T = T_a), [B,4,4]     (:333-338)
+ *   baseline   per-item array [B] or NULL -> the scalar `baseline`
+ *   out_disp / out_cost [B,k,h,w], out_local [B,n_local_out,h,w]: soft-max splat with metric
+ *              clamp(d - mean(d), +-50) of the resized disparity (global mean, :374)     (:373-379, :415-419)
+ * fp32 atomics in the splat: summation order not deterministic (as the reference's atomicAdd). */
+size_t ts_reproject_memory_workspace_bytes(int B, int h, int w, int k, int n_local_out);
+int ts_reproject_memory_fwd(const float* prev_disp, long long disp_bstride, int full_h, int full_w,
+                            const float* mem_disp, const float* mem_cost, int k,
+                            const float* local_map, int n_local_in, int n_local_out,
+                            const float* K, int k_dim, const float* T_a, const float* T_b,
+                            const float* baseline_ptr, float baseline, float factor,
+                            float* out_disp, float* out_cost, float* out_local, void* workspace,
+                            int B, int h, int w, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * K3  3-D aggregation pyramid, inference form (BatchNorm folded into per-channel scale/shift,
  * activation fused: act 0 none, 1 SiLU, 2 ReLU, 3 tanh(x/100).clamp(-1,1)*act_param, 4 = channel 0 none and

@@ -65,6 +65,10 @@ SIGNATURES = {
     "ts_resize_bilinear_fwd": (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_float, ctypes.c_longlong, c_ptr]),
     "ts_range_candidates_fwd": (c_int, [c_f32p] * 4 + [c_int] * 3 + [c_float, c_int, c_int, c_ptr]),
     "ts_project_to_3d_fwd": (c_int, [c_f32p] * 7 + [c_int] * 6 + [c_float, c_ptr]),
+    "ts_reproject_memory_workspace_bytes": (c_size, [c_int] * 5),
+    "ts_reproject_memory_fwd": (c_int, [c_f32p, ctypes.c_longlong, c_int, c_int, c_f32p, c_f32p, c_int, c_f32p, c_int, c_int,
+                                        c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_float, c_float, c_f32p, c_f32p, c_f32p,
+                                        c_ptr, c_int, c_int, c_int, c_ptr]),
     "ts_resize3d_add_act_bwd": (c_int, [c_f32p] * 5 + [c_int] * 9 + [c_ptr]),
     "ts_pool3d5_avgmax_bwd": (c_int, [c_f32p] * 4 + [c_int] * 5 + [c_ptr]),
     "ts_merge_candidates_bwd": (c_int, [c_f32p] * 5 + [c_int] * 5 + [c_ptr]),

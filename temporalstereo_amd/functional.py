@@ -638,6 +638,57 @@ def FunctionSoftsplat(tenInput, tenFlow, tenMetric, strType, deterministic=False
     return out
 
 
+def reproject_memory(prev_disp, mem_disp, mem_cost, local_map, n_local_out, K, T_a, T_b, baseline, factor, h, w):
+    """The fused temporal state update (ts_reproject_memory_fwd): what update_past_cost and update_local_map of
+    the reference (projects/TemporalStereo/TemporalStereo.py:386-426, :340-384) compute together, three launches.
+
+    prev_disp [B,1,H,W]; mem_disp/mem_cost [B,k,h,w] or None; local_map [B,n,h,w] or None; K [B,3|4,3|4] full-
+    resolution intrinsics; T = T_a @ T_b (T_b may be None); baseline scalar or tensor with B elements.
+    Returns (moved mem_disp, moved mem_cost, moved local map), None where not requested."""
+    _require_gpu(prev_disp, K, T_a)
+    if prev_disp.dim() != 4 or prev_disp.shape[1] != 1:
+        raise RuntimeError("reproject_memory: prev_disp must be [B,1,H,W], got %s" % (tuple(prev_disp.shape),))
+    B, _, Hf, Wf = prev_disp.shape
+    dev = prev_disp.device
+    prev_disp = _lib.contiguous(prev_disp)
+    k = 0
+    if mem_disp is not None:
+        mem_disp, mem_cost = _lib.contiguous(mem_disp), _lib.contiguous(mem_cost)
+        k = mem_disp.shape[1]
+        if tuple(mem_disp.shape) != (B, k, h, w) or mem_cost.shape != mem_disp.shape:
+            raise RuntimeError("reproject_memory: memory shapes %s / %s, expected [%d,k,%d,%d]"
+                               % (tuple(mem_disp.shape), tuple(mem_cost.shape), B, h, w))
+    n_in = 0
+    if local_map is not None:
+        local_map = _lib.contiguous(local_map)
+        n_in = local_map.shape[1]
+        if tuple(local_map.shape) != (B, n_in, h, w):
+            raise RuntimeError("reproject_memory: local map %s, expected [%d,n,%d,%d]" % (tuple(local_map.shape), B, h, w))
+    n_local_out = min(int(n_local_out), n_in + 1)
+    K, T_a = _lib.contiguous(K), _lib.contiguous(T_a)
+    T_b = None if T_b is None else _lib.contiguous(T_b)
+    base_t, base_s = None, 0.0
+    if torch.is_tensor(baseline):
+        if baseline.numel() == 1 and baseline.device.type == 'cpu':
+            base_s = float(baseline)
+        else:
+            base_t = _lib.contiguous(baseline.to(device=dev, dtype=torch.float32).reshape(-1).expand(B))
+    else:
+        base_s = float(baseline)
+    f32 = dict(device=dev, dtype=torch.float32)
+    out_d = torch.empty((B, k, h, w), **f32) if k else None
+    out_c = torch.empty((B, k, h, w), **f32) if k else None
+    out_l = torch.empty((B, n_local_out, h, w), **f32) if n_local_out else None
+    L = _lib.lib()
+    ws = torch.empty(L.ts_reproject_memory_workspace_bytes(B, h, w, k, n_local_out), device=dev, dtype=torch.uint8)
+    opt = lambda t: None if t is None else _lib.ptr(t)
+    _lib.check(L.ts_reproject_memory_fwd(_lib.ptr(prev_disp), prev_disp.stride(0), Hf, Wf, opt(mem_disp), opt(mem_cost), k,
+                                         opt(local_map), n_in, n_local_out, _lib.ptr(K), K.shape[-1], _lib.ptr(T_a), opt(T_b),
+                                         opt(base_t), base_s, float(factor), opt(out_d), opt(out_c), opt(out_l),
+                                         _lib.ptr(ws), B, h, w, _stream()), "ts_reproject_memory_fwd")
+    return out_d, out_c, out_l
+
+
 def project_to_3d(depth, K, inv_K=None, T_target_to_source=None, eps=1e-7):
     """project_to_3d of the reference (layers/inverse_warp.py:92-178), forward only (the project
     calls it on detached tensors).  Returns triangular_depth / optical_flow / flow_mask /

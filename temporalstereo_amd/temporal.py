@@ -4,61 +4,42 @@ Own counterpart of the `update_map` method of the reference's LightningModule
 (projects/TemporalStereo/TemporalStereo.py:326-461; closures update_local_map :340-384 and
 update_past_cost :386-426): the previous frame's disparity gives a rigid flow (pose + depth), the
 top-k (disparity candidate, cost) memory and the local disparity map are re-projected into the
-current frame and forward-splatted with softmax weighting.  Re-projection and splat run on the HIP
-kernels (functional.project_to_3d, functional.FunctionSoftsplat); the remaining glue is a handful of
-bilinear resizes of 1/8-resolution maps.
+current frame and forward-splatted with softmax weighting.
+
+The whole update is ONE native call (functional.reproject_memory -> ts_reproject_memory_fwd, three
+launches): resize of the previous disparity, scaled intrinsics and their inverse, pose composition,
+re-projection of every plane and the shared soft-max splat.  Issued op by op (the reference's ~60
+framework calls; this module's first version used ~25) the update is host-bound at ~0.75 ms per frame
+on MI355X -- half an aggregation pass; fused it is ~0.05 ms.
 """
 import torch
-import torch.nn.functional as F
 
 from . import functional as TF
 
-EXPMAX = 50          # clamp of the splat metric, projects/TemporalStereo/TemporalStereo.py:5
+EXPMAX = 50          # clamp of the splat metric, projects/TemporalStereo/TemporalStereo.py:5 (baked into the kernel)
 
 
-def _scaled_intrinsics(K, factor):
-    down_K = torch.cat((K[:, 0:1, :] / factor, K[:, 1:2, :] / factor, K[:, 2:, :]), dim=1)
-    return down_K, torch.inverse(down_K), down_K[:, 0, 0].view(-1, 1, 1, 1)
-
-
-def _resize_disp(disp, h, w):
-    return F.interpolate(disp * w / disp.shape[-1], size=(h, w), mode='bilinear', align_corners=True)
-
-
-def _metric(prev_disp):
-    return (prev_disp[:, :1] - prev_disp[:, :1].mean()).clamp(-EXPMAX, EXPMAX)
+def _local_hw(local_map, full_h, full_w):
+    if local_map is not None:
+        return tuple(local_map.shape[-2:])
+    return full_h // 8, full_w // 8                 # :343-347
 
 
 @torch.no_grad()
-def update_past_cost(prev_disp, memory, K, T_past_to_now, baseline, full_w):
+def update_past_cost(prev_disp, memory, K, T_past_to_now, baseline, full_w, T_b=None):
     """:386-426 -> {'disp_sample','cost_volume'} warped into the current frame (detached)."""
     ds, cv = memory['disp_sample'].detach(), memory['cost_volume'].detach()
-    k, h, w = ds.shape[1:]
-    down_K, down_inv_K, f = _scaled_intrinsics(K, full_w / w)
-    pd = _resize_disp(prev_disp, h, w)
-    flow = TF.project_to_3d(baseline * f / (pd + 1e-5), down_K, down_inv_K, T_past_to_now)['optical_flow'][:, :2]
-    moved = TF.project_to_3d(baseline * f / (ds + 1e-5), down_K, down_inv_K, T_past_to_now)['triangular_depth']
-    moved_ds = baseline * f / (moved + 1e-5)
-    warped = TF.FunctionSoftsplat(torch.cat([moved_ds, cv], dim=1), flow.contiguous(), _metric(pd), 'softmax')
-    return {'disp_sample': warped[:, :k].contiguous(), 'cost_volume': warped[:, k:].contiguous()}
+    h, w = ds.shape[-2:]
+    out_d, out_c, _ = TF.reproject_memory(prev_disp, ds, cv, None, 0, K, T_past_to_now, T_b, baseline, full_w / w, h, w)
+    return {'disp_sample': out_d, 'cost_volume': out_c}
 
 
 @torch.no_grad()
-def update_local_map(prev_disp, local_map, K, T_past_to_now, baseline, full_h, full_w, local_map_size):
+def update_local_map(prev_disp, local_map, K, T_past_to_now, baseline, full_h, full_w, local_map_size, T_b=None):
     """:340-384 -> local disparity map [B, <=local_map_size, h, w] in the current frame (detached)."""
-    if local_map is not None:
-        h, w = local_map.shape[-2:]
-    else:
-        h, w = full_h // 8, full_w // 8
-    down_K, down_inv_K, f = _scaled_intrinsics(K, full_w / w)
-    pd = _resize_disp(prev_disp, h, w)
-    if local_map is None:
-        planes = pd
-    else:
-        planes = torch.cat([pd, local_map], dim=1)[:, :local_map_size]
-    proj = TF.project_to_3d(baseline * f / (planes + 1e-5), down_K, down_inv_K, T_past_to_now)
-    moved = baseline * f / (proj['triangular_depth'] + 1e-5)
-    return TF.FunctionSoftsplat(moved, proj['optical_flow'][:, :2].contiguous(), _metric(pd), 'softmax')
+    h, w = _local_hw(local_map, full_h, full_w)
+    n_out = 1 if local_map is None else local_map_size
+    return TF.reproject_memory(prev_disp, None, None, local_map, n_out, K, T_past_to_now, T_b, baseline, full_w / w, h, w)[2]
 
 
 @torch.no_grad()
@@ -67,19 +48,35 @@ def update_map(prev_info, K, T_now, inv_T_past, baseline, full_h, full_w, use_pa
 
     K [B,4,4] full-resolution intrinsics; T_now / inv_T_past [B,4,4]; baseline [B,1,1,1] or scalar.
     """
-    T_past_to_now = prev_info.get('T_past_to_now', None)
-    if T_past_to_now is None:
-        T_past_to_now = torch.bmm(T_now, inv_T_past)
+    T_a, T_b = prev_info.get('T_past_to_now', None), None
+    if T_a is None:
+        T_a, T_b = T_now, inv_T_past                # composed inside the kernel (:333-338)
     prev_disp = prev_info['prev_disp'].detach()
     memory = prev_info.get('cost_memory', None)
-    if use_past_cost and memory is not None:
-        memory = update_past_cost(prev_disp, memory, K, T_past_to_now, baseline, full_w)
-    elif not use_past_cost:
+    move_memory = use_past_cost and memory is not None
+    local_map = prev_info.get('local_map', None)
+    if local_map is not None:
+        local_map = local_map.detach()
+    same_grid = move_memory and local_map_size > 0 and \
+        tuple(memory['disp_sample'].shape[-2:]) == _local_hw(local_map, full_h, full_w)
+    if same_grid:                                   # the normal case: both live on the 1/8 grid -> one call
+        ds, cv = memory['disp_sample'].detach(), memory['cost_volume'].detach()
+        h, w = ds.shape[-2:]
+        n_out = 1 if local_map is None else local_map_size
+        out_d, out_c, out_l = TF.reproject_memory(prev_disp, ds, cv, local_map, n_out, K, T_a, T_b, baseline,
+                                                  full_w / w, h, w)
+        memory = {'disp_sample': out_d, 'cost_volume': out_c}
+        prev_info['local_map'] = out_l
+    else:
+        if move_memory:
+            memory = update_past_cost(prev_disp, memory, K, T_a, baseline, full_w, T_b)
+        if local_map_size > 0:
+            prev_info['local_map'] = update_local_map(prev_disp, local_map, K, T_a, baseline, full_h, full_w,
+                                                      local_map_size, T_b)
+    if not use_past_cost:
         memory = None
     prev_info['cost_memory'] = memory
     prev_info['use_past_cost'] = use_past_cost
     if local_map_size > 0:
-        prev_info['local_map'] = update_local_map(prev_disp, prev_info.get('local_map', None), K, T_past_to_now,
-                                                  baseline, full_h, full_w, local_map_size)
         prev_info['local_map_size'] = local_map_size
     return prev_info

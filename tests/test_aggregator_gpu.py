@@ -116,3 +116,68 @@ def test_temporal_update_vs_oracle():
         assert epe(a, b) < 1e-4 and float((a - b).abs().max()) < 5e-2
     assert got['local_map'].shape == ref['local_map'].shape == (B, 3, h, w)
     assert epe(got['local_map'].cpu(), ref['local_map']) < 1e-4
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_temporal_update_fuzz_vs_oracle(case):
+    """The fused update (ts_reproject_memory_fwd) against the oracle's op-by-op restatement over odd sizes,
+    larger motions (taps leaving the frame), absent memory / local maps, per-item baselines, 3x3 intrinsics,
+    a pre-composed pose and local_map_size cropping."""
+    import temporalstereo_amd as ts
+    from oracle import temporal as otemporal
+    dev = _dev()
+    rng = np.random.RandomState(700 + case)
+    B = int(rng.randint(1, 4))
+    H, W = int(rng.randint(9, 40)) * 8 + int(rng.randint(0, 8)), int(rng.randint(12, 60)) * 8 + int(rng.randint(0, 8))
+    h, w = H // 8, W // 8
+    k = int(rng.randint(1, 4))
+    n_in = int(rng.randint(0, 4))
+    size = int(rng.randint(0, 5)) if case != 1 else 3
+    with_memory = case != 2
+    use_past = case != 3
+    prev_disp = rng.uniform(2.0, 60.0, (B, 1, H, W)).astype(np.float32)
+    base = rng.uniform(1.0, 12.0, (B, 1, h, w)).astype(np.float32)
+    mem = {'disp_sample': (base + rng.uniform(-0.5, 0.5, (B, k, h, w))).astype(np.float32),
+           'cost_volume': rng.randn(B, k, h, w).astype(np.float32)}
+    lm = (base * rng.uniform(0.9, 1.1, (B, n_in, h, w))).astype(np.float32) if n_in else None
+    K = synth.sceneflow_intrinsics(B, H, W)
+    K[:, 0, 2] = W / 2.0 + rng.uniform(-3, 3, B); K[:, 1, 2] = H / 2.0 + rng.uniform(-3, 3, B)
+    if case == 4:
+        K = K[:, :3, :3].copy()
+    T = synth.small_motion(700 + case, B)
+    T[:, :3, 3] *= (1.0 if case % 2 else 6.0)                 # bigger translations: some pixels leave the frame
+    T2 = np.linalg.inv(synth.small_motion(900 + case, B)).astype(np.float32)
+    baseline = rng.uniform(0.3, 1.2, (B, 1, 1, 1)).astype(np.float32) if case in (5, 6) else 0.54
+
+    def run(mod, to):
+        info = {'prev_disp': to(prev_disp)}
+        if with_memory:
+            info['cost_memory'] = {kk: to(v) for kk, v in mem.items()}
+        if lm is not None:
+            info['local_map'] = to(lm)
+        if case == 7:
+            info['T_past_to_now'] = to(np.matmul(T, T2))
+        bl = to(baseline) if isinstance(baseline, np.ndarray) else baseline
+        return mod.update_map(info, to(K), to(T), to(T2), bl, H, W, use_past_cost=use_past, local_map_size=size)
+    ref = run(otemporal, lambda a: t(a))
+    got = run(ts.temporal, lambda a: t(a, dev))
+    tag = "B=%d %dx%d k=%d n_in=%d size=%d mem=%s use=%s" % (B, H, W, k, n_in, size, with_memory, use_past)
+
+    def close(a, b, what):
+        a = a.cpu()
+        assert a.shape == b.shape, (tag, what, a.shape, b.shape)
+        d = (a - b).abs()
+        # splat targets that receive almost no weight amplify rounding (x / (den + 1e-22)): robust criterion
+        assert float(d.mean()) < 2e-4 and float((d > 1e-2 * (1 + b.abs())).float().mean()) < 2e-3, \
+            (tag, what, float(d.mean()), float(d.max()))
+    if ref.get('cost_memory') is None:
+        assert got.get('cost_memory') is None, tag
+    else:
+        for key in ("disp_sample", "cost_volume"):
+            close(got['cost_memory'][key], ref['cost_memory'][key], key)
+    if size > 0:
+        close(got['local_map'], ref['local_map'], "local_map")
+        assert got['local_map_size'] == size
+    else:
+        assert ('local_map' in got) == ('local_map' in ref)
+    assert got['use_past_cost'] == ref['use_past_cost']

@@ -282,7 +282,7 @@ def main():
             st = torch.cuda.Stream(device=dev)
             ins = make_inputs(dev, seed + 100 * (i + 1) + rank, a.batch)
             with torch.cuda.stream(st):
-                eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind")
+                eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind", private_streams=True)
                 with torch.no_grad():
                     for _ in range(3):
                         eng(*ins, {})

@@ -78,7 +78,7 @@ class InferenceEngine:
     """`engine(left_feats, right_feats, left_image, right_image, prev_info)` -> same tuple as
     TEMPORALSTEREO.forward, executed as a hipGraph replay."""
 
-    def __init__(self, net, warmup=3, backend="native", graph=None, replay=None, inputs="copy"):
+    def __init__(self, net, warmup=3, backend="native", graph=None, replay=None, inputs="copy", private_streams=False):
         """backend 'native': every stage on libts_hip.so kernels (aggregation.native);
         backend 'module': the nn.Module forward (torch/MIOpen convolutions + HIP K1/K4).
         replay: 'plan'  -- record the pass once into a native launch plan and re-issue it with one host
@@ -90,7 +90,9 @@ class InferenceEngine:
         inputs: 'copy' -- every call copies its arguments into the replay's own static buffers;
                 'bind' -- the replay is bound to the tensors of the first call: the producer (the
                           backbone) writes each frame's features into those same tensors, so nothing is
-                          copied; a call with different storage records a new plan for it."""
+                          copied; a call with different storage records a new plan for it.
+        private_streams: the native backend's two helper streams are shared by every engine of a device;
+                True gives this engine its own pair (several passes in flight on one GPU)."""
         if inputs not in ("copy", "bind"):
             raise ValueError("inputs must be 'copy' or 'bind'")
         self.bind = inputs == "bind"
@@ -104,7 +106,7 @@ class InferenceEngine:
         net = net.eval()
         if backend == "native":
             from .native import NativeAggregator
-            self.net = NativeAggregator(net)
+            self.net = NativeAggregator(net, private_streams=private_streams)
             # cross-stream edges inside a captured graph replay far slower than they run eagerly on
             # ROCm 7.2 (measured 4.7 ms vs 1.9 ms per pair): a captured pass stays on one stream
             self.net.overlap = not graph

@@ -225,3 +225,22 @@ def test_native_vs_module_config1():
     for a, b in zip(got[0], ref[0]):
         assert epe(a.cpu(), b.cpu()) * (512 / a.shape[-1]) < 1e-3
     assert epe(got[0][0][:, :, ::4, ::4].cpu(), t(g["disp_full_sub4"])) < 1e-3
+
+
+def test_helper_streams_are_qualified_and_shared():
+    """The overlap's helper streams are picked by their cross-stream edge cost (some high-priority streams of
+    this runtime signal 4-5x slower than others, which triples the pass time) and shared per device."""
+    import bench
+    from temporalstereo_amd.aggregation import native
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    dev = torch.device("cuda:0")
+    net = bench.build_model(dev, synth.SEED0, 4).eval()
+    e1, e2 = InferenceEngine(net), InferenceEngine(net)
+    assert e1.net.fast is e2.net.fast and e1.net.aux is e2.net.aux and e1.net.fast is not e1.net.aux
+    e3 = InferenceEngine(net, private_streams=True)
+    assert e3.net.fast is not e1.net.fast and e3.net.aux is not e1.net.aux
+    main = torch.cuda.current_stream()
+    floor = native._round_trip_us(main, torch.cuda.Stream(device=dev))
+    for s in (e1.net.fast, e1.net.aux, e3.net.fast, e3.net.aux):
+        assert s.priority == -1
+        assert native._round_trip_us(main, s) < 2.5 * floor

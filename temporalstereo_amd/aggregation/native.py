@@ -62,7 +62,7 @@ _QUALIFIED = {}         # device index -> list of qualified high-priority stream
 _ROUND_TRIP_SLACK = 1.6
 
 
-def _round_trip_us(main, s, n=40):
+def _round_trip_us(main, s, n=20):
     L = _lib._real_lib()
     buf = torch.zeros(2, 256, device=s.device)
     pm, ps = _lib.ctypes.c_void_p(main.cuda_stream), _lib.ctypes.c_void_p(s.cuda_stream)
@@ -74,11 +74,15 @@ def _round_trip_us(main, s, n=40):
                 _lib.check(L.ts_copy_rows_fwd(a, b, 1, 256, 256, 256, st), "ts_copy_rows_fwd")
                 _lib.check(L.ts_stream_fork(st, other), "ts_stream_fork")
     lap(5)
-    torch.cuda.synchronize(s.device)
-    t0 = time.perf_counter()
-    lap(n)
-    torch.cuda.synchronize(s.device)
-    return (time.perf_counter() - t0) / n * 1e6
+    best = None
+    for _ in range(3):                          # the minimum of three laps: robust against a busy host
+        torch.cuda.synchronize(s.device)
+        t0 = time.perf_counter()
+        lap(n)
+        torch.cuda.synchronize(s.device)
+        us = (time.perf_counter() - t0) / n * 1e6
+        best = us if best is None else min(best, us)
+    return best
 
 
 def qualified_streams(dev, count, private=False):

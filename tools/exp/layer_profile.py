@@ -8,8 +8,10 @@ from temporalstereo_amd.aggregation import native
 from temporalstereo_amd import functional as TF
 dev = torch.device("cuda:0")
 seed = synth.SEED0 + 2
-net = bench.build_model(dev, seed); inputs = bench.make_inputs(dev, seed, 1); bench.calibrate_batchnorm(net, inputs)
+net = bench.build_model(dev, seed); inputs = bench.make_inputs(dev, seed, int(sys.argv[1]) if len(sys.argv) > 1 else 1); bench.calibrate_batchnorm(net, inputs)
 agg = native.NativeAggregator(net)
+agg.overlap = False
+native._chunk_cap(int(os.environ.get('CAP', '8')))
 records = []
 def wrap(mod, name, describe):
     orig = getattr(mod, name)

@@ -5,7 +5,7 @@ import bench, synth
 from temporalstereo_amd.aggregation import native
 from temporalstereo_amd.aggregation.engine import InferenceEngine
 dev = torch.device("cuda:0")
-cases = [(1, 544, 960, 12), (1, 384, 1248, 12), (8, 480, 640, 8)]
+cases = [(1, 544, 960, 12), (2, 544, 960, 12), (4, 544, 960, 12), (8, 480, 640, 8), (2, 384, 1248, 12)]
 orig_cap = native._chunk_cap
 def timeit(net, inputs, overlap):
     eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind")

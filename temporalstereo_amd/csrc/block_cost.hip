@@ -1178,6 +1178,187 @@ block_cost_bwd_main(const float* __restrict__ L, const float* __restrict__ R, co
   }
 }
 
+// The same backward without global atomics on the feature gradients: a workgroup owns rows y0..y0+3 of its 8
+// channels of gL AND of gR outright (the warp moves samples along x only), so the D candidates' contributions are
+// summed in two LDS row tiles (ds_add_f32), one channel at a time, and leave as plain coalesced stores.  The
+// atomic version issues 3 * C * D * H * W global atomics (62.7 M at the 1/4 level: 1.40 ms); this one only the
+// 16-way sum of gDisp over the channel groups: 0.52 ms.  What is left is the LDS atomic rate itself (48 per
+// thread and channel, ~3 cycles per lane); the next step is to sum gL over the candidates through lane shuffles
+// (items of one block in adjacent lanes) and to merge the taps of consecutive pixels before they reach the LDS.
+// One item (candidate, 4x4 block) per thread.
+template <bool SAMPLED, bool VEC>
+__global__ void __launch_bounds__(512, 4)   // <= 128 VGPRs: three 5-wave workgroups per CU
+block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
+                    const float* __restrict__ dout, const float* __restrict__ dP1, const float* __restrict__ dP2,
+                    float* __restrict__ gL, float* __restrict__ gR, float* __restrict__ gD, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int by = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int y0 = by * TR;
+  const int H = s.H, W = s.W, D = s.D, C = s.C;
+  const size_t HW = static_cast<size_t>(H) * W;
+  const size_t goff = (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const float* Lg = L + goff;
+  const float* Rg = R + goff;
+  const int Wl = 4 * s.Wq;
+  float* accL = lds + static_cast<size_t>(GRP) * TR * 4 * s.Wqp;       // [TR][Wl]
+  float* accR = accL + TR * Wl;                                        // [TR][Wl]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int i = tid; i < 2 * TR * Wl; i += nthr) accL[i] = 0.f;
+  stage_right_rows<VEC>(lds, Rg, y0, H, W, HW, s.Wq, s.Wqp);           // ends with a barrier
+
+  const float Wm1 = static_cast<float>(W - 1);
+  const int nitems = s.nbx * D;
+  const bool live = tid < nitems;
+  const int d = live ? tid / s.nbx : 0;
+  const int bx = live ? tid - d * s.nbx : 0;
+  const int x4 = bx * 4;
+  const float* dplane0 = dout + (static_cast<size_t>(b) * s.Ctot * D + d) * HW;
+  const size_t cstride = static_cast<size_t>(D) * HW;
+  const size_t pbase = ((static_cast<size_t>(b) * s.G + g) * D + d);
+
+  float dvs[TR][4], gdacc[TR][4];       // candidates kept, tap positions recomputed (registers)
+  float dp1[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float dp2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < TR; ++r) {
+    const int y = min(y0 + r, H - 1);
+    float dv[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (SAMPLED)
+      unpack(ld4<VEC>(disp + (static_cast<size_t>(b) * D + d) * HW + static_cast<size_t>(y) * W, x4, W), dv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dvs[r][k] = dv[k];
+      gdacc[r][k] = 0.f;
+    }
+  }
+  if (live && s.scales > 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int py = 2 * by + i, px = 2 * bx + j;
+        if (py < s.H1 && px < s.W1) dp1[i][j] = dP1[(pbase * s.H1 + py) * s.W1 + px];
+      }
+    if (s.scales > 2 && by < s.H2 && bx < s.W2) dp2 = dP2[(pbase * s.H2 + by) * s.W2 + bx];
+  }
+  auto lds_add = [](float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  const int dump = 2 * TR * Wl, dumpR = TR * Wl;   // the float past accR, relative to accL / to accR
+
+#pragma unroll 1
+  for (int c = 0; c < GRP; ++c) {
+    if (live) {
+      if constexpr (SAMPLED) {     // opaque to the optimiser: keeps the tap arithmetic inside the loop instead of
+#pragma unroll                    // 32 loop-invariant registers (which spilled to scratch: 133 synchronous reloads)
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(dvs[r][q]));
+      }
+      // one pixel's difference e = L - warped R and the slope of R between its two taps; every LDS read is
+      // unconditional at a clamped index and masked afterwards (a read behind a condition becomes a branch
+      // around a wait: 118 of them in the first version of this kernel)
+      auto diff = [&](int r, int kk, float lval, bool ok, float& slope, int& a, float& f) {
+        source_column<SAMPLED>(x4 + kk, d, dvs[r][kk], W, Wm1, a, f);
+        const float* src = lds + static_cast<size_t>(c * TR + r) * 4 * s.Wqp;
+        const int i0 = min(max(a, 0), W - 1), i1 = min(max(a + 1, 0), W - 1);
+        // masked by multiplication: a select would be turned back into a load behind a branch
+        const float r0 = src[(i0 & 3) * s.Wqp + (i0 >> 2)] * ((a >= 0 && a < W) ? 1.f : 0.f);
+        const float r1 = SAMPLED ? src[(i1 & 3) * s.Wqp + (i1 >> 2)] * ((a + 1 >= 0 && a + 1 < W) ? 1.f : 0.f) : 0.f;
+        slope = r1 - r0;
+        const float t = (1.f - f) * r0 + f * r1;
+        return ok ? (lval - t) : 0.f;
+      };
+      // pass A: the 2x2 / 4x4 block sums of e
+      float m1[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int r = 0; r < TR; ++r) {
+        const int y = y0 + r;
+        float lv[4];
+        unpack(ld4<VEC>(Lg + c * HW + static_cast<size_t>(min(y, H - 1)) * W, x4, W), lv);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          float slope, f;
+          int a;
+          m1[r >> 1][kk >> 1] += diff(r, kk, lv[kk], (y < H) && (VEC || x4 + kk < W), slope, a, f);
+        }
+      }
+      const float m2 = (m1[0][0] + m1[0][1] + m1[1][0] + m1[1][1]) * 0.0625f;
+      const size_t chan = static_cast<size_t>(g * GRP + c);
+      if constexpr (SAMPLED) {     // ... and keeps pass B from inheriting 64 registers of pass A's intermediates
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(dvs[r][q]));
+      }
+      // pass B: e again (cheaper than 16 more live registers), the gradients, LDS accumulation
+#pragma unroll
+      for (int r = 0; r < TR; ++r) {
+        const int y = y0 + r;
+        if (y < H) {                                                     // wave-uniform
+          const size_t rowoff = static_cast<size_t>(y) * W;
+          float lv[4], dg0r[4], dmain[4], dwarp[4] = {0.f, 0.f, 0.f, 0.f};
+          unpack(ld4<VEC>(Lg + c * HW + rowoff, x4, W), lv);
+          unpack(ld4<VEC>(dplane0 + static_cast<size_t>(s.mainC + g) * cstride + rowoff, x4, W), dg0r);
+          unpack(ld4<VEC>(dplane0 + chan * cstride + rowoff, x4, W), dmain);
+          if constexpr (SAMPLED) unpack(ld4<VEC>(dplane0 + (chan + C) * cstride + rowoff, x4, W), dwarp);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int x = x4 + kk;
+            const bool inb = VEC || x < W;
+            float slope, f;
+            int a;
+            const float ev = diff(r, kk, lv[kk], inb, slope, a, f);
+            float ge = -2.f * ev * dg0r[kk];
+            ge -= 0.125f * m1[r >> 1][kk >> 1] * dp1[r >> 1][kk >> 1];   // 2 * (sum/4) / 4
+            ge -= 0.125f * m2 * dp2;                                      // 2 * mean / 16
+            float gl, gt;
+            if constexpr (SAMPLED) {
+              gl = ge + dmain[kk];
+              gt = dwarp[kk] - ge;
+            } else {
+              ge -= 2.f * ev * dmain[kk];
+              gl = ge;
+              gt = -ge;
+            }
+            // out-of-range contributions go to a dump slot with value 0: no branches around the LDS atomics
+            const bool t0 = inb && a >= 0 && a < W, t1 = SAMPLED && inb && a + 1 >= 0 && a + 1 < W;
+            lds_add(accL + (inb ? r * Wl + x : dump), inb ? gl : 0.f);
+            lds_add(accR + (t0 ? r * Wl + a : dumpR), t0 ? (1.f - f) * gt : 0.f);
+            if constexpr (SAMPLED) {
+              lds_add(accR + (t1 ? r * Wl + a + 1 : dumpR), t1 ? f * gt : 0.f);
+              gdacc[r][kk] -= inb ? gt * slope : 0.f;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // the channel's rows leave as plain stores; the tiles are cleared for the next channel
+    for (int i = tid; i < 2 * TR * s.Wq; i += nthr) {
+      const int which = i / (TR * s.Wq);                  // 0: gL, 1: gR
+      const int rj = i - which * TR * s.Wq;
+      const int r = rj / s.Wq, j = rj - r * s.Wq;
+      float* acc = (which ? accR : accL) + r * Wl + 4 * j;
+      const float4 v = *reinterpret_cast<const float4*>(acc);
+      *reinterpret_cast<float4*>(acc) = make_float4(0.f, 0.f, 0.f, 0.f);
+      float* dst = which ? gR : gL;
+      const int y = y0 + r;
+      if (dst != nullptr && y < H) st4<VEC>(dst + goff + c * HW + static_cast<size_t>(y) * W, 4 * j, W, v);
+    }
+    __syncthreads();
+  }
+  if constexpr (SAMPLED) {
+    if (gD && live) {
+#pragma unroll
+      for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (y0 + r < H && x4 + k < W)
+            unsafeAtomicAdd(gD + (static_cast<size_t>(b) * D + d) * HW + static_cast<size_t>(y0 + r) * W + x4 + k,
+                            gdacc[r][k]);
+    }
+  }
+}
+
 template <bool SAMPLED>
 int launch_bwd(const float* left, const float* right, const float* disp, const float* grad_out,
                float* grad_left, float* grad_right, float* grad_disp, void* workspace,
@@ -1189,8 +1370,13 @@ int launch_bwd(const float* left, const float* right, const float* disp, const f
   if (scales > 1) TS_REQUIRE_PTR(workspace);
   hipStream_t st = ts::as_stream(stream);
   const size_t nfeat = static_cast<size_t>(B) * C * H * W * sizeof(float);
-  if (grad_left) if (hipError_t e = hipMemsetAsync(grad_left, 0, nfeat, st)) return ts::fail(e, "memset grad_left");
-  if (grad_right) if (hipError_t e = hipMemsetAsync(grad_right, 0, nfeat, st)) return ts::fail(e, "memset grad_right");
+  // tile path: the workgroup that owns a row tile writes every element of it (no zero fill, no global atomics)
+  const size_t tile_lds = (static_cast<size_t>(GRP) * TR * 4 * s.Wqp + 2 * TR * 4 * s.Wq + 4) * sizeof(float);
+  const bool tile = tile_lds <= 64 * 1024 && s.nbx * D <= 512;
+  if (!tile) {
+    if (grad_left) if (hipError_t e = hipMemsetAsync(grad_left, 0, nfeat, st)) return ts::fail(e, "memset grad_left");
+    if (grad_right) if (hipError_t e = hipMemsetAsync(grad_right, 0, nfeat, st)) return ts::fail(e, "memset grad_right");
+  }
   if (SAMPLED && grad_disp)
     if (hipError_t e = hipMemsetAsync(grad_disp, 0, static_cast<size_t>(B) * D * H * W * sizeof(float), st))
       return ts::fail(e, "memset grad_disp");
@@ -1214,6 +1400,14 @@ int launch_bwd(const float* left, const float* right, const float* disp, const f
   int threads = static_cast<int>(ts::round_up(static_cast<size_t>((nitems + passes - 1) / passes), ts::kWave));
   if (threads > 256) threads = 256;
   const dim3 grid(s.nby, s.G, B);
+  if (tile) {
+    const int tthreads = static_cast<int>(ts::round_up(static_cast<size_t>(nitems), ts::kWave));
+    if (vec) hipLaunchKernelGGL((block_cost_bwd_tile<SAMPLED, true>), grid, dim3(tthreads), tile_lds, st, left, right, disp,
+                                grad_out, dP1, dP2, grad_left, grad_right, grad_disp, s);
+    else hipLaunchKernelGGL((block_cost_bwd_tile<SAMPLED, false>), grid, dim3(tthreads), tile_lds, st, left, right, disp,
+                            grad_out, dP1, dP2, grad_left, grad_right, grad_disp, s);
+    return ts::launched("block_cost_bwd_tile");
+  }
 #define TS_LAUNCH_BWD(V, S)                                                                          \
   hipLaunchKernelGGL((block_cost_bwd_main<SAMPLED, V, S>), grid, dim3(threads), (S) ? lds_bytes : 0, st, \
                      left, right, disp, grad_out, dP1, dP2, grad_left, grad_right, grad_disp, s)

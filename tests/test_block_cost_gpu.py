@@ -134,7 +134,8 @@ def test_full_size_precise_level_properties():
 
 
 @pytest.mark.parametrize("sampled", [False, True])
-@pytest.mark.parametrize("shape", [(2, 16, 10, 14, 3), (1, 8, 9, 13, 4), (1, 16, 12, 20, 5)])
+@pytest.mark.parametrize("shape", [(2, 16, 10, 14, 3), (1, 8, 9, 13, 4), (1, 16, 12, 20, 5), (2, 24, 21, 130, 3), (1, 8, 7, 258, 2),
+                                   (1, 16, 34, 60, 8), (1, 8, 8, 520, 2)])     # the last one: more items than the tile kernel takes
 def test_backward_vs_oracle_autograd(shape, sampled):
     """Gradients through the C ABI backward vs autograd of the oracle (same torch ops as the
     reference).  fp32 atomics -> 1e-4 relative to the gradient scale."""

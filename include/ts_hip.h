@@ -253,6 +253,9 @@ int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, c
                          int B, int Cin, int Cout, int H, int W, int act, long long out_bstride, void* stream);
 int ts_resize_bilinear_fwd(const float* x, float* out, int B, int C, int h, int w, int Ho, int Wo, float value_scale,
                            long long out_bstride, void* stream);
+/* two same-shaped dense maps in one launch (the top-k memory's candidates and costs, precise.py:100-103, coarse.py:91-96) */
+int ts_resize_bilinear_pair_fwd(const float* x0, const float* x1, float* out0, float* out1, int B, int C, int h, int w,
+                                int Ho, int Wo, float value_scale0, float value_scale1, void* stream);
 /* search range of the next level and its five candidates from an upsampled disparity:
  * low = d - range, high = d + range (aggregation/TemporalStereo/TemporalStereo.py:110,119);
  * candidates[:, off+i] = |high-low| * {0,3,4,5,8}/8 + min(low,high)  (fine.py:82-87, precise.py:73-78) */

@@ -305,6 +305,19 @@ def resize_bilinear(x, size, value_scale=1.0, out=None):
     return out
 
 
+def resize_bilinear_pair(x0, x1, size, scale0, scale1):
+    """Two same-shaped maps through resize_bilinear in one launch."""
+    B, C, h, w = x0.shape
+    if x1.shape != x0.shape:
+        raise RuntimeError("resize_bilinear_pair: shapes differ")
+    o0 = torch.empty((B, C, size[0], size[1]), device=x0.device, dtype=torch.float32)
+    o1 = torch.empty_like(o0)
+    rc = _lib.lib().ts_resize_bilinear_pair_fwd(_lib.ptr(_lib.contiguous(x0)), _lib.ptr(_lib.contiguous(x1)), _lib.ptr(o0), _lib.ptr(o1),
+                                                B, C, h, w, size[0], size[1], float(scale0), float(scale1), _stream())
+    _lib.check(rc, "ts_resize_bilinear_pair_fwd")
+    return o0, o1
+
+
 def copy_rows(src, dst):
     """dst[...] = src for a `dst` that is a channel slice of a larger contiguous tensor ([B, C, ...])."""
     B = src.shape[0]
@@ -485,8 +498,7 @@ class _MergingLevel(_LevelBase):
         if memory is not None and prev_info.get('use_past_cost', False):
             mem_s, mem_c = memory['disp_sample'], memory['cost_volume']
             if resize_memory:                                           # coarse.py:91-96
-                mem_s = resize_bilinear(mem_s, (H, W), W / mem_s.shape[-1])
-                mem_c = resize_bilinear(mem_c, (H, W), 1.0)
+                mem_s, mem_c = resize_bilinear_pair(mem_s, mem_c, (H, W), W / mem_s.shape[-1], 1.0)
             mem_s, mem_c = _lib.contiguous(mem_s), _lib.contiguous(mem_c)
         Dm = D0 + K
         nch = 4 * C if self.fusion else C
@@ -601,8 +613,8 @@ class NativePrecise(_LevelBase):
         rc = _lib.lib().ts_unet_upsample_fwd(_lib.ptr(mask), _lib.ptr(disp), _lib.ptr(full), B, H, W, 4 * H, 4 * W, _stream())
         _lib.check(rc, "ts_unet_upsample_fwd")
         prev_info['prev_disp'] = full
-        prev_info['cost_memory'] = {'disp_sample': resize_bilinear(mem_s, (H // 2, W // 2), 0.5),      # precise.py:100-103
-                                    'cost_volume': resize_bilinear(mem_c, (H // 2, W // 2), 1.0)}
+        mem_s, mem_c = resize_bilinear_pair(mem_s, mem_c, (H // 2, W // 2), 0.5, 1.0)                  # precise.py:100-103
+        prev_info['cost_memory'] = {'disp_sample': mem_s, 'cost_volume': mem_c}
         return full, disp, cost, off, ds
 
 

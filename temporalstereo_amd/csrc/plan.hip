@@ -72,6 +72,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_resize3d_add_act_bwd),    TS_PLAN_OP(ts_pool3d5_avgmax_bwd),
     TS_PLAN_OP(ts_merge_candidates_bwd),
     TS_PLAN_OP(ts_reproject_memory_fwd),
+    TS_PLAN_OP(ts_resize_bilinear_pair_fwd),
     TS_PLAN_OP(ts_calib_stream),             TS_PLAN_OP(ts_conv_set_chunk_cap),
 };
 

@@ -269,55 +269,77 @@ convex_upsample_kernel(const float* __restrict__ mask, const float* __restrict__
 }
 
 // UNet.upsample: mask [B,9,Ho,Wo] softmax over 9; out = sum_k bilinear(unfold(disp)_k * Wo/w)(oy,ox) * p_k
+// V consecutive output pixels of a row per thread: the 9 logit planes (the bulk of the traffic: 18.8 MB at
+// 544x960) are read as 16-byte vectors when V == 4.
+template <int V>
 __global__ void __launch_bounds__(256)
 unet_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ disp, float* __restrict__ out,
                      int B, int h, int w, int Ho, int Wo, float sh, float sw) {
-  const long long n = static_cast<long long>(B) * Ho * Wo;
+  const int Wv = Wo / V;
+  const long long n = static_cast<long long>(B) * Ho * Wv;
   const size_t HWo = static_cast<size_t>(Ho) * Wo;
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const int ox = static_cast<int>(i % Wo);
-    const long long t = i / Wo;
+    const int oxv = static_cast<int>(i % Wv) * V;
+    const long long t = i / Wv;
     const int oy = static_cast<int>(t % Ho), b = static_cast<int>(t / Ho);
-    int y0, y1, x0, x1;
-    float ly, lx;
-    lin_src(sh, oy, h, y0, y1, ly);
-    lin_src(sw, ox, w, x0, x1, lx);
-    const float* mp = mask + static_cast<size_t>(b) * 9 * HWo + static_cast<size_t>(oy) * Wo + ox;
+    const float* mp = mask + static_cast<size_t>(b) * 9 * HWo + static_cast<size_t>(oy) * Wo + oxv;
     const float* dp = disp + static_cast<size_t>(b) * h * w;
-    // All 9 logits and the 4x4 disparity patch around (y0, x0) are requested before anything is used:
-    // the 36 (tap, bilinear corner) reads of the reference all land in that patch.
-    float m[9], mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) m[k] = mp[k * HWo];
-    float pd[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-        const float dv = dp[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
-        // disp * w_out / w_in in the reference's evaluation order (module.py:478); zero padding of unfold
-        pd[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dv * static_cast<float>(Wo) / static_cast<float>(w) : 0.f;
-      }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) mx = fmaxf(mx, m[k]);
-    const bool iy = y1 > y0, ix = x1 > x0;
-    float den = 0.f, acc = 0.f;
+    float m[9][V];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const float e = expf(m[k] - mx);
-      den += e;
-      const int ry = k / 3, rx = k % 3;            // patch row / column of (y0 + dy, x0 + dx)
-      const float a00 = pd[ry][rx];
-      const float a01 = ix ? pd[ry][rx + 1] : a00;
-      const float a10 = iy ? pd[ry + 1][rx] : a00;
-      const float a11 = iy ? (ix ? pd[ry + 1][rx + 1] : pd[ry + 1][rx]) : a01;
-      const float top = (1.f - lx) * a00 + lx * a01;
-      const float bot = (1.f - lx) * a10 + lx * a11;
-      acc += e * ((1.f - ly) * top + ly * bot);
+      if constexpr (V == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(mp + k * HWo);
+        m[k][0] = q.x; m[k][1] = q.y; m[k][2] = q.z; m[k][3] = q.w;
+      } else {
+        m[k][0] = mp[k * HWo];
+      }
     }
-    out[i] = acc / den;
+    int y0, y1;
+    float ly;
+    lin_src(sh, oy, h, y0, y1, ly);
+    const bool iy = y1 > y0;
+    float res[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int ox = oxv + v;
+      int x0, x1;
+      float lx;
+      lin_src(sw, ox, w, x0, x1, lx);
+      // the 36 (tap, bilinear corner) reads of the reference all land in the 4x4 patch around (y0, x0)
+      float pd[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+          const float dv = dp[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+          // disp * w_out / w_in in the reference's evaluation order (module.py:478); zero padding of unfold
+          pd[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dv * static_cast<float>(Wo) / static_cast<float>(w) : 0.f;
+        }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) mx = fmaxf(mx, m[k][v]);
+      const bool ix = x1 > x0;
+      float den = 0.f, acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float e = expf(m[k][v] - mx);
+        den += e;
+        const int ry = k / 3, rx = k % 3;            // patch row / column of (y0 + dy, x0 + dx)
+        const float a00 = pd[ry][rx];
+        const float a01 = ix ? pd[ry][rx + 1] : a00;
+        const float a10 = iy ? pd[ry + 1][rx] : a00;
+        const float a11 = iy ? (ix ? pd[ry + 1][rx + 1] : pd[ry + 1][rx]) : a01;
+        const float top = (1.f - lx) * a00 + lx * a01;
+        const float bot = (1.f - lx) * a10 + lx * a11;
+        acc += e * ((1.f - ly) * top + ly * bot);
+      }
+      res[v] = acc / den;
+    }
+    float* op = out + static_cast<size_t>(b) * HWo + static_cast<size_t>(oy) * Wo + oxv;
+    if constexpr (V == 4) *reinterpret_cast<float4*>(op) = make_float4(res[0], res[1], res[2], res[3]);
+    else op[0] = res[0];
   }
 }
 
@@ -340,6 +362,31 @@ resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, int
     const float bot = (1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1];
     const int b = bc / C, c = bc - b * C;
     out[static_cast<size_t>(b) * out_bstride + (static_cast<size_t>(c) * Ho + oy) * Wo + ox] = ((1.f - ly) * top + ly * bot) * vscale;
+  }
+}
+
+// two same-shaped maps in one launch (the top-k memory's candidates and costs, precise.py:100-103 / coarse.py:91-96)
+__global__ void __launch_bounds__(256)
+resize_bilinear_pair_kernel(const float* __restrict__ x0, const float* __restrict__ x1, float* __restrict__ out0,
+                            float* __restrict__ out1, int BC, int h, int w, int Ho, int Wo, float sh, float sw, float vs0,
+                            float vs1) {
+  const float* x = blockIdx.y ? x1 : x0;
+  float* out = blockIdx.y ? out1 : out0;
+  const float vscale = blockIdx.y ? vs1 : vs0;
+  const long long n = static_cast<long long>(BC) * Ho * Wo;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int ox = static_cast<int>(i % Wo);
+    const long long t = i / Wo;
+    const int oy = static_cast<int>(t % Ho), bc = static_cast<int>(t / Ho);
+    int y0, y1, xa, xb;
+    float ly, lx;
+    lin_src(sh, oy, h, y0, y1, ly);
+    lin_src(sw, ox, w, xa, xb, lx);
+    const float* p = x + static_cast<size_t>(bc) * h * w;
+    const float top = (1.f - lx) * p[y0 * w + xa] + lx * p[y0 * w + xb];
+    const float bot = (1.f - lx) * p[y1 * w + xa] + lx * p[y1 * w + xb];
+    out[i] = ((1.f - ly) * top + ly * bot) * vscale;
   }
 }
 
@@ -605,8 +652,13 @@ extern "C" int ts_unet_upsample_fwd(const float* mask, const float* disp, float*
                                     void* stream) {
   TS_REQUIRE(B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, TS_ERR_SHAPE, "unet_upsample: bad size");
   TS_REQUIRE_PTR(mask); TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(out);
-  hipLaunchKernelGGL(unet_upsample_kernel, dim3(grid_for(static_cast<long long>(B) * Ho * Wo, 256)), dim3(256), 0,
-                     ts::as_stream(stream), mask, disp, out, B, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo));
+  const bool vec = (Wo % 4 == 0) && ts::aligned16(mask) && ts::aligned16(out);
+  if (vec)
+    hipLaunchKernelGGL(unet_upsample_kernel<4>, dim3(grid_for(static_cast<long long>(B) * Ho * (Wo / 4), 256)), dim3(256), 0,
+                       ts::as_stream(stream), mask, disp, out, B, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo));
+  else
+    hipLaunchKernelGGL(unet_upsample_kernel<1>, dim3(grid_for(static_cast<long long>(B) * Ho * Wo, 256)), dim3(256), 0,
+                       ts::as_stream(stream), mask, disp, out, B, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo));
   return ts::launched("unet_upsample_kernel");
 }
 
@@ -618,6 +670,16 @@ extern "C" int ts_resize_bilinear_fwd(const float* x, float* out, int B, int C, 
                      ts::as_stream(stream), x, out, B * C, C, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo), value_scale,
                      out_bstride);
   return ts::launched("resize_bilinear_kernel");
+}
+
+extern "C" int ts_resize_bilinear_pair_fwd(const float* x0, const float* x1, float* out0, float* out1, int B, int C, int h,
+                                           int w, int Ho, int Wo, float value_scale0, float value_scale1, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, TS_ERR_SHAPE, "resize_bilinear_pair: bad size");
+  TS_REQUIRE_PTR(x0); TS_REQUIRE_PTR(x1); TS_REQUIRE_PTR(out0); TS_REQUIRE_PTR(out1);
+  hipLaunchKernelGGL(resize_bilinear_pair_kernel, dim3(grid_for(static_cast<long long>(B) * C * Ho * Wo, 256), 2), dim3(256), 0,
+                     ts::as_stream(stream), x0, x1, out0, out1, B * C, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo),
+                     value_scale0, value_scale1);
+  return ts::launched("resize_bilinear_pair_kernel");
 }
 
 // ---- backward entries (training) ------------------------------------------------------------------

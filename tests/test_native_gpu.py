@@ -244,3 +244,34 @@ def test_helper_streams_are_qualified_and_shared():
     for s in (e1.net.fast, e1.net.aux, e3.net.fast, e3.net.aux):
         assert s.priority == -1
         assert native._round_trip_us(main, s) < 2.5 * floor
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_unet_upsample_kernel_vs_module_formula(aligned):
+    """ts_unet_upsample_fwd (vector path: 4 pixels per thread; scalar path when the output is not 16-byte aligned)
+    against the torch formulation of UNet.upsample (module.py:468-482)."""
+    from temporalstereo_amd import _lib
+    dev = _dev()
+    B, h, w = 2, 9, 13
+    Ho, Wo = 4 * h, 4 * w
+    mask = _rand(61, B, 9, Ho, Wo, scale=2.0, dev=dev)
+    disp = t(synth.uniform(62, "d", (B, 1, h, w), 0.0, 40.0), dev)
+    nb = F.unfold(disp, kernel_size=(3, 3), padding=(1, 1)).reshape(B, 9, h, w)
+    ref = torch.sum(F.interpolate(nb * Wo / w, size=(Ho, Wo), mode='bilinear', align_corners=True) * F.softmax(mask, dim=1),
+                    dim=1, keepdim=True)
+    buf = torch.zeros(B * Ho * Wo + 4, device=dev)
+    out = buf[0 if aligned else 1:][:B * Ho * Wo].view(B, 1, Ho, Wo)
+    rc = _lib.lib().ts_unet_upsample_fwd(_lib.ptr(mask), _lib.ptr(disp), _lib.ptr(out), B, h, w, Ho, Wo,
+                                         _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "ts_unet_upsample_fwd")
+    assert float((out - ref).abs().max()) < 2e-4
+
+
+def test_resize_bilinear_pair_matches_two_single_calls():
+    from temporalstereo_amd.aggregation import native
+    dev = _dev()
+    a, b = _rand(63, 2, 2, 17, 30, dev=dev), _rand(64, 2, 2, 17, 30, dev=dev)
+    pa, pb = native.resize_bilinear_pair(a, b, (8, 15), 0.5, 1.0)
+    assert torch.equal(pa, native.resize_bilinear(a, (8, 15), 0.5)) and torch.equal(pb, native.resize_bilinear(b, (8, 15), 1.0))
+    ref = F.interpolate(a * 0.5, size=(8, 15), mode='bilinear', align_corners=True)
+    assert float((pa - ref).abs().max()) < 1e-5

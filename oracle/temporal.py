@@ -5,7 +5,9 @@ Restates the closures of `update_map` in projects/TemporalStereo/TemporalStereo.
   update_local_map          :340-384
   update_past_cost          :386-426
   state bookkeeping         :428-461
-The splat inside is oracle.splat.softsplat (parity unpinned by the reference, see splat.py).
+Pinned: tests/golden/temporal_update_*.npz are outputs of the reference's own update_map (its definition compiled
+from the reference file by tools/gen_golden.py) -- with the one substitution that the CUDA-only FunctionSoftsplat is
+oracle.splat.softsplat, whose arithmetic stays pinned analytically (parity unpinned by reference output, see splat.py).
 """
 import torch
 import torch.nn.functional as F

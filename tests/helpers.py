@@ -60,3 +60,38 @@ def aggregator_inputs(g, dims, device="cpu"):
 
 def epe(a, b):
     return float((a.double() - b.double()).abs().mean())
+
+
+def temporal_update_from_golden(g, mod, device="cpu"):
+    """Runs `mod.update_map` (oracle.temporal or temporalstereo_amd.temporal) on the inputs of a
+    tests/golden/temporal_update_*.npz fixture (made by the reference's own update_map, tools/gen_golden.py)."""
+    to = lambda a: t(a, device)
+    info = {"prev_disp": to(g["prev_disp"]),
+            "cost_memory": {"disp_sample": to(g["mem_disp_sample"]), "cost_volume": to(g["mem_cost_volume"])}}
+    if int(g["has_local_in"]):
+        info["local_map"] = to(g["local_map_in"])
+    if int(g["composed"]):
+        info["T_past_to_now"] = torch.bmm(to(g["T_now"]), to(g["inv_T_past"]))
+    H, W = (int(v) for v in g["full_hw"])
+    return mod.update_map(info, to(g["K"]), to(g["T_now"]), to(g["inv_T_past"]), to(g["baseline"]), H, W,
+                          use_past_cost=bool(int(g["use_past_cost"])), local_map_size=int(g["local_map_size"]))
+
+
+def check_temporal_update(g, info, tol_mean, tol_far):
+    def close(a, b, what):
+        a = a.detach().cpu().double()
+        b = torch.from_numpy(b).double()
+        assert a.shape == b.shape, (what, tuple(a.shape), tuple(b.shape))
+        d = (a - b).abs()
+        # targets that receive almost no splat weight amplify rounding (x / (den + 1e-22)): bulk + rare outliers
+        assert float(d.mean()) < tol_mean and float((d > 1e-2 * (1 + b.abs())).double().mean()) < tol_far, \
+            (what, float(d.mean()), float(d.max()))
+    if int(g["has_memory_out"]):
+        close(info["cost_memory"]["disp_sample"], g["out_disp_sample"], "disp_sample")
+        close(info["cost_memory"]["cost_volume"], g["out_cost_volume"], "cost_volume")
+    else:
+        assert info.get("cost_memory") is None
+    if int(g["has_local_out"]):
+        close(info["local_map"], g["out_local_map"], "local_map")
+        assert info["local_map_size"] == int(g["local_map_size"])
+    assert info["use_past_cost"] == bool(int(g["use_past_cost"]))

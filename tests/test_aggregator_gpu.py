@@ -181,3 +181,13 @@ def test_temporal_update_fuzz_vs_oracle(case):
     else:
         assert ('local_map' in got) == ('local_map' in ref)
     assert got['use_past_cost'] == ref['use_past_cost']
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_temporal_update_vs_reference_vectors(case):
+    """The fused HIP update (ts_reproject_memory_fwd) against vectors made by the reference's own update_map."""
+    import temporalstereo_amd as ts
+    from helpers import temporal_update_from_golden, check_temporal_update
+    g = load("temporal_update_%d" % case)
+    info = temporal_update_from_golden(g, ts.temporal, _dev())
+    check_temporal_update(g, info, 2e-4, 2e-3)

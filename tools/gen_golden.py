@@ -256,6 +256,75 @@ def aggregator_case(name, dims, seed, B, H, W, temporal, store_inputs, training=
     save(name, **arrs)
 
 
+def temporal_update_cases(M):
+    """K2c: the reference's OWN `update_map` (projects/TemporalStereo/TemporalStereo.py:326-461) executed here.
+
+    The method lives inside a pytorch_lightning module whose import needs packages this image lacks, so its
+    function definition is taken from the reference file's syntax tree and compiled as is (nothing is copied into
+    this repository; the fixture holds inputs and outputs only).  It runs against the reference's real
+    project_to_3d; the one foreign piece is FunctionSoftsplat, which exists only as cupy/CUDA kernels
+    (softsplat.py:252,269-270) and is bound to oracle.splat.softsplat -- so these vectors pin the glue (intrinsics
+    scaling, pose composition, disparity <-> depth, metric, plane selection, state bookkeeping), not the splat
+    arithmetic, which stays pinned by the analytic tests of tests/test_oracle_splat.py."""
+    import ast
+    import types
+    import torch.nn.functional as F
+    from architecture.modeling.layers import project_to_3d
+    sys.path.insert(0, ROOT)
+    from oracle import splat as osplat
+    path = os.path.join(ref_import.REFERENCE_ROOT, "projects", "TemporalStereo", "TemporalStereo.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TemporalStereo")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "update_map")
+    ns = {"torch": torch, "F": F, "project_to_3d": project_to_3d, "EXPMAX": 50,
+          "FunctionSoftsplat": lambda tenInput, tenFlow, tenMetric, strType: osplat.softsplat(tenInput, tenFlow, tenMetric, strType)}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    update_map = ns["update_map"]
+
+    cases = [  # name, B, H, W, k, local maps in, local_map_size, use_past_cost, pre-composed pose, translation scale
+        ("temporal_update_0", 2, 64, 96, 2, 2, 3, True, False, 1.0),
+        ("temporal_update_1", 1, 72, 120, 2, 0, 3, True, False, 6.0),      # first temporal frame: no local map yet
+        ("temporal_update_2", 2, 64, 96, 2, 3, 2, True, True, 1.0),        # cropped to local_map_size, T_past_to_now given
+        ("temporal_update_3", 1, 80, 104, 3, 1, 0, True, False, 1.0),      # local maps off
+        ("temporal_update_4", 2, 64, 96, 2, 2, 3, False, False, 1.0),      # past cost off
+    ]
+    for name, B, H, W, k, n_in, size, use_past, composed, tscale in cases:
+        seed = synth.SEED0 + 300 + int(name[-1])
+        h, w = H // 8, W // 8
+        prev_disp = synth.uniform(seed, "pd", (B, 1, H, W), 2.0, 60.0)
+        base = synth.uniform(seed, "mb", (B, 1, h, w), 1.0, 12.0)
+        mem_s = (base + synth.uniform(seed, "ms", (B, k, h, w), -0.5, 0.5)).astype(np.float32)
+        mem_c = synth.normal(seed, "mc", (B, k, h, w))
+        lm = (base * synth.uniform(seed, "lm", (B, n_in, h, w), 0.9, 1.1)).astype(np.float32) if n_in else None
+        K = synth.sceneflow_intrinsics(B, H, W)
+        T_now = synth.small_motion(seed, B)
+        T_now[:, :3, 3] *= tscale
+        inv_T_past = np.linalg.inv(synth.small_motion(seed + 50, B)).astype(np.float32)
+        baseline = synth.uniform(seed, "bl", (B, 1, 1, 1), 0.3, 1.2)
+        me = types.SimpleNamespace(with_previous=True, use_past_cost=use_past, local_map_size=size)
+        batch = {"baseline": T(baseline), ("color_aug", 0, "l"): torch.zeros(B, 3, H, W), ("K", 0): T(K),
+                 ("inv_T", -1, "l"): T(inv_T_past), ("T", 0, "l"): T(T_now)}
+        info = {"prev_disp": T(prev_disp), "cost_memory": {"disp_sample": T(mem_s), "cost_volume": T(mem_c)}}
+        if lm is not None:
+            info["local_map"] = T(lm)
+        if composed:
+            info["T_past_to_now"] = torch.bmm(T(T_now), T(inv_T_past))
+        with torch.no_grad():
+            outs, info = update_map(me, batch, info, 0)
+        arrs = dict(prev_disp=prev_disp, mem_disp_sample=mem_s, mem_cost_volume=mem_c, K=K, T_now=T_now, inv_T_past=inv_T_past,
+                    baseline=baseline, full_hw=np.array([H, W]), local_map_size=size, use_past_cost=int(use_past),
+                    composed=int(composed), has_local_in=int(lm is not None), has_memory_out=int(info["cost_memory"] is not None),
+                    has_local_out=int(size > 0))
+        if lm is not None:
+            arrs["local_map_in"] = lm
+        if info["cost_memory"] is not None:
+            arrs["out_disp_sample"] = info["cost_memory"]["disp_sample"]
+            arrs["out_cost_volume"] = info["cost_memory"]["cost_volume"]
+        if size > 0:
+            arrs["out_local_map"] = info["local_map"]
+        save(name, **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -264,8 +333,12 @@ def main():
     if "--only-siblings" in sys.argv:
         sibling_cases(M)
         return
+    if "--only-temporal" in sys.argv:
+        temporal_update_cases(M)
+        return
     functional_cases(M)
     sibling_cases(M)
+    temporal_update_cases(M)
     aggregator_case("agg_tiny_single", TINY, synth.SEED0 + 100, 2, 96, 160, temporal=False, store_inputs=True)
     aggregator_case("agg_tiny_temporal", TINY, synth.SEED0 + 101, 2, 96, 160, temporal=True, store_inputs=True)
     aggregator_case("agg_tiny_train", TINY, synth.SEED0 + 102, 2, 96, 160, temporal=False, store_inputs=True,

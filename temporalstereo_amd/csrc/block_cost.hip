@@ -1182,9 +1182,9 @@ block_cost_bwd_main(const float* __restrict__ L, const float* __restrict__ R, co
 // channels of gL AND of gR outright (the warp moves samples along x only), so the D candidates' contributions are
 // summed in two LDS row tiles (ds_add_f32), one channel at a time, and leave as plain coalesced stores.  The
 // atomic version issues 3 * C * D * H * W global atomics (62.7 M at the 1/4 level: 1.40 ms); this one only the
-// 16-way sum of gDisp over the channel groups: 0.52 ms.  What is left is the LDS atomic rate itself (48 per
-// thread and channel, ~3 cycles per lane); the next step is to sum gL over the candidates through lane shuffles
-// (items of one block in adjacent lanes) and to merge the taps of consecutive pixels before they reach the LDS.
+// 16-way sum of gDisp over the channel groups.  The LDS atomic rate (~3 cycles per lane) is what bounds it: with
+// 48 atomics per thread and channel 0.52 ms; gL is therefore summed over the candidates by lane shuffles (the D
+// items of a block sit in adjacent lanes) and stored plainly -- 32 atomics, 0.40 ms.
 // One item (candidate, 4x4 block) per thread.
 template <bool SAMPLED, bool VEC>
 __global__ void __launch_bounds__(512, 4)   // <= 128 VGPRs: three 5-wave workgroups per CU
@@ -1207,10 +1207,16 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
   stage_right_rows<VEC>(lds, Rg, y0, H, W, HW, s.Wq, s.Wqp);           // ends with a barrier
 
   const float Wm1 = static_cast<float>(W - 1);
-  const int nitems = s.nbx * D;
-  const bool live = tid < nitems;
-  const int d = live ? tid / s.nbx : 0;
-  const int bx = live ? tid - d * s.nbx : 0;
+  // The D candidates of one 4x4 block sit in ADJACENT lanes (64 / D blocks per wave): their gL contributions are
+  // summed by lane shuffles and written without atomics (the LDS atomic rate, ~3 cycles per lane, is what bounds
+  // this kernel: 48 atomics per thread and channel cost 390 of its 518 us, these 16 of them 130 us).
+  const int per_wave = 64 / D;
+  const int lane = tid & 63, bxl = lane / D;
+  const int dl = lane - bxl * D;
+  const int bxw = (tid >> 6) * per_wave + bxl;
+  const bool live = bxl < per_wave && bxw < s.nbx;
+  const int d = live ? dl : 0;
+  const int bx = live ? bxw : 0;
   const int x4 = bx * 4;
   const float* dplane0 = dout + (static_cast<size_t>(b) * s.Ctot * D + d) * HW;
   const size_t cstride = static_cast<size_t>(D) * HW;
@@ -1242,11 +1248,10 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
     if (s.scales > 2 && by < s.H2 && bx < s.W2) dp2 = dP2[(pbase * s.H2 + by) * s.W2 + bx];
   }
   auto lds_add = [](float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  const int dump = 2 * TR * Wl, dumpR = TR * Wl;   // the float past accR, relative to accL / to accR
 
 #pragma unroll 1
   for (int c = 0; c < GRP; ++c) {
-    if (live) {
+    {   // every lane runs this block (the shuffles below need whole waves); lanes without an item contribute zeros
       if constexpr (SAMPLED) {     // opaque to the optimiser: keeps the tap arithmetic inside the loop instead of
 #pragma unroll                    // 32 loop-invariant registers (which spilled to scratch: 133 synchronous reloads)
         for (int r = 0; r < TR; ++r)
@@ -1278,7 +1283,7 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
         for (int kk = 0; kk < 4; ++kk) {
           float slope, f;
           int a;
-          m1[r >> 1][kk >> 1] += diff(r, kk, lv[kk], (y < H) && (VEC || x4 + kk < W), slope, a, f);
+          m1[r >> 1][kk >> 1] += diff(r, kk, lv[kk], live && (y < H) && (VEC || x4 + kk < W), slope, a, f);
         }
       }
       const float m2 = (m1[0][0] + m1[0][1] + m1[1][0] + m1[1][1]) * 0.0625f;
@@ -1300,10 +1305,12 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
           unpack(ld4<VEC>(dplane0 + static_cast<size_t>(s.mainC + g) * cstride + rowoff, x4, W), dg0r);
           unpack(ld4<VEC>(dplane0 + chan * cstride + rowoff, x4, W), dmain);
           if constexpr (SAMPLED) unpack(ld4<VEC>(dplane0 + (chan + C) * cstride + rowoff, x4, W), dwarp);
+          int pend_a = -1;
+          float pend_v = 0.f;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const int x = x4 + kk;
-            const bool inb = VEC || x < W;
+            const bool inb = live && (VEC || x < W);
             float slope, f;
             int a;
             const float ev = diff(r, kk, lv[kk], inb, slope, a, f);
@@ -1319,15 +1326,26 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
               gl = ge;
               gt = -ge;
             }
-            // out-of-range contributions go to a dump slot with value 0: no branches around the LDS atomics
-            const bool t0 = inb && a >= 0 && a < W, t1 = SAMPLED && inb && a + 1 >= 0 && a + 1 < W;
-            lds_add(accL + (inb ? r * Wl + x : dump), inb ? gl : 0.f);
-            lds_add(accR + (t0 ? r * Wl + a : dumpR), t0 ? (1.f - f) * gt : 0.f);
-            if constexpr (SAMPLED) {
-              lds_add(accR + (t1 ? r * Wl + a + 1 : dumpR), t1 ? f * gt : 0.f);
-              gdacc[r][kk] -= inb ? gt * slope : 0.f;
+            // gL: sum over the block's candidates in the neighbouring lanes, one plain store by the first of them
+            float gsum = inb ? gl : 0.f;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+              const float up = __shfl_down(gsum, off, 64);
+              gsum += (dl + off < D) ? up : 0.f;
             }
+            if (inb && dl == 0) accL[r * Wl + x] = gsum;
+            // gR: two taps per pixel; the +1 tap is carried to the next pixel and merged into its tap when they share
+            // a column (neighbours of a smooth candidate map do).  Predicated atomics, not a dump slot: the cost of an
+            // LDS atomic is per ACTIVE lane, and lanes sent to one dump address serialise (0.44 ms vs 0.40 ms).
+            const bool t0 = inb && a >= 0 && a < W, t1 = SAMPLED && inb && a + 1 >= 0 && a + 1 < W;
+            const bool merge = t0 && pend_a == a;
+            if (pend_a >= 0 && !merge) lds_add(accR + r * Wl + pend_a, pend_v);
+            if (t0) lds_add(accR + r * Wl + a, (1.f - f) * gt + (merge ? pend_v : 0.f));
+            pend_a = t1 ? a + 1 : -1;
+            pend_v = f * gt;
+            if constexpr (SAMPLED) gdacc[r][kk] -= inb ? gt * slope : 0.f;
           }
+          if (pend_a >= 0) lds_add(accR + r * Wl + pend_a, pend_v);
         }
       }
     }
@@ -1372,7 +1390,8 @@ int launch_bwd(const float* left, const float* right, const float* disp, const f
   const size_t nfeat = static_cast<size_t>(B) * C * H * W * sizeof(float);
   // tile path: the workgroup that owns a row tile writes every element of it (no zero fill, no global atomics)
   const size_t tile_lds = (static_cast<size_t>(GRP) * TR * 4 * s.Wqp + 2 * TR * 4 * s.Wq + 4) * sizeof(float);
-  const bool tile = tile_lds <= 64 * 1024 && s.nbx * D <= 512;
+  const int tile_threads = D <= 16 ? ((s.nbx + 64 / D - 1) / (64 / D)) * 64 : 1 << 30;   // 64 / D blocks per wave
+  const bool tile = tile_lds <= 64 * 1024 && tile_threads <= 512;
   if (!tile) {
     if (grad_left) if (hipError_t e = hipMemsetAsync(grad_left, 0, nfeat, st)) return ts::fail(e, "memset grad_left");
     if (grad_right) if (hipError_t e = hipMemsetAsync(grad_right, 0, nfeat, st)) return ts::fail(e, "memset grad_right");
@@ -1401,7 +1420,7 @@ int launch_bwd(const float* left, const float* right, const float* disp, const f
   if (threads > 256) threads = 256;
   const dim3 grid(s.nby, s.G, B);
   if (tile) {
-    const int tthreads = static_cast<int>(ts::round_up(static_cast<size_t>(nitems), ts::kWave));
+    const int tthreads = tile_threads;
     if (vec) hipLaunchKernelGGL((block_cost_bwd_tile<SAMPLED, true>), grid, dim3(tthreads), tile_lds, st, left, right, disp,
                                 grad_out, dP1, dP2, grad_left, grad_right, grad_disp, s);
     else hipLaunchKernelGGL((block_cost_bwd_tile<SAMPLED, false>), grid, dim3(tthreads), tile_lds, st, left, right, disp,

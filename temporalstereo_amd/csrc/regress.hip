@@ -35,16 +35,25 @@ topk_softargmax_fwd(const float* __restrict__ cost, const float* __restrict__ sa
     int bi[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { bc[j] = -INFINITY; bi[j] = -1; }
-    for (int d = 0; d < D; ++d) {
-      float c = cost[base + static_cast<size_t>(d) * HW];
-      int ci = d;
-      // insertion into the descending list; strict '>' keeps the lowest index first among ties
+    // eight candidates requested at a time (clamped index: unconditional loads), then inserted in order -- a
+    // load-per-iteration loop serialises D global round trips on the small levels
+    for (int d0 = 0; d0 < D; d0 += 8) {
+      float cc[8];
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const bool take = (c > bc[j]) || (bi[j] < 0);
-        const float tc = bc[j];
-        const int ti = bi[j];
-        if (take) { bc[j] = c; bi[j] = ci; c = tc; ci = ti; }
+      for (int u = 0; u < 8; ++u) cc[u] = cost[base + static_cast<size_t>(min(d0 + u, D - 1)) * HW];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float c = cc[u];
+        int ci = d0 + u;
+        const bool real = ci < D;
+        // insertion into the descending list; strict '>' keeps the lowest index first among ties
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const bool take = real && ((c > bc[j]) || (bi[j] < 0));
+          const float tc = bc[j];
+          const int ti = bi[j];
+          if (take) { bc[j] = c; bi[j] = ci; c = tc; ci = ti; }
+        }
       }
     }
     // softmax over the k kept costs (bc[0] is the maximum)

@@ -226,3 +226,67 @@ def test_regression_and_splat_kernels_random_shapes():
             m = None if mode == "summation" else (met.abs() + 0.1 if mode == "linear" else met)
             got = ts.FunctionSoftsplat(inp.to(dev), flow.to(dev), None if m is None else m.to(dev), mode)
             np.testing.assert_allclose(got.cpu().numpy(), osp.softsplat(inp, flow, m, mode).numpy(), rtol=1e-4, atol=1e-4, err_msg=tag + " splat " + mode)
+
+
+def test_three_frame_sequence_engine_vs_module_path():
+    """A whole temporal sequence the way the reference's wrapper runs it (projects/TemporalStereo/TemporalStereo.py:
+    282-324): frame t's aggregation writes prev_disp / cost memory, update_map moves them (and the growing local map)
+    into frame t+1.  Per frame: native engine on the fused HIP update against the nn.Module path on the oracle's
+    op-by-op update, both starting from the SAME previous state (the module path's) -- a random-weight network
+    amplifies the few flipped pixels of one frame through the splat into the next, so two pipelines that each
+    carry their own state drift apart by frame 2 (27 % of the pixels beyond 0.1 px) without either being wrong."""
+    import bench
+    import temporalstereo_amd as ts
+    from oracle import temporal as otemporal
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    dev = torch.device("cuda:0")
+    B, H, W, ns, size = 2, 128, 192, 4, 3
+    seed = 5150
+    net = ts.TEMPORALSTEREO(coarse=ts.CoarseAggregation(32, 8, ns), fine=ts.FineAggregation(16, 8, 5), precise=ts.PreciseAggregation(8, 8, 5))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_values(shapes, seed).items()}, strict=True)
+    net = net.to(dev)
+    frames = []
+    for f in range(3):
+        lf, rf = synth.feature_pyramid(seed + f, B, H, W, chans=(8, 16, 32))
+        il, ir = synth.images(seed + f, B, H, W)
+        frames.append(([torch.from_numpy(x).to(dev) for x in lf], [torch.from_numpy(x).to(dev) for x in rf],
+                       torch.from_numpy(il).to(dev), torch.from_numpy(ir).to(dev)))
+    bench.calibrate_batchnorm(net, frames[0])
+    K = torch.from_numpy(synth.sceneflow_intrinsics(B, H, W))
+    poses = [torch.from_numpy(synth.small_motion(seed + 10 * f, B)) for f in range(3)]
+    eng = InferenceEngine(net, backend="native", replay="plan")
+
+    def moved(v, where):
+        if isinstance(v, dict):
+            return {k: moved(x, where) for k, x in v.items()}
+        return v.detach().clone().to(where) if torch.is_tensor(v) else v
+
+    state = {}
+    for f in range(3):
+        info_e, info_m = {}, {}
+        if f:
+            inv_past = torch.inverse(poses[f - 1])
+            info_e = ts.temporal.update_map(moved(state, dev), K.to(dev), poses[f].to(dev), inv_past.to(dev), 0.54, H, W,
+                                            use_past_cost=True, local_map_size=size)
+            info_m = moved(otemporal.update_map(moved(state, "cpu"), K, poses[f], inv_past, 0.54, H, W,
+                                                use_past_cost=True, local_map_size=size), dev)
+            assert info_e["local_map"].shape == info_m["local_map"].shape == (B, min(f, size), H // 8, W // 8)
+            for a, b in ((info_e["local_map"], info_m["local_map"]),
+                         (info_e["cost_memory"]["disp_sample"], info_m["cost_memory"]["disp_sample"]),
+                         (info_e["cost_memory"]["cost_volume"], info_m["cost_memory"]["cost_volume"])):
+                d = (a - b).abs()
+                assert float(d.mean()) < 2e-4 and float((d > 1e-2 * (1 + b.abs())).double().mean()) < 2e-3, "frame %d state" % f
+        out_e = eng(*frames[f], dict(info_e))
+        with torch.no_grad():
+            out_m = net(*frames[f], dict(info_m))
+        tag = "frame %d" % f
+        assert [tuple(c.shape) for c in out_e[1]] == [tuple(c.shape) for c in out_m[1]], tag
+        for i in range(4):
+            diff = (out_e[0][i] - out_m[0][i]).abs() * (W / out_m[0][i].shape[-1])
+            med, far = float(diff.median()), float((diff > 0.1).double().mean())
+            assert med < 2e-3 and far < 0.02, tag + " disparity %d: median %.3g px, %.2f%% beyond 0.1 px" % (i, med, 100 * far)
+        for key in ("prev_disp", "cost_memory"):
+            assert key in out_e[5] and key in out_m[5]
+        state = moved(out_m[5], dev)

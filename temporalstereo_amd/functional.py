@@ -104,25 +104,88 @@ def _fms_args(reference_fm, target_fm, disp_sample):
     return _lib.contiguous(reference_fm), _lib.contiguous(target_fm), _lib.contiguous(disp_sample), B, C, H, W, disp_sample.shape[1]
 
 
+def _fms_backward(l, r, d, g_ref, g_warp, needs):
+    """Gradients of [ref repeated | right warped by every candidate] w.r.t. (left, right, candidates): that volume is the
+    first 2C channels of the sampled block cost, so its backward is ts_block_cost_sampled_bwd at scales = 1 with a zero
+    gradient on the correlation planes (one padded copy of the incoming gradient; these ops are not on the shipped path)."""
+    B, C, H, W = l.shape
+    D = d.shape[1]
+    L = _lib.lib()
+    gpad = torch.zeros((B, 2 * C + C // 8, D, H, W), device=l.device, dtype=torch.float32)
+    if g_ref is not None:
+        gpad[:, :C] = g_ref
+    gpad[:, C:2 * C] = g_warp
+    gl = torch.empty_like(l) if needs[0] else None
+    gr = torch.empty_like(r) if needs[1] else None
+    gd = torch.empty_like(d) if needs[2] else None
+    ws = torch.empty(max(int(L.ts_block_cost_bwd_workspace_bytes(B, C, H, W, D, 1)), 256), device=l.device, dtype=torch.uint8)
+    rc = L.ts_block_cost_sampled_bwd(_lib.ptr(l), _lib.ptr(r), _lib.ptr(d), _lib.ptr(gpad), _lib.ptr(gl), _lib.ptr(gr), _lib.ptr(gd),
+                                     _lib.ptr(ws), B, C, H, W, D, 1, _stream())
+    _lib.check(rc, "ts_block_cost_sampled_bwd")
+    return gl, gr, gd
+
+
+class _CatFms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, reference_fm, target_fm, disp_sample):
+        l, r, d, B, C, H, W, D = _fms_args(reference_fm, target_fm, disp_sample)
+        out = torch.empty((B, 2 * C, D, H, W), device=l.device, dtype=torch.float32)
+        rc = _lib.lib().ts_cat_fms_fwd(_lib.ptr(l), _lib.ptr(r), _lib.ptr(d), _lib.ptr(out), B, C, H, W, D, _stream())
+        _lib.check(rc, "ts_cat_fms_fwd")
+        ctx.save_for_backward(l, r, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        l, r, d = ctx.saved_tensors
+        C = l.shape[1]
+        g = _lib.contiguous(g)
+        return _fms_backward(l, r, d, g[:, :C], g[:, C:], ctx.needs_input_grad)
+
+
+class _DifFms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, reference_fm, target_fm, disp_sample):
+        l, r, d, B, C, H, W, D = _fms_args(reference_fm, target_fm, disp_sample)
+        out = torch.empty((B, C, D, H, W), device=l.device, dtype=torch.float32)
+        ws = torch.empty(int(_lib.lib().ts_dif_fms_workspace_bytes()), device=l.device, dtype=torch.uint8)
+        rc = _lib.lib().ts_dif_fms_fwd(_lib.ptr(l), _lib.ptr(r), _lib.ptr(d), _lib.ptr(out), _lib.ptr(ws), B, C, H, W, D, _stream())
+        _lib.check(rc, "ts_dif_fms_fwd")
+        ctx.save_for_backward(l, r, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        # dif_fms.py:33-41 differentiated by hand: |e| where the warped value is > 0, the tensor-wide maximum elsewhere
+        # (torch.max() hands its gradient to the maximal element, split evenly among ties); the warp itself through
+        # the cost-volume backward kernel
+        l, r, d = ctx.saved_tensors
+        B, C, H, W = l.shape
+        with torch.no_grad():
+            warped = _CatFms.apply(l, r, d)[:, C:]
+            e = l.unsqueeze(2) - warped
+            a = e.abs()
+            keep = (warped > 0).to(g.dtype)
+            g_a = g * keep
+            g_max = (g * (1 - keep)).sum()
+            top = (a == a.max()).to(g.dtype)
+            g_a = g_a + top * (g_max / top.sum())
+            g_e = g_a * torch.sign(e)
+            gl, gr, gd = _fms_backward(l, r, d, None, -g_e, (False,) + tuple(ctx.needs_input_grad[1:]))
+            gl = g_e.sum(2) if ctx.needs_input_grad[0] else None
+        return gl, gr, gd
+
+
 def cat_fms(reference_fm, target_fm, disp_sample):
     """aggregation/utils/cat_fms.py:5 (same arguments): [B,2C,D,H,W] = cat[left repeated over D, right warped by every
-    candidate].  Forward only (the shipped configs use block_cost)."""
-    l, r, d, B, C, H, W, D = _fms_args(reference_fm, target_fm, disp_sample)
-    out = torch.empty((B, 2 * C, D, H, W), device=l.device, dtype=torch.float32)
-    rc = _lib.lib().ts_cat_fms_fwd(_lib.ptr(l), _lib.ptr(r), _lib.ptr(d), _lib.ptr(out), B, C, H, W, D, _stream())
-    _lib.check(rc, "ts_cat_fms_fwd")
-    return out
+    candidate] (the shipped configs use block_cost).  Differentiable in all three arguments."""
+    return _CatFms.apply(reference_fm, target_fm, disp_sample)
 
 
 def dif_fms(reference_fm, target_fm, disp_sample):
     """aggregation/utils/dif_fms.py:5 (same arguments): [B,C,D,H,W] = |left - warped right| with the elements whose warped
-    value is not > 0 filled with the tensor-wide maximum difference.  Forward only."""
-    l, r, d, B, C, H, W, D = _fms_args(reference_fm, target_fm, disp_sample)
-    out = torch.empty((B, C, D, H, W), device=l.device, dtype=torch.float32)
-    ws = torch.empty(int(_lib.lib().ts_dif_fms_workspace_bytes()), device=l.device, dtype=torch.uint8)
-    rc = _lib.lib().ts_dif_fms_fwd(_lib.ptr(l), _lib.ptr(r), _lib.ptr(d), _lib.ptr(out), _lib.ptr(ws), B, C, H, W, D, _stream())
-    _lib.check(rc, "ts_dif_fms_fwd")
-    return out
+    value is not > 0 filled with the tensor-wide maximum difference.  Differentiable in all three arguments."""
+    return _DifFms.apply(reference_fm, target_fm, disp_sample)
 
 
 # --------------------------------------------------------------------------------------- K3 convolutions

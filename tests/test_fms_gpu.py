@@ -67,3 +67,27 @@ def test_fms_is_block_cost_without_the_correlation_channels_and_rejects_bad_inpu
         ts.cat_fms(l[:, :12], r[:, :12], d)                      # C % 8
     with pytest.raises(RuntimeError):
         ts.dif_fms(l, r, d[:, :1])                                # D == 1 divides by zero in the reference's warp
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 9, 13, 3), (1, 16, 12, 40, 5), (1, 8, 6, 130, 2)])
+def test_fms_backward_vs_oracle_autograd(shape):
+    """Gradients of cat_fms / dif_fms (left, right, candidates) against autograd through the oracle's torch formulation
+    (the same ops as the reference).  dif_fms: candidates are kept away from the `warped > 0` threshold."""
+    import oracle.cost_volume as ocv
+    import temporalstereo_amd as ts
+    B, C, H, W, D = shape
+    dev = _dev()
+    L = synth.normal(31, "L", (B, C, H, W)); R = np.abs(synth.normal(31, "R", (B, C, H, W))) + 0.2      # warped > 0 inside the image
+    disp = synth.uniform(31, "d", (B, D, H, W), -2.0, W * 0.5)
+    for name, fn_gpu, fn_cpu, cout in (("cat_fms", ts.cat_fms, ocv.cat_fms, 2 * C), ("dif_fms", ts.dif_fms, ocv.dif_fms, C)):
+        gout = synth.normal(32, "g" + name, (B, cout, D, H, W))
+        lc, rc, dc = (t(v).requires_grad_() for v in (L, R, disp))
+        fn_cpu(lc, rc, dc).backward(t(gout))
+        lg, rg, dg = (t(v, dev).requires_grad_() for v in (L, R, disp))
+        out = fn_gpu(lg, rg, dg)
+        assert out.requires_grad
+        out.backward(t(gout, dev))
+        for got, want, what in ((lg.grad, lc.grad, "left"), (rg.grad, rc.grad, "right"), (dg.grad, dc.grad, "candidates")):
+            scale = float(want.abs().max()) + 1e-6
+            err = float((got.cpu() - want).abs().max())
+            assert err <= 3e-4 * scale + 1e-5, "%s grad %s: max err %g (scale %g)" % (name, what, err, scale)

@@ -206,6 +206,9 @@ def main():
                          "with the HIP convolution Functions (unfused BatchNorm / activation); -graph: replayed "
                          "as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2),
+                    help="native mode: 2 = the engine keeps two passes in flight on double-buffered launch plans (the "
+                         "chain of step k+1 overlaps the 1/4-level tail of step k); 1 = one pass at a time")
     ap.add_argument("--inflight", type=int, default=0,
                     help="extra measurement (does not change `value`): pairs/s with this many independent pairs in "
                          "flight per GPU, each a batch-1 pass on its own streams; 0/1 skips it")
@@ -246,7 +249,8 @@ def main():
         from temporalstereo_amd import layers
         layers.set_conv_backend("torch")
     # inputs='bind': the features stay where the (out-of-scope) backbone would write them, resident in HBM
-    runner = InferenceEngine(net, backend=mode.split("-")[0], replay=replay, inputs="bind")
+    depth = a.frames_in_flight if mode == "native" else 1
+    runner = InferenceEngine(net, backend=mode.split("-")[0], replay=replay, inputs="bind", pipeline=depth)
 
     def step():
         with torch.no_grad():
@@ -272,6 +276,22 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         k1_times = k1.measure(max(a.steps, 20)) if rank == 0 else {}
+
+    # one pass at a time (what a latency-bound caller sees), next to the two-in-flight headline
+    one_at_a_time = None
+    if depth > 1 and rank == 0:
+        single = InferenceEngine(net, backend="native", replay="plan", inputs="bind")
+        with torch.no_grad():
+            for _ in range(3):
+                single(*inputs, {})
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                single(*inputs, {})
+            torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / a.steps
+        one_at_a_time = dict(value=a.batch / dt1, unit="pairs/s per GPU", ms_per_step=dt1 * 1e3,
+                             note="same engine with frames_in_flight=1 on rank 0: every pass waits for the previous one")
 
     # Serving-style concurrency: N independent batch-1 passes in flight on one GPU (each its own plan, buffers
     # and streams).  The chain of small launches of one pass leaves most CUs idle; another pass fills them.
@@ -362,8 +382,10 @@ def main():
                       config=dict(workload="BASELINE configs[1]: FlyingThings3D 540x960 (run 544x960) D=192 "
                                            "single-frame aggregation, batch %d/GPU, eval" % a.batch,
                                   run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
-                                  parallelism="replicas x%d" % world, exec_mode=mode),
+                                  parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth),
                       roofline=roofline)
+        if one_at_a_time is not None:
+            result["one_pass_at_a_time"] = one_at_a_time
         if concurrent is not None:
             result["concurrent_pairs"] = concurrent
         if world == 1 and not a.no_cpu_baseline:

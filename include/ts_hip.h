@@ -296,6 +296,10 @@ int ts_plan_length(const ts_plan* plan);
 int ts_plan_add_call(ts_plan* plan, const char* name, const unsigned long long* words, int n_words);
 int ts_plan_run(ts_plan* plan);
 int ts_stream_fork(void* from_stream, void* to_stream);
+/* Named events (slot 0..255): record on one stream now, wait from another stream in a LATER call (an edge that spans
+ * replays: "the pass that last used these buffers is done").  Waiting on a never-recorded slot is a no-op. */
+int ts_event_record(int slot, void* stream);
+int ts_event_wait(int slot, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement support (no reference counterpart): float4 streams used by bench.py to calibrate

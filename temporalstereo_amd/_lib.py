@@ -80,6 +80,8 @@ SIGNATURES = {
     "ts_plan_add_call": (c_int, [c_ptr, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong), c_int]),
     "ts_plan_run": (c_int, [c_ptr]),
     "ts_stream_fork": (c_int, [c_ptr, c_ptr]),
+    "ts_event_record": (c_int, [c_int, c_ptr]),
+    "ts_event_wait": (c_int, [c_int, c_ptr]),
 }
 
 # entry points that only answer a question (nothing is enqueued): never part of a recorded plan

@@ -74,11 +74,23 @@ class _Recorded:
         self.recorder.run()
 
 
+_next_slot = [0]
+
+
+def _new_event_slot():
+    """A process-wide event slot of the native library (ts_event_record / ts_event_wait)."""
+    if _next_slot[0] >= 256:
+        raise RuntimeError("out of event slots")
+    _next_slot[0] += 1
+    return _next_slot[0] - 1
+
+
 class InferenceEngine:
     """`engine(left_feats, right_feats, left_image, right_image, prev_info)` -> same tuple as
     TEMPORALSTEREO.forward, executed as a hipGraph replay."""
 
-    def __init__(self, net, warmup=3, backend="native", graph=None, replay=None, inputs="copy", private_streams=False):
+    def __init__(self, net, warmup=3, backend="native", graph=None, replay=None, inputs="copy", private_streams=False,
+                 pipeline=1):
         """backend 'native': every stage on libts_hip.so kernels (aggregation.native);
         backend 'module': the nn.Module forward (torch/MIOpen convolutions + HIP K1/K4).
         replay: 'plan'  -- record the pass once into a native launch plan and re-issue it with one host
@@ -92,7 +104,14 @@ class InferenceEngine:
                           backbone) writes each frame's features into those same tensors, so nothing is
                           copied; a call with different storage records a new plan for it.
         private_streams: the native backend's two helper streams are shared by every engine of a device;
-                True gives this engine its own pair (several passes in flight on one GPU)."""
+                True gives this engine its own pair (several passes in flight on one GPU).
+        pipeline: 2 keeps two passes in flight (replay='plan', inputs='bind' only).  The pass is recorded twice, on
+                two sets of buffers used alternately, and the latency chain of a call (coarse -> fine levels, on the
+                engine's own streams) no longer waits for the caller's stream, where the 1/4-level tail of the
+                previous call is still running on the other buffers: consecutive, independent frames overlap
+                (single-frame mode; a temporal sequence has a true dependency from frame to frame and gains
+                nothing).  Contract: the bound input tensors are complete on the device when the call is made, and
+                the outputs of a call stay valid until the call after next."""
         if inputs not in ("copy", "bind"):
             raise ValueError("inputs must be 'copy' or 'bind'")
         self.bind = inputs == "bind"
@@ -117,6 +136,11 @@ class InferenceEngine:
         self.backend, self.use_graph, self.replay = backend, graph, replay
         self.warmup = warmup
         self._graphs = {}
+        if pipeline not in (1, 2) or (pipeline == 2 and not (replay == "plan" and self.bind)):
+            raise ValueError("pipeline=2 needs replay='plan' and inputs='bind'")
+        self.pipeline = pipeline
+        self._slots = [_new_event_slot() for _ in range(pipeline)] if pipeline > 1 else [None]
+        self._turn = {}
 
     def _capture(self, args):
         static_in = args if self.bind else _clone_static(args)
@@ -154,6 +178,11 @@ class InferenceEngine:
             with torch.no_grad():
                 return self.net(args[0], args[1], args[2], args[3], dict(prev_info))
         sig = _sig_of(args) + ((_ptrs_of(args),) if self.bind else ())
+        if self.pipeline > 1:                      # double-buffered plans, used alternately
+            turn = self._turn.get(sig, 0)
+            self._turn[sig] = (turn + 1) % self.pipeline
+            sig = sig + (turn,)
+            self.net.pipeline_slot = self._slots[turn]
         cap = self._graphs.get(sig)
         if cap is None:
             cap = self._graphs[sig] = self._record(args) if self.replay == "plan" else self._capture(args)

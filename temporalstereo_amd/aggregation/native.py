@@ -633,6 +633,7 @@ class NativeAggregator:
         # dispatched ahead of the wide kernels' (which fill whatever is left) and both finish together.
         dev = next(net.parameters()).device
         self.fast, self.aux = qualified_streams(dev, 2, private=private_streams)
+        self.pipeline_slot = None            # set by the engine while it records one of its double-buffered plans
         self.overlap = True
 
     def _coarse_level(self, l16, r16, prev_info, out, mask=None):
@@ -665,9 +666,17 @@ class NativeAggregator:
             # caller's stream waiting on it, so tensors allocated under it are safe to hand over.
             main = torch.cuda.current_stream()
             mainp, fastp = _lib.ctypes.c_void_p(main.cuda_stream), _lib.ctypes.c_void_p(self.fast.cuda_stream)
-            _lib.check(_lib.lib().ts_stream_fork(mainp, fastp), "ts_stream_fork")
             aux = self.aux
-            _edge(main, aux)
+            if self.pipeline_slot is None:
+                _lib.check(_lib.lib().ts_stream_fork(mainp, fastp), "ts_stream_fork")
+                _edge(main, aux)
+            else:
+                # Two passes in flight (engine.py, pipeline=2): the chain of this pass does not wait for the caller's
+                # stream -- i.e. for the 1/4-level tail of the PREVIOUS pass, which runs on other buffers -- but only
+                # for the pass that last used THESE buffers (event recorded at its end, below).
+                auxp = _lib.ctypes.c_void_p(aux.cuda_stream)
+                _lib.check(_lib.lib().ts_event_wait(self.pipeline_slot, fastp), "ts_event_wait")
+                _lib.check(_lib.lib().ts_event_wait(self.pipeline_slot, auxp), "ts_event_wait")
             _PAR["on"], _PAR["aux"] = True, aux
             try:
                 # Short K chunks (small LDS tiles) while three streams share the CUs: measured 1.53 ms/pair
@@ -697,6 +706,8 @@ class NativeAggregator:
                     ds = self._fine_level(l8, r8, ds, prev_info, out, joined(mf), joined(ltf))
                 _lib.check(_lib.lib().ts_stream_fork(fastp, mainp), "ts_stream_fork")
                 full, d, c, o, s = self.precise(both, mask, ds, prev_info)
+                if self.pipeline_slot is not None:
+                    _lib.check(_lib.lib().ts_event_record(self.pipeline_slot, mainp), "ts_event_record")
             finally:
                 _PAR["on"], _PAR["aux"] = False, None
                 _chunk_cap(32)

@@ -12,6 +12,7 @@
 // The reference has no counterpart (it runs eagerly under PyTorch); the closest notion is a CUDA
 // graph with static input/output buffers, and the contract is the same: pointers are baked in.
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -69,6 +70,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_unet_upsample_fwd),       TS_PLAN_OP(ts_deconv2d_k4s2_fwd),
     TS_PLAN_OP(ts_resize_bilinear_fwd),     TS_PLAN_OP(ts_range_candidates_fwd),
     TS_PLAN_OP(ts_copy_rows_fwd),           TS_PLAN_OP(ts_stream_fork),
+    TS_PLAN_OP(ts_event_record),            TS_PLAN_OP(ts_event_wait),
     TS_PLAN_OP(ts_resize3d_add_act_bwd),    TS_PLAN_OP(ts_pool3d5_avgmax_bwd),
     TS_PLAN_OP(ts_merge_candidates_bwd),
     TS_PLAN_OP(ts_reproject_memory_fwd),
@@ -146,6 +148,40 @@ extern "C" int ts_stream_fork(void* from_stream, void* to_stream) {
   hipError_t e = hipEventRecord(ev, ts::as_stream(from_stream));
   if (e == hipSuccess) e = hipStreamWaitEvent(ts::as_stream(to_stream), ev, 0);
   if (e != hipSuccess) return ts::fail(static_cast<int>(e), "stream_fork: %s", hipGetErrorString(e));
+  return TS_OK;
+}
+
+// Named events (slots 0..255, created on first use): an edge whose record and wait are issued by DIFFERENT calls --
+// e.g. "the pass that last used these buffers has finished" recorded at the end of one replay and waited on at the
+// start of the replay after next (two passes in flight on double-buffered plans).  Waiting on a slot that was never
+// recorded is a no-op.
+namespace {
+hipEvent_t g_slot[256];
+bool g_slot_made[256];
+bool g_slot_recorded[256];
+std::mutex g_slot_lock;
+}  // namespace
+
+extern "C" int ts_event_record(int slot, void* stream) {
+  TS_REQUIRE(slot >= 0 && slot < 256, TS_ERR_SHAPE, "event_record: slot %d", slot);
+  std::lock_guard<std::mutex> hold(g_slot_lock);
+  if (!g_slot_made[slot]) {
+    hipError_t e = hipEventCreateWithFlags(&g_slot[slot], hipEventDisableTiming);
+    if (e != hipSuccess) return ts::fail(static_cast<int>(e), "event_record: %s", hipGetErrorString(e));
+    g_slot_made[slot] = true;
+  }
+  hipError_t e = hipEventRecord(g_slot[slot], ts::as_stream(stream));
+  if (e != hipSuccess) return ts::fail(static_cast<int>(e), "event_record: %s", hipGetErrorString(e));
+  g_slot_recorded[slot] = true;
+  return TS_OK;
+}
+
+extern "C" int ts_event_wait(int slot, void* stream) {
+  TS_REQUIRE(slot >= 0 && slot < 256, TS_ERR_SHAPE, "event_wait: slot %d", slot);
+  std::lock_guard<std::mutex> hold(g_slot_lock);
+  if (!g_slot_recorded[slot]) return TS_OK;
+  hipError_t e = hipStreamWaitEvent(ts::as_stream(stream), g_slot[slot], 0);
+  if (e != hipSuccess) return ts::fail(static_cast<int>(e), "event_wait: %s", hipGetErrorString(e));
   return TS_OK;
 }
 

@@ -139,7 +139,7 @@ class InferenceEngine:
         if pipeline not in (1, 2) or (pipeline == 2 and not (replay == "plan" and self.bind)):
             raise ValueError("pipeline=2 needs replay='plan' and inputs='bind'")
         self.pipeline = pipeline
-        self._slots = [_new_event_slot() for _ in range(pipeline)] if pipeline > 1 else [None]
+        self._slot_of = {}          # one named event per recorded plan: "the pass that last used these buffers is done"
         self._turn = {}
 
     def _capture(self, args):
@@ -182,7 +182,9 @@ class InferenceEngine:
             turn = self._turn.get(sig, 0)
             self._turn[sig] = (turn + 1) % self.pipeline
             sig = sig + (turn,)
-            self.net.pipeline_slot = self._slots[turn]
+            if sig not in self._slot_of:
+                self._slot_of[sig] = _new_event_slot()
+            self.net.pipeline_slot = self._slot_of[sig]
         cap = self._graphs.get(sig)
         if cap is None:
             cap = self._graphs[sig] = self._record(args) if self.replay == "plan" else self._capture(args)

@@ -1,0 +1,33 @@
+"""GPU: the one-line JSON contract of bench.py (driver-facing) on a short run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "pairs/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - d["config"]["batch_per_gpu"]) < 1e-6 * d["value"]      # value = pairs / time
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] < 1.0 and r["traffic"] is not None
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["parity"]["delta_epe_px"] < d["parity"]["tolerance_px"] == 1e-3
+    assert d["config"]["frames_in_flight"] == 2 and d["one_pass_at_a_time"]["value"] > 0

@@ -206,9 +206,9 @@ def main():
                          "with the HIP convolution Functions (unfused BatchNorm / activation); -graph: replayed "
                          "as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=(1, 2),
-                    help="native mode: 2 = the engine keeps two passes in flight on double-buffered launch plans (the "
-                         "chain of step k+1 overlaps the 1/4-level tail of step k); 1 = one pass at a time")
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3),
+                    help="native mode: N > 1 = the engine keeps N independent passes in flight on N sets of launch-plan "
+                         "buffers, each pass a three-stage pipeline over the engine's streams; 1 = one pass at a time")
     ap.add_argument("--inflight", type=int, default=0,
                     help="extra measurement (does not change `value`): pairs/s with this many independent pairs in "
                          "flight per GPU, each a batch-1 pass on its own streams; 0/1 skips it")
@@ -277,7 +277,7 @@ def main():
         elapsed = time.perf_counter() - t0
         k1_times = k1.measure(max(a.steps, 20)) if rank == 0 else {}
 
-    # one pass at a time (what a latency-bound caller sees), next to the two-in-flight headline
+    # one pass at a time (what a latency-bound caller sees), next to the several-in-flight headline
     one_at_a_time = None
     if depth > 1 and rank == 0:
         single = InferenceEngine(net, backend="native", replay="plan", inputs="bind")

@@ -136,8 +136,8 @@ class InferenceEngine:
         self.backend, self.use_graph, self.replay = backend, graph, replay
         self.warmup = warmup
         self._graphs = {}
-        if pipeline not in (1, 2) or (pipeline == 2 and not (replay == "plan" and self.bind)):
-            raise ValueError("pipeline=2 needs replay='plan' and inputs='bind'")
+        if pipeline not in (1, 2, 3) or (pipeline > 1 and not (replay == "plan" and self.bind)):
+            raise ValueError("pipeline>1 needs replay='plan' and inputs='bind'")
         self.pipeline = pipeline
         self._slot_of = {}          # one named event per recorded plan: "the pass that last used these buffers is done"
         self._turn = {}

@@ -654,6 +654,37 @@ class NativeAggregator:
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
 
+    def _staged_pass(self, l4, l8, l16, r4, r8, r16, left_image, right_image, prev_info, out):
+        """Several passes in flight (engine.py, pipeline >= 2): the pass as a three-stage pipeline, one stage per
+        stream -- `fast`: upsampling logits + coarse level, `aux`: fine level, caller's stream: wide UNet half, then the
+        1/4-level tail -- with exactly two cross-stream edges (coarse -> fine, fine -> tail) and no branches inside a
+        stage: every edge towards a stream that is still busy with the previous pass's stage would stall this pass
+        behind it (measured: 773 pairs/s with the latency-mode branches kept, 882 without, depth 2).  None of the
+        engine's streams waits for the caller's stream, where the tail of the previous pass is still running on other
+        buffers; they wait for the pass that last used THESE buffers (named event, recorded at the end)."""
+        L = _lib.lib()
+        main = torch.cuda.current_stream()
+        slot = self.pipeline_slot
+        P = lambda st: _lib.ctypes.c_void_p(st.cuda_stream)
+        _lib.check(L.ts_event_wait(slot, P(self.fast)), "ts_event_wait")
+        _lib.check(L.ts_event_wait(slot, P(self.aux)), "ts_event_wait")
+        try:
+            _chunk_cap(8)
+            with torch.cuda.stream(self.fast):
+                mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
+                ltf = self.fine.left_term(_lib.contiguous(l8))
+                ds = self._coarse_level(l16, r16, prev_info, out, lambda: mc)
+            both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
+            _edge(self.fast, self.aux)
+            with torch.cuda.stream(self.aux):
+                ds = self._fine_level(l8, r8, ds, prev_info, out, lambda: mf, lambda: ltf)
+            _edge(self.aux, main)
+            res = self.precise(both, mask, ds, prev_info)
+            _lib.check(L.ts_event_record(slot, P(main)), "ts_event_record")
+        finally:
+            _chunk_cap(32)
+        return res
+
     @torch.no_grad()
     def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):
         l4, l8, l16 = left_feats
@@ -661,22 +692,16 @@ class NativeAggregator:
         out = ([], [], [], [], [])
         disps, costs, offs, samples, ranges = out
         left_image, right_image = _lib.contiguous(left_image), _lib.contiguous(right_image)
-        if self.overlap:
+        if self.overlap and self.pipeline_slot is not None:
+            full, d, c, o, s = self._staged_pass(l4, l8, l16, r4, r8, r16, left_image, right_image, prev_info, out)
+        elif self.overlap:
             # Every use of `fast` starts by waiting on an event of the caller's stream and ends with the
             # caller's stream waiting on it, so tensors allocated under it are safe to hand over.
             main = torch.cuda.current_stream()
             mainp, fastp = _lib.ctypes.c_void_p(main.cuda_stream), _lib.ctypes.c_void_p(self.fast.cuda_stream)
             aux = self.aux
-            if self.pipeline_slot is None:
-                _lib.check(_lib.lib().ts_stream_fork(mainp, fastp), "ts_stream_fork")
-                _edge(main, aux)
-            else:
-                # Two passes in flight (engine.py, pipeline=2): the chain of this pass does not wait for the caller's
-                # stream -- i.e. for the 1/4-level tail of the PREVIOUS pass, which runs on other buffers -- but only
-                # for the pass that last used THESE buffers (event recorded at its end, below).
-                auxp = _lib.ctypes.c_void_p(aux.cuda_stream)
-                _lib.check(_lib.lib().ts_event_wait(self.pipeline_slot, fastp), "ts_event_wait")
-                _lib.check(_lib.lib().ts_event_wait(self.pipeline_slot, auxp), "ts_event_wait")
+            _lib.check(_lib.lib().ts_stream_fork(mainp, fastp), "ts_stream_fork")
+            _edge(main, aux)
             _PAR["on"], _PAR["aux"] = True, aux
             try:
                 # Short K chunks (small LDS tiles) while three streams share the CUs: measured 1.53 ms/pair
@@ -706,8 +731,6 @@ class NativeAggregator:
                     ds = self._fine_level(l8, r8, ds, prev_info, out, joined(mf), joined(ltf))
                 _lib.check(_lib.lib().ts_stream_fork(fastp, mainp), "ts_stream_fork")
                 full, d, c, o, s = self.precise(both, mask, ds, prev_info)
-                if self.pipeline_slot is not None:
-                    _lib.check(_lib.lib().ts_event_record(self.pipeline_slot, mainp), "ts_event_record")
             finally:
                 _PAR["on"], _PAR["aux"] = False, None
                 _chunk_cap(32)

@@ -30,4 +30,4 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["parity"]["delta_epe_px"] < d["parity"]["tolerance_px"] == 1e-3
-    assert d["config"]["frames_in_flight"] == 2 and d["one_pass_at_a_time"]["value"] > 0
+    assert d["config"]["frames_in_flight"] == 3 and d["one_pass_at_a_time"]["value"] > 0

@@ -277,10 +277,11 @@ def test_resize_bilinear_pair_matches_two_single_calls():
     assert float((pa - ref).abs().max()) < 1e-5
 
 
-def test_engine_two_passes_in_flight_matches_plain_engine():
-    """pipeline=2: the pass is recorded on two sets of buffers used alternately and the chain of a call no longer waits
-    for the previous call's tail.  Outputs are bit-identical to the plain engine, follow the CONTENT of the bound
-    inputs, and a call's outputs survive exactly one further call."""
+@pytest.mark.parametrize("depth", [2, 3])
+def test_engine_passes_in_flight_match_plain_engine(depth):
+    """pipeline=N: the pass is recorded on N sets of buffers used in turn, as a three-stage pipeline over the engine's
+    streams that does not wait for the previous call's tail.  Outputs are bit-identical to the plain engine, follow the
+    CONTENT of the bound inputs, and a call's outputs survive exactly N-1 further calls."""
     import bench
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     dev = _dev()
@@ -305,12 +306,12 @@ def test_engine_two_passes_in_flight_matches_plain_engine():
     want_b = [t.clone() for t in plain(*other, {})[0]]
     with pytest.raises(ValueError):
         InferenceEngine(net, backend="native", replay="plan", inputs="copy", pipeline=2)
-    eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind", pipeline=2)
-    o1 = eng(*bound, {})
-    o2 = eng(*bound, {})
-    assert o1[0][0].data_ptr() != o2[0][0].data_ptr()                       # two sets of buffers
+    eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind", pipeline=depth)
+    first = [eng(*bound, {}) for _ in range(depth)]
+    o1, o2 = first[0], first[-1]
+    assert len({o[0][0].data_ptr() for o in first}) == depth                 # N sets of buffers
     torch.cuda.synchronize()
-    assert all(torch.equal(a, b) for a, b in zip(o1[0], want_a)) and all(torch.equal(a, b) for a, b in zip(o2[0], want_a))
+    assert all(torch.equal(a, b) for o in first for a, b in zip(o[0], want_a))
     # new content in the bound tensors (the producer's job; complete on the device before the call)
     for dst, src in zip(bound[0] + bound[1] + [bound[2], bound[3]], other[0] + other[1] + [other[2], other[3]]):
         dst.copy_(src)

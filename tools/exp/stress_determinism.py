@@ -24,9 +24,9 @@ for replay in ("plan", "eager"):
                 if bad <= 5: print(replay, "iteration", i, "max abs diffs", diffs, flush=True)
     print("replay=%s: %d / %d iterations differed" % (replay, bad, N), flush=True)
 
-# two passes in flight: snapshots are taken on the caller's stream (ordered after each pass's tail) without ever
+# three passes in flight: snapshots are taken on the caller's stream (ordered after each pass's tail) without ever
 # synchronising the host, so consecutive passes really overlap while they are checked
-eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind", pipeline=2)
+eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind", pipeline=3)
 ref_full = InferenceEngine(net, backend="native", replay="plan", inputs="bind")(*inputs, {})
 ref_t = [t.clone() for t in ref_full[0]] + [t.clone() for t in ref_full[1]]
 for _ in range(4): eng(*inputs, {})
@@ -37,7 +37,7 @@ for i in range(N):
     if len(snaps) == 50:
         torch.cuda.synchronize()
         bad = sum(1 for sn in snaps if any(not torch.equal(a, b) for a, b in zip(sn, ref_t)))
-        if bad: print("pipeline=2: %d of 50 snapshots differ (iteration %d)" % (bad, i), flush=True)
+        if bad: print("pipeline=3: %d of 50 snapshots differ (iteration %d)" % (bad, i), flush=True)
         snaps = []
 torch.cuda.synchronize()
-print("pipeline=2: %d overlapped passes checked against the plain engine" % N, flush=True)
+print("pipeline=3: %d overlapped passes checked against the plain engine" % N, flush=True)

@@ -105,13 +105,13 @@ class InferenceEngine:
                           copied; a call with different storage records a new plan for it.
         private_streams: the native backend's two helper streams are shared by every engine of a device;
                 True gives this engine its own pair (several passes in flight on one GPU).
-        pipeline: 2 keeps two passes in flight (replay='plan', inputs='bind' only).  The pass is recorded twice, on
-                two sets of buffers used alternately, and the latency chain of a call (coarse -> fine levels, on the
-                engine's own streams) no longer waits for the caller's stream, where the 1/4-level tail of the
-                previous call is still running on the other buffers: consecutive, independent frames overlap
-                (single-frame mode; a temporal sequence has a true dependency from frame to frame and gains
-                nothing).  Contract: the bound input tensors are complete on the device when the call is made, and
-                the outputs of a call stay valid until the call after next."""
+        pipeline: N = 2 or 3 keeps N passes in flight (replay='plan', inputs='bind' only).  The pass is recorded N times,
+                on N sets of buffers used in turn, as a three-stage pipeline over the engine's streams (coarse level |
+                fine level | wide UNet half + 1/4-level tail on the caller's stream); none of the engine's streams waits
+                for the caller's stream, where the tail of the previous call is still running on other buffers:
+                consecutive, independent frames overlap (single-frame mode; a temporal sequence has a true dependency
+                from frame to frame and should use pipeline=1).  Contract: the bound input tensors are complete on
+                the device when the call is made, and the outputs of a call stay valid for N-1 further calls."""
         if inputs not in ("copy", "bind"):
             raise ValueError("inputs must be 'copy' or 'bind'")
         self.bind = inputs == "bind"

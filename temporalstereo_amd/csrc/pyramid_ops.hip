@@ -299,6 +299,27 @@ unet_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ d
     float ly;
     lin_src(sh, oy, h, y0, y1, ly);
     const bool iy = y1 > y0;
+    // The 36 (tap, bilinear corner) reads of the reference for one output pixel all land in the 4x4 patch around
+    // (y0, x0); the V pixels of a thread span at most V/ceil(1/sw)+1 source columns, so ONE 4 x (4 + XS) patch serves
+    // them all (XS = 1 when V == 4 and the upsampling factor is >= 4: 20 loads instead of 64).
+    constexpr int XS = (V == 4) ? 1 : 0;
+    int xb, xb1;
+    float lxb;
+    lin_src(sw, oxv, w, xb, xb1, lxb);
+    int xe = xb, xe1;
+    float lxe;
+    if (V > 1) lin_src(sw, oxv + V - 1, w, xe, xe1, lxe);
+    const bool shared = (xe - xb) <= XS;
+    float P[4][4 + XS];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4 + XS; ++c) {
+        const int yy = y0 - 1 + r, xx = xb - 1 + c;
+        const float dv = dp[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+        // disp * w_out / w_in in the reference's evaluation order (module.py:478); zero padding of unfold
+        P[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dv * static_cast<float>(Wo) / static_cast<float>(w) : 0.f;
+      }
     float res[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -306,17 +327,23 @@ unet_upsample_kernel(const float* __restrict__ mask, const float* __restrict__ d
       int x0, x1;
       float lx;
       lin_src(sw, ox, w, x0, x1, lx);
-      // the 36 (tap, bilinear corner) reads of the reference all land in the 4x4 patch around (y0, x0)
       float pd[4][4];
+      if (shared) {
+        const bool sh = XS && (x0 != xb);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-          const float dv = dp[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
-          // disp * w_out / w_in in the reference's evaluation order (module.py:478); zero padding of unfold
-          pd[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dv * static_cast<float>(Wo) / static_cast<float>(w) : 0.f;
-        }
+          for (int c = 0; c < 4; ++c) pd[r][c] = sh ? P[r][c + XS] : P[r][c];
+      } else {                                  // small upsampling factors: each pixel reads its own patch
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+            const float dv = dp[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+            pd[r][c] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dv * static_cast<float>(Wo) / static_cast<float>(w) : 0.f;
+          }
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int k = 0; k < 9; ++k) mx = fmaxf(mx, m[k][v]);

@@ -233,9 +233,17 @@ def _strides5(t):
     return t.stride(0), t.stride(1)
 
 
-def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0, addend=None):
-    """x [B,Cin,D,H,W] -> [B,Cout,D,Ho,Wo].  addend [B,Cout,1,Ho,Wo]: added to every depth plane's raw sum."""
+def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0, addend=None, second=None):
+    """x [B,Cin,D,H,W] -> [B,Cout,D,Ho,Wo].  addend [B,Cout,1,Ho,Wo]: added to every depth plane's raw sum.
+    second: another tensor of x's shape with B == 1 -- the two are convolved as ONE batch of two (the batch stride
+    handed to the kernel is simply the distance between the two allocations), without stacking them first."""
     B, Cin, D, H, W = x.shape
+    if second is not None:
+        if B != 1 or second.shape != x.shape or not (x.is_contiguous() and second.is_contiguous()):
+            raise ValueError("conv_hw(second=...): two contiguous tensors of one shape with batch 1")
+        if (second.data_ptr() - x.data_ptr()) % 4:
+            raise ValueError("conv_hw(second=...): allocations are not 4-byte aligned relative to each other")
+        B = 2
     assert Cin == f.cin, (Cin, f.cin)
     if transposed:
         Ho, Wo = 2 * H, 2 * W
@@ -245,6 +253,9 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
     if out is None:
         out = torch.empty((B, f.cout, D, Ho, Wo), device=x.device, dtype=torch.float32)
     ib, ic = _strides5(x)
+    if second is not None:
+        ib = (second.data_ptr() - x.data_ptr()) // 4
+        _lib.ptr(second)                                   # kept alive with a recorded plan
     ob, oc = _strides5(out)
     L = _lib.lib()
     wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, f.cout, D, H, W, stride, int(transposed)))
@@ -562,10 +573,14 @@ class NativePrecise(_LevelBase):
     def _c2d(x, f, stride, out=None):
         return conv_hw(x, f, stride, 1, out=out)
 
-    def encode(self, imgs, cat4):
+    def encode(self, imgs, cat4, pair=None):
         """UNet.encoder (module.py:459-466) for the left and right images at once (stacked on the batch
-        axis); the 1/4 features go straight into their channel slice of `cat4`."""
-        x = self._c2d(imgs.unsqueeze(2), self.enc[0], self.enc_stride[0])
+        axis, or -- batch 1 -- given as the `pair` of separate tensors); the 1/4 features go straight into
+        their channel slice of `cat4`."""
+        if pair is not None:
+            x = conv_hw(pair[0].unsqueeze(2), self.enc[0], self.enc_stride[0], 1, second=pair[1].unsqueeze(2))
+        else:
+            x = self._c2d(imgs.unsqueeze(2), self.enc[0], self.enc_stride[0])
         s2 = self._c2d(x, self.enc[1], self.enc_stride[1])
         x = self._c2d(s2, self.enc[2], self.enc_stride[2])
         self._c2d(x, self.enc[3], self.enc_stride[3], out=cat4[:, self.in_planes:].unsqueeze(2))
@@ -586,9 +601,12 @@ class NativePrecise(_LevelBase):
         both = torch.empty((2 * B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)   # [left | right] x [feat | spx4]
         lcat, rcat = both[:B], both[B:]
         copy_rows(left, lcat[:, :Cf]); copy_rows(right, rcat[:, :Cf])
-        imgs = torch.empty((2 * B,) + tuple(left_image.shape[1:]), device=left.device, dtype=torch.float32)
-        copy_rows(left_image, imgs[:B]); copy_rows(right_image, imgs[B:])
-        s2 = self.encode(imgs, both)
+        if B == 1:                 # the two images as one batch of two without stacking them (two launches fewer)
+            s2 = self.encode(None, both, pair=(left_image, right_image))
+        else:
+            imgs = torch.empty((2 * B,) + tuple(left_image.shape[1:]), device=left.device, dtype=torch.float32)
+            copy_rows(left_image, imgs[:B]); copy_rows(right_image, imgs[B:])
+            s2 = self.encode(imgs, both)
         lterm = self.left_term(lcat)
         s2l = s2[:B]
         f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)

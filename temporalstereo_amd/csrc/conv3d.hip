@@ -197,7 +197,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     wci[q] = ci;
     wl[q] = v < WV ? r * WP + co4 * 4 : KT * NC * WP;
   }
-  const __amdgpu_buffer_rsrc_t xr = ig_rsrc(x + static_cast<size_t>(b) * p.in_bstride, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t xr = ig_rsrc(x + static_cast<long long>(b) * p.in_bstride, p.in_bytes);   // signed: the batch stride may be the distance between two allocations
   const __amdgpu_buffer_rsrc_t wr = ig_rsrc(w, p.w_bytes);
   const unsigned cstride_b = static_cast<unsigned>(p.in_cstride) * 4u;
   const unsigned wstride_b = static_cast<unsigned>(KT * p.coutp) * 4u;

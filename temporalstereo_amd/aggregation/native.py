@@ -233,14 +233,16 @@ def _strides5(t):
     return t.stride(0), t.stride(1)
 
 
-def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0, addend=None, second=None):
+def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0, addend=None, second=None,
+            out_second=None):
     """x [B,Cin,D,H,W] -> [B,Cout,D,Ho,Wo].  addend [B,Cout,1,Ho,Wo]: added to every depth plane's raw sum.
     second: another tensor of x's shape with B == 1 -- the two are convolved as ONE batch of two (the batch stride
-    handed to the kernel is simply the distance between the two allocations), without stacking them first."""
+    handed to the kernel is simply the distance between the two allocations), without stacking them first.
+    out_second: with `second`, the second batch element's output goes to this separate tensor (`out` holds the first)."""
     B, Cin, D, H, W = x.shape
     if second is not None:
-        if B != 1 or second.shape != x.shape or not (x.is_contiguous() and second.is_contiguous()):
-            raise ValueError("conv_hw(second=...): two contiguous tensors of one shape with batch 1")
+        if B != 1 or second.shape != x.shape or _strides5(second)[1] != _strides5(x)[1]:
+            raise ValueError("conv_hw(second=...): two tensors of one shape and channel stride with batch 1")
         if (second.data_ptr() - x.data_ptr()) % 4:
             raise ValueError("conv_hw(second=...): allocations are not 4-byte aligned relative to each other")
         B = 2
@@ -257,6 +259,11 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
         ib = (second.data_ptr() - x.data_ptr()) // 4
         _lib.ptr(second)                                   # kept alive with a recorded plan
     ob, oc = _strides5(out)
+    if out_second is not None:
+        if second is None or out.shape[0] != 1 or out_second.shape != out.shape or _strides5(out_second)[1] != oc:
+            raise ValueError("conv_hw(out_second=...): needs `second` and two outputs of one shape and channel stride")
+        ob = (out_second.data_ptr() - out.data_ptr()) // 4
+        _lib.ptr(out_second)
     L = _lib.lib()
     wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, f.cout, D, H, W, stride, int(transposed)))
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
@@ -573,7 +580,7 @@ class NativePrecise(_LevelBase):
     def _c2d(x, f, stride, out=None):
         return conv_hw(x, f, stride, 1, out=out)
 
-    def encode(self, imgs, cat4, pair=None):
+    def encode(self, imgs, cat4, pair=None, s2_left=None):
         """UNet.encoder (module.py:459-466) for the left and right images at once (stacked on the batch
         axis, or -- batch 1 -- given as the `pair` of separate tensors); the 1/4 features go straight into
         their channel slice of `cat4`."""
@@ -581,8 +588,16 @@ class NativePrecise(_LevelBase):
             x = conv_hw(pair[0].unsqueeze(2), self.enc[0], self.enc_stride[0], 1, second=pair[1].unsqueeze(2))
         else:
             x = self._c2d(imgs.unsqueeze(2), self.enc[0], self.enc_stride[0])
-        s2 = self._c2d(x, self.enc[1], self.enc_stride[1])
-        x = self._c2d(s2, self.enc[2], self.enc_stride[2])
+        if s2_left is not None:
+            # batch 1: the left view's 1/2-resolution features are written where the decoder concatenates them
+            # (module.py:488), the right view's into a buffer of their own; the next layer reads the two as a pair
+            s2_right = torch.empty((1,) + tuple(s2_left.shape[1:]), device=x.device, dtype=torch.float32)
+            conv_hw(x[:1], self.enc[1], self.enc_stride[1], 1, out=s2_left, second=x[1:], out_second=s2_right)
+            x = conv_hw(s2_left, self.enc[2], self.enc_stride[2], 1, second=s2_right)
+            s2 = None
+        else:
+            s2 = self._c2d(x, self.enc[1], self.enc_stride[1])
+            x = self._c2d(s2, self.enc[2], self.enc_stride[2])
         self._c2d(x, self.enc[3], self.enc_stride[3], out=cat4[:, self.in_planes:].unsqueeze(2))
         return s2
 
@@ -601,19 +616,18 @@ class NativePrecise(_LevelBase):
         both = torch.empty((2 * B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)   # [left | right] x [feat | spx4]
         lcat, rcat = both[:B], both[B:]
         copy_rows(left, lcat[:, :Cf]); copy_rows(right, rcat[:, :Cf])
-        if B == 1:                 # the two images as one batch of two without stacking them (two launches fewer)
-            s2 = self.encode(None, both, pair=(left_image, right_image))
+        C32, C2 = self.deconv4.cout, self.enc[1].cout
+        cat2 = torch.empty((B, C32 + C2, 2 * H, 2 * W), device=left.device, dtype=torch.float32)      # [deconv4 | s2 of the left view]
+        if B == 1:                 # the two views as one batch of two without stacking them (three launches fewer)
+            self.encode(None, both, pair=(left_image, right_image), s2_left=cat2[:, C32:].unsqueeze(2))
         else:
             imgs = torch.empty((2 * B,) + tuple(left_image.shape[1:]), device=left.device, dtype=torch.float32)
             copy_rows(left_image, imgs[:B]); copy_rows(right_image, imgs[B:])
             s2 = self.encode(imgs, both)
+            copy_rows(s2[:B].squeeze(2), cat2[:, C32:])
         lterm = self.left_term(lcat)
-        s2l = s2[:B]
         f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)
-        C32 = self.deconv4.cout
-        cat2 = torch.empty((B, C32 + s2l.shape[1], 2 * H, 2 * W), device=left.device, dtype=torch.float32)
         self._deconv(_lib.contiguous(f), self.deconv4, cat2, cat2.stride(0))
-        copy_rows(s2l.squeeze(2), cat2[:, C32:])
         g = _lib.contiguous(self._c2d(cat2.unsqueeze(2), self.concat, 1).squeeze(2))
         mask = torch.empty((B, 9, 4 * H, 4 * W), device=left.device, dtype=torch.float32)
         self._deconv(g, self.deconv2, mask, mask.stride(0))

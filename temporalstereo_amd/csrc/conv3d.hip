@@ -354,7 +354,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   const bool split = p.ksplit > 1;
   const __amdgpu_buffer_rsrc_t yr = split
       ? ig_rsrc(p.partial + (static_cast<size_t>(ks) * p.B + b) * p.Cout * oplane, p.part_bytes)
-      : ig_rsrc(y + static_cast<size_t>(b) * p.out_bstride, p.out_bytes);
+      : ig_rsrc(y + static_cast<long long>(b) * p.out_bstride, p.out_bytes);
   const unsigned ocs = split ? oplane * 4u : static_cast<unsigned>(p.out_cstride) * 4u;
   const float* ab = (MODE == MODE_HW && p.addend) ? p.addend + static_cast<size_t>(b) * p.add_bstride : nullptr;
 #pragma unroll

@@ -265,16 +265,16 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     __syncthreads();
     if (c0 + NC < kend) fetch(c0 + NC);                 // next chunk in flight under the MFMAs below
 #pragma unroll 1
-    for (int c8 = 0; c8 < NC / 8; ++c8) {               // eight channels at a time (rolled: code size)
+    for (int c8 = 0; c8 < (NC >= 8 ? NC / 8 : 1); ++c8) {   // eight channels at a time (rolled: code size); NC == 4: one quad
       const float* it = in_tile + c8 * 8 * chan_elems;
       const float* wt0 = w_tile + c8 * 8 * WP + aoff;
       if (MODE == MODE_HW) {
         // 18 steps (tap, 4 channels); the fragments of step s+1 are read from LDS before the MFMAs of
         // step s issue, so the matrix pipe never waits on an LDS round trip
-        constexpr int NS = 18;
+        constexpr int NS = (NC == 4) ? 9 : 18;
         float a[2][CB], bv[2][4];
         auto frag = [&](int s, int slot) {
-          const int tap = s >> 1, cq = s & 1;
+          const int tap = (NC == 4) ? s : (s >> 1), cq = (NC == 4) ? 0 : (s & 1);
           const int toff = (tap / 3) * DL * pitch + (tap % 3) * DL;
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb) a[slot][cb] = wt0[(tap * NC + cq * 4) * WP + cb * 16];
@@ -444,6 +444,10 @@ int launch_nc(long long wgs, const float* x, const float* w, const float* scale,
   constexpr size_t per_ch = (static_cast<size_t>(G::chan_elems) + static_cast<size_t>(KT) * WP) * sizeof(float);
   constexpr size_t lds_cu = 160 * 1024;
   const size_t per_cu = static_cast<size_t>((wgs + ts::kNumCU - 1) / ts::kNumCU);
+  if constexpr (MODE == MODE_HW) {
+    // 3-channel image layers: a 4-channel chunk (one k = 4 MFMA step per tap) instead of 8 with five zero channels
+    if (p.Cin <= 4 && p.ksplit == 1) return launch_one<CB, MODE, KT, ST, DL, 4>(x, w, scale, shift, y, p, grid, st);
+  }
   const int max_nc = g_chunk_cap;
   auto fits = [&](int nc) { return nc <= max_nc && (nc * per_ch + 16) * per_cu <= lds_cu && p.kspan >= nc; };
   if constexpr (32 * per_ch + 16 <= lds_cu) { if (fits(32)) return launch_one<CB, MODE, KT, ST, DL, 32>(x, w, scale, shift, y, p, grid, st); }

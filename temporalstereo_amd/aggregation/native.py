@@ -580,26 +580,31 @@ class NativePrecise(_LevelBase):
     def _c2d(x, f, stride, out=None):
         return conv_hw(x, f, stride, 1, out=out)
 
-    def encode(self, imgs, cat4, pair=None, s2_left=None):
-        """UNet.encoder (module.py:459-466) for the left and right images at once (stacked on the batch
-        axis, or -- batch 1 -- given as the `pair` of separate tensors); the 1/4 features go straight into
-        their channel slice of `cat4`."""
-        if pair is not None:
-            x = conv_hw(pair[0].unsqueeze(2), self.enc[0], self.enc_stride[0], 1, second=pair[1].unsqueeze(2))
+    def encode(self, left_image, right_image, cat4, s2_left):
+        """UNet.encoder (module.py:459-466) for both views without stacking them first: the left view's 1/2-resolution
+        features are written where the decoder concatenates them (`s2_left`, a channel slice, module.py:488), the 1/4
+        features of both views go straight into their channel slice of `cat4`.
+        Batch 1: every layer runs once on the two views as ONE batch of two (the batch stride handed to the kernel is
+        the distance between the two allocations).  Larger batches: the first three layers run once per view (a kernel
+        takes one batch stride), which still replaces the three stacking copies by nothing."""
+        B = left_image.shape[0]
+        e, st = self.enc, self.enc_stride
+        li, ri = left_image.unsqueeze(2), right_image.unsqueeze(2)
+        s2_right = torch.empty((B,) + tuple(s2_left.shape[1:]), device=li.device, dtype=torch.float32)
+        if B == 1:
+            x = conv_hw(li, e[0], st[0], 1, second=ri)
+            conv_hw(x[:1], e[1], st[1], 1, out=s2_left, second=x[1:], out_second=s2_right)
+            x = conv_hw(s2_left, e[2], st[2], 1, second=s2_right)
         else:
-            x = self._c2d(imgs.unsqueeze(2), self.enc[0], self.enc_stride[0])
-        if s2_left is not None:
-            # batch 1: the left view's 1/2-resolution features are written where the decoder concatenates them
-            # (module.py:488), the right view's into a buffer of their own; the next layer reads the two as a pair
-            s2_right = torch.empty((1,) + tuple(s2_left.shape[1:]), device=x.device, dtype=torch.float32)
-            conv_hw(x[:1], self.enc[1], self.enc_stride[1], 1, out=s2_left, second=x[1:], out_second=s2_right)
-            x = conv_hw(s2_left, self.enc[2], self.enc_stride[2], 1, second=s2_right)
-            s2 = None
-        else:
-            s2 = self._c2d(x, self.enc[1], self.enc_stride[1])
-            x = self._c2d(s2, self.enc[2], self.enc_stride[2])
-        self._c2d(x, self.enc[3], self.enc_stride[3], out=cat4[:, self.in_planes:].unsqueeze(2))
-        return s2
+            Hx, Wx = (li.shape[-2] - 1) // st[0] + 1, (li.shape[-1] - 1) // st[0] + 1
+            x = torch.empty((2 * B, e[0].cout, 1, Hx, Wx), device=li.device, dtype=torch.float32)
+            conv_hw(li, e[0], st[0], 1, out=x[:B]); conv_hw(ri, e[0], st[0], 1, out=x[B:])
+            conv_hw(x[:B], e[1], st[1], 1, out=s2_left); conv_hw(x[B:], e[1], st[1], 1, out=s2_right)
+            Hy, Wy = (s2_left.shape[-2] - 1) // st[2] + 1, (s2_left.shape[-1] - 1) // st[2] + 1
+            y = torch.empty((2 * B, e[2].cout, 1, Hy, Wy), device=li.device, dtype=torch.float32)
+            conv_hw(s2_left, e[2], st[2], 1, out=y[:B]); conv_hw(s2_right, e[2], st[2], 1, out=y[B:])
+            x = y
+        self._c2d(x, e[3], st[3], out=cat4[:, self.in_planes:].unsqueeze(2))
 
     def _deconv(self, x, f, out, out_bstride):
         B, Cin, H, W = x.shape
@@ -618,13 +623,7 @@ class NativePrecise(_LevelBase):
         copy_rows(left, lcat[:, :Cf]); copy_rows(right, rcat[:, :Cf])
         C32, C2 = self.deconv4.cout, self.enc[1].cout
         cat2 = torch.empty((B, C32 + C2, 2 * H, 2 * W), device=left.device, dtype=torch.float32)      # [deconv4 | s2 of the left view]
-        if B == 1:                 # the two views as one batch of two without stacking them (three launches fewer)
-            self.encode(None, both, pair=(left_image, right_image), s2_left=cat2[:, C32:].unsqueeze(2))
-        else:
-            imgs = torch.empty((2 * B,) + tuple(left_image.shape[1:]), device=left.device, dtype=torch.float32)
-            copy_rows(left_image, imgs[:B]); copy_rows(right_image, imgs[B:])
-            s2 = self.encode(imgs, both)
-            copy_rows(s2[:B].squeeze(2), cat2[:, C32:])
+        self.encode(left_image, right_image, both, cat2[:, C32:].unsqueeze(2))
         lterm = self.left_term(lcat)
         f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)
         self._deconv(_lib.contiguous(f), self.deconv4, cat2, cat2.stride(0))

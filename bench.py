@@ -259,7 +259,8 @@ def main():
             return net(*inputs, {})
 
     with K1Probe() as k1:
-        out = step()            # set-up, not a benchmark step: records the launch plan / captures the graph
+        for _ in range(depth):  # set-up, not benchmark steps: record the launch plan of every buffer set / capture the graph
+            out = step()
         torch.cuda.synchronize()
         for _ in range(a.warmup):
             out = step()

@@ -391,22 +391,26 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   }
 }
 
-// sums the split-K partials in a fixed order (deterministic) and applies scale / shift / activation
+// sums the split-K partials in a fixed order (deterministic) and applies scale / shift / activation.
+// grid.y = (batch element, output channel): no 64-bit division per element
 __global__ void __launch_bounds__(256)
 conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ scale, const float* __restrict__ shift,
                    float* __restrict__ y, int B, int Cout, long long plane, int ksplit, int act, float act_param,
                    long long out_bstride, long long out_cstride, const float* __restrict__ addend, long long add_bstride,
                    long long hw_o) {
+  const int bc = blockIdx.y;
+  const int co = bc % Cout, b = bc / Cout;
   const long long n = static_cast<long long>(B) * Cout * plane;
-  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
-       i += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const long long px = i % plane;
-    const long long t = i / plane;
-    const int co = static_cast<int>(t % Cout), b = static_cast<int>(t / Cout);
+  const float* pp = partial + static_cast<long long>(bc) * plane;
+  float* yp = y + b * out_bstride + co * out_cstride;
+  const float* ap = addend ? addend + b * add_bstride + co * hw_o : nullptr;
+  const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+  const unsigned uplane = static_cast<unsigned>(plane), uhw = static_cast<unsigned>(hw_o);
+  for (unsigned px = blockIdx.x * blockDim.x + threadIdx.x; px < uplane; px += gridDim.x * blockDim.x) {
     float v = 0.f;
-    for (int k = 0; k < ksplit; ++k) v += partial[k * n + i];
-    if (addend) v += addend[b * add_bstride + co * hw_o + px % hw_o];
-    y[b * out_bstride + co * out_cstride + px] = apply_act(v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f), act, act_param, co);
+    for (int k = 0; k < ksplit; ++k) v += pp[k * n + px];
+    if (ap) v += ap[px % uhw];
+    yp[px] = apply_act(v * sc + sh, act, act_param, co);
   }
 }
 
@@ -742,9 +746,11 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
   else rc = launch_ig<MODE_HW, 9, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, D, st);
   if (rc || !split) return rc;
   const long long plane = static_cast<long long>(D) * p.Ho * p.Wo;
-  long long blocks = (static_cast<long long>(B) * Cout * plane + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(conv_splitk_finish, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, p.partial, scale, shift, y,
+  TS_REQUIRE(static_cast<long long>(B) * Cout <= 65535 && plane < (1ll << 31), TS_ERR_UNSUPPORTED, "conv3d_hw: split-K finish grid too large");
+  long long blocks = (plane + 255) / 256;
+  const long long cap = (4096 + static_cast<long long>(B) * Cout - 1) / (static_cast<long long>(B) * Cout);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(conv_splitk_finish, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(B * Cout)), dim3(256), 0, st, p.partial, scale, shift, y,
                      B, Cout, plane, ksplit, act, act_param, out_bstride, out_cstride, addend, addend_bstride,
                      static_cast<long long>(p.Ho) * p.Wo);
   return ts::launched("conv_splitk_finish");

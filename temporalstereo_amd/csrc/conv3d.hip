@@ -81,12 +81,13 @@ struct IG {
 
 template <int MODE, int KT, int ST, int DL>
 struct Geom {
-  static constexpr int RR = (MODE == MODE_D) ? 1 : (ST == 2 ? 5 : 3);   // rows / column groups each thread
-  static constexpr int QC = (MODE == MODE_D) ? 1 : (ST == 2 ? 2 : 1);   // stages per channel
   static constexpr int NTR = (MODE == MODE_D) ? KT : 1;                 // planes staged per channel (MODE_D)
   static constexpr int in_rows = (MODE == MODE_HW) ? 7 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 10 : 9) : 1);
   static constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 34 : 33) : 256);
   static constexpr int pitch = (MODE == MODE_D) ? 256 : (in_cols | 1);
+  // staged elements per thread and channel: the tile is dealt linearly to the 256 threads (a (row, column-of-64) deal
+  // wasted over half of the load slots on a 10 x 34 tile)
+  static constexpr int RQ_HW = (in_rows * in_cols + 255) / 256;
   static constexpr int chan_raw = (MODE == MODE_D) ? NTR * 256 : in_rows * pitch;
   static constexpr int pad0 = (16 - (chan_raw & 31)) & 31;
   // == 16 (mod 32): the four k-slots of a B fragment sit on disjoint banks; >= 1 spare word (dump slot)
@@ -106,7 +107,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using G = Geom<MODE, KT, ST, DL>;
   constexpr int WP = (CB * 16) | 16;                  // weight row pitch (k-slots on disjoint banks)
-  constexpr int RR = G::RR, QC = G::QC, NTR = G::NTR, RQ = NTR * RR * QC;
+  constexpr int NTR = G::NTR, RQ = (MODE == MODE_D) ? NTR : G::RQ_HW;
   constexpr int in_rows = G::in_rows, in_cols = G::in_cols, pitch = G::pitch, chan_elems = G::chan_elems;
   constexpr int WV = KT * NC * CB * 4;                // 16-byte weight vectors per chunk
   constexpr int RWN = (WV + 255) / 256;
@@ -160,7 +161,6 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 
   // ---- staging geometry of this thread: where each of its RQ elements of a channel comes from (byte
   // offset inside the batch element, kOOB = zero padding) and where it goes in the LDS channel tile ----
-  const int tcol = threadIdx.x & 63, trow = threadIdx.x >> 6;
   unsigned goff[RQ];
   int loff[RQ];
   if (MODE == MODE_D) {
@@ -172,16 +172,14 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < RR; ++r) {
-      const int cy = trow + 4 * r, gy = iy0 + cy;
-#pragma unroll
-      for (int q = 0; q < QC; ++q) {
-        const int cx = tcol + 64 * q, gx = ix0 + cx;
-        const bool slot = cy < in_rows && cx < in_cols;
-        const bool live = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        goff[r * QC + q] = live ? (static_cast<unsigned>(od) * HW + static_cast<unsigned>(gy) * p.W + gx) * 4u : kOOB;
-        loff[r * QC + q] = slot ? cy * pitch + cx : G::chan_raw;             // dump slot in the channel padding
-      }
+    for (int q = 0; q < RQ; ++q) {
+      const int e = static_cast<int>(threadIdx.x) + 256 * q;
+      const bool slot = e < in_rows * in_cols;
+      const int cy = e / in_cols, cx = e - cy * in_cols;
+      const int gy = iy0 + cy, gx = ix0 + cx;
+      const bool live = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      goff[q] = live ? (static_cast<unsigned>(od) * HW + static_cast<unsigned>(gy) * p.W + gx) * 4u : kOOB;
+      loff[q] = slot ? cy * pitch + cx : G::chan_raw;                        // dump slot in the channel padding
     }
   }
   // weights: vector v of a chunk = 4 consecutive output channels of (tap, ci)

@@ -160,23 +160,23 @@ def coarse_level(sv, left, right, prev_info, num_sample, delta=1.0, scales=3, to
     """coarse.py:77-116."""
     B, _, H, W = left.shape
     raw = block_cost(left, right, int(num_sample), scales)
-    ds = torch.linspace(0, num_sample - 1, num_sample).view(1, num_sample, 1, 1).expand(B, num_sample, H, W)
-    vol = init3d(sv.sub("init3d"), raw)
-    vol, ds, order = merge_memory(sv, vol, ds, prev_info, topk, resize_to=(H, W))
-    if fusion:
-        vol = pyramid_fusion(sv.sub("fuse"), vol)
+    ds0 = torch.linspace(0, num_sample - 1, num_sample, dtype=left.dtype).view(1, num_sample, 1, 1).expand(B, num_sample, H, W)
+    init = init3d(sv.sub("init3d"), raw)
+    merged, ds, order = merge_memory(sv, init, ds0, prev_info, topk, resize_to=(H, W))
+    vol = pyramid_fusion(sv.sub("fuse"), merged) if fusion else merged
     cost, off = prediction_heads(sv.sub("pred_heads"), vol, delta)
     disp, _, _ = topk_softargmax(cost, ds, off, k=topk)
     up = convex_upsample(sv.sub("convex_upsample"), left, disp)
     if trace is not None:
-        trace.update(coarse_raw=raw, coarse_order=order, coarse_disp_lowres=disp)
+        trace.update(coarse_raw=raw, coarse_order=order, coarse_disp_lowres=disp, coarse_init=init, coarse_ds0=ds0,
+                     coarse_merged=merged, coarse_fused=vol, coarse_cost=cost, coarse_off=off, coarse_ds=ds, coarse_up=up)
     return up, cost, off, ds
 
 
 def candidates_in_range(low, high):
     """fine.py:82-87 / precise.py:73-78: |high-low| * {0,3,4,5,8}/8 + min(low,high)."""
-    steps = torch.tensor([0., 3., 4., 5., 8.])
-    steps = (steps / steps.max()).view(1, 5, 1, 1).to(low.dtype)
+    steps = torch.tensor([0., 3., 4., 5., 8.], dtype=low.dtype)
+    steps = (steps / steps.max()).view(1, 5, 1, 1)
     return torch.abs(high - low) * steps + torch.min(low, high)
 
 
@@ -188,16 +188,17 @@ def fine_level(sv, left, right, low, high, prev_info, delta=1.0, scales=3, topk=
     if lm is not None and prev_info.get('local_map_size', 0) > 0:
         lm = F.interpolate(lm * W / lm.shape[-1], size=(H, W), mode='bilinear', align_corners=True)
         ds = torch.cat([lm, ds], dim=1)
-    raw = block_cost(left, right, ds, scales)
-    vol = init3d(sv.sub("init3d"), raw)
-    vol, ds, order = merge_memory(sv, vol, ds, prev_info, topk)
-    if fusion:
-        vol = pyramid_fusion(sv.sub("fuse"), vol)
+    ds0 = ds
+    raw = block_cost(left, right, ds0, scales)
+    init = init3d(sv.sub("init3d"), raw)
+    merged, ds, order = merge_memory(sv, init, ds0, prev_info, topk)
+    vol = pyramid_fusion(sv.sub("fuse"), merged) if fusion else merged
     cost, off = prediction_heads(sv.sub("pred_heads"), vol, delta)
     disp, _, _ = topk_softargmax(cost, ds, off, k=topk)
     up = convex_upsample(sv.sub("convex_upsample"), left, disp)
     if trace is not None:
-        trace.update(fine_raw=raw, fine_order=order, fine_disp_lowres=disp)
+        trace.update(fine_raw=raw, fine_order=order, fine_disp_lowres=disp, fine_low=low, fine_high=high, fine_ds0=ds0,
+                     fine_init=init, fine_merged=merged, fine_fused=vol, fine_cost=cost, fine_off=off, fine_ds=ds, fine_up=up)
     return up, cost, off, ds
 
 
@@ -246,7 +247,9 @@ def precise_level(sv, left, right, low, high, left_img, right_img, prev_info, de
         'cost_volume': F.interpolate(mem_v, scale_factor=1 / 2, mode='bilinear', align_corners=True),
     }
     if trace is not None:
-        trace.update(precise_raw=raw)
+        trace.update(precise_raw=raw, precise_low=low, precise_high=high, precise_left=left, precise_right=right,
+                     precise_s2l=s2l, precise_init=vol, precise_cost=cost, precise_off=off, precise_ds=ds,
+                     precise_disp_lowres=disp, precise_mem_s=mem_s, precise_mem_v=mem_v, precise_full=full)
     return full, disp, cost, off, ds
 
 

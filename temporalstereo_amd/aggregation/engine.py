@@ -123,6 +123,8 @@ class InferenceEngine:
         if any(p.device.type != "cuda" for p in net.parameters()):
             raise RuntimeError("InferenceEngine needs the module on the GPU (there is no CPU path)")
         net = net.eval()
+        self.module = net
+        self.device = next(net.parameters()).device
         if backend == "native":
             from .native import NativeAggregator
             self.net = NativeAggregator(net, private_streams=private_streams)
@@ -141,6 +143,45 @@ class InferenceEngine:
         self.pipeline = pipeline
         self._slot_of = {}          # one named event per recorded plan: "the pass that last used these buffers is done"
         self._turn = {}
+        # The native backend works on FOLDED COPIES of the weights and every recorded plan bakes in pointers to them:
+        # a load_state_dict / optimizer step / .to() after construction must re-fold (demo.py:250 of the reference loads
+        # the checkpoint after building the model).  Exact trigger: a load_state_dict hook; cheap per-call check: the
+        # (storage, version) stamp of a spread of sentinel tensors -- every in-place update of the whole model (optimizer
+        # step, load_state_dict's copy_) bumps all versions, .to() moves all storages; an edit of a single tensor by
+        # hand is what refresh() is for.
+        self._tensors = list(net.parameters()) + list(net.buffers())
+        self._sentinels = self._tensors[::16] + self._tensors[-1:]
+        self._stamp = self._weights_stamp()
+        self._stale = False
+        self._hook = net.register_load_state_dict_post_hook(self._on_load_state_dict)
+
+    def _on_load_state_dict(self, module, incompatible_keys):
+        self._stale = True
+
+    def _weights_stamp(self, full=False):
+        return tuple((t.data_ptr(), t._version) for t in (self._tensors if full else self._sentinels))
+
+    def refresh(self):
+        """Re-read the module's parameters and buffers: re-folds BatchNorm / re-lays the weights (native backend) and
+        drops every recorded plan / captured graph (their baked-in pointers and constants are stale).  Called
+        automatically when the weights are seen to have changed; call it yourself after editing single tensors."""
+        if self.module.training:
+            raise RuntimeError("InferenceEngine runs the eval-mode (folded BatchNorm) pass: call module.eval() first")
+        dev = next(self.module.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("InferenceEngine needs the module on the GPU (there is no CPU path)")
+        torch.cuda.synchronize(self.device)        # passes still in flight read the buffers about to be dropped
+        self.device = dev
+        if self.backend == "native":
+            self.net.device = dev
+            with torch.cuda.device(dev):
+                self.net._build(self.module)
+        self._graphs.clear()
+        self._turn.clear()
+        self._tensors = list(self.module.parameters()) + list(self.module.buffers())
+        self._sentinels = self._tensors[::16] + self._tensors[-1:]
+        self._stamp = self._weights_stamp()
+        self._stale = False
 
     def _capture(self, args):
         static_in = args if self.bind else _clone_static(args)
@@ -171,13 +212,22 @@ class InferenceEngine:
         return _Recorded(rec, static_in, out)
 
     def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):
+        if self._stale or self._weights_stamp() != self._stamp:
+            self.refresh()
+        with torch.cuda.device(self.device):
+            return self._run(left_feats, right_feats, left_image, right_image, prev_info)
+
+    def _run(self, left_feats, right_feats, left_image, right_image, prev_info):
         state = {k: v for k, v in prev_info.items()
                  if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}
         args = (list(left_feats), list(right_feats), left_image, right_image, state)
         if self.replay == "eager":
             with torch.no_grad():
                 return self.net(args[0], args[1], args[2], args[3], dict(prev_info))
-        sig = _sig_of(args) + ((_ptrs_of(args),) if self.bind else ())
+        # a replay is tied to what it was recorded on: shapes, (bound) storages, and the caller's stream -- the plan's
+        # launches and cross-stream edges name that stream, and the copies into / reads out of the static buffers are
+        # ordered with the replay only on it
+        sig = _sig_of(args) + ((_ptrs_of(args),) if self.bind else ()) + (torch.cuda.current_stream().cuda_stream,)
         if self.pipeline > 1:                      # double-buffered plans, used alternately
             turn = self._turn.get(sig, 0)
             self._turn[sig] = (turn + 1) % self.pipeline

@@ -177,11 +177,15 @@ class Folded:
         shift = torch.zeros(pad, device=w.device)
         b = bias.detach().float() if bias is not None else torch.zeros(cout, device=w.device)
         if bn is not None:
-            if not isinstance(bn, (nn.BatchNorm2d, nn.BatchNorm3d)):
-                raise NotImplementedError("only BatchNorm can be folded, got %r" % (bn,))
-            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            # any running-statistics BatchNorm folds exactly in eval mode, nn.SyncBatchNorm (what dist.sync_batchnorm /
+            # Lightning's sync_batchnorm=True leave behind after data-parallel training) included
+            if not isinstance(bn, nn.modules.batchnorm._BatchNorm) or bn.running_mean is None:
+                raise NotImplementedError("only BatchNorm with running statistics can be folded, got %r" % (bn,))
+            gamma = bn.weight.detach().float() if bn.affine else torch.ones(cout, device=w.device)
+            beta = bn.bias.detach().float() if bn.affine else torch.zeros(cout, device=w.device)
+            s = gamma / torch.sqrt(bn.running_var.detach().float() + bn.eps)
             scale[:cout] = s
-            shift[:cout] = bn.bias.detach().float() + (b - bn.running_mean.detach().float()) * s
+            shift[:cout] = beta + (b - bn.running_mean.detach().float()) * s
         else:
             shift[:cout] = b
         self.scale, self.shift = scale.contiguous(), shift.contiguous()
@@ -505,10 +509,12 @@ class _MergingLevel(_LevelBase):
         self.fusion = mod.spatial_fusion
         if self.fusion:
             self.conv5 = fold_wrapper(mod.fuse.conv_5x5, "d")
-            self.fuse = SepConv(mod.fuse.conv_fuse)
+            self.fuse_conv = SepConv(mod.fuse.conv_fuse)
         self.up = ConvexUp(mod.convex_upsample)
 
-    def merge_fuse_predict(self, vol, samples, prev_info, feat, resize_memory, mask=None, next_range=None):
+    def merge(self, vol, samples, prev_info, resize_memory):
+        """coarse.py:84-105 / fine.py:105-122 -> (cat4, sorted candidates): the merged, D-sorted volume sits in the first C
+        channels of `cat4`, whose other 3C channels PyramidFusion fills (module.py:412-421)."""
         B, C, D0, H, W = vol.shape
         K = self.topk
         memory = prev_info.get('cost_memory', None)
@@ -528,16 +534,24 @@ class _MergingLevel(_LevelBase):
                                                 _lib.ptr(self.past_w), _lib.ptr(self.past_scale), _lib.ptr(self.past_shift),
                                                 _lib.ptr(samp), _lib.ptr(x0), B, C, D0, K, H, W, vb, vc, ob, oc, _stream())
         _lib.check(rc, "ts_merge_candidates_fwd")
-        if self.fusion:                                                 # PyramidFusion, module.py:412-421
-            br = Branch("pool")
-            with br:
-                pool5(x0, cat4[:, 2 * C:3 * C], cat4[:, 3 * C:])
-            conv_d(x0, self.conv5, 5, 1, 1, 2, out=cat4[:, C:2 * C])
-            br.join()
-            y = self.fuse(cat4)
-        else:
-            y = x0
-        cost, off = self.heads(y)
+        return cat4, samp
+
+    def fuse(self, cat4):
+        """PyramidFusion (module.py:412-421) on the merged volume in cat4[:, :C]; without spatial fusion the volume itself."""
+        C = self.C
+        x0 = cat4[:, :C]
+        if not self.fusion:
+            return x0
+        br = Branch("pool")
+        with br:
+            pool5(x0, cat4[:, 2 * C:3 * C], cat4[:, 3 * C:])
+        conv_d(x0, self.conv5, 5, 1, 1, 2, out=cat4[:, C:2 * C])
+        br.join()
+        return self.fuse_conv(cat4)
+
+    def merge_fuse_predict(self, vol, samples, prev_info, feat, resize_memory, mask=None, next_range=None):
+        cat4, samp = self.merge(vol, samples, prev_info, resize_memory)
+        cost, off = self.heads(self.fuse(cat4))
         disp, _, _ = TF.topk_softargmax(cost, samp, off, k=self.topk)
         if callable(mask):
             mask = mask()                    # produced on another stream: the callable joins it
@@ -657,15 +671,22 @@ class NativeAggregator:
             raise RuntimeError("NativeAggregator folds BatchNorm: put the module in eval() first")
         if any(p.device.type != "cuda" for p in net.parameters()):
             raise RuntimeError("NativeAggregator needs the module on the GPU (there is no CPU path)")
-        self.coarse, self.fine, self.precise = NativeCoarse(net.coarse), NativeFine(net.fine), NativePrecise(net.precise)
         # The coarse and fine levels are a chain of ~70 small kernels (grids of 50-500 workgroups) that
         # leave most of the 256 CUs idle; the disparity-independent half of the refinement UNet is
         # ~0.6 ms of wide kernels.  The chain runs on a HIGH-priority stream so that its workgroups are
         # dispatched ahead of the wide kernels' (which fill whatever is left) and both finish together.
         dev = next(net.parameters()).device
+        self.device = dev
+        with torch.cuda.device(dev):
+            self._build(net)
         self.fast, self.aux = qualified_streams(dev, 2, private=private_streams)
         self.pipeline_slot = None            # set by the engine while it records one of its double-buffered plans
         self.overlap = True
+
+    def _build(self, net):
+        """Fold BatchNorm / bias into per-channel scale and shift and re-lay the weights out for the kernels.  The
+        result is a private COPY of the parameters: call again (InferenceEngine.refresh does) after they change."""
+        self.coarse, self.fine, self.precise = NativeCoarse(net.coarse), NativeFine(net.fine), NativePrecise(net.precise)
 
     def _coarse_level(self, l16, r16, prev_info, out, mask=None):
         rng = 4
@@ -718,6 +739,12 @@ class NativeAggregator:
 
     @torch.no_grad()
     def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):
+        if left_image.device != self.device:
+            raise RuntimeError("NativeAggregator lives on %s, inputs are on %s" % (self.device, left_image.device))
+        with torch.cuda.device(self.device):      # the launch stream is the CURRENT device's current stream
+            return self._pass(left_feats, right_feats, left_image, right_image, prev_info)
+
+    def _pass(self, left_feats, right_feats, left_image, right_image, prev_info):
         l4, l8, l16 = left_feats
         r4, r8, r16 = right_feats
         out = ([], [], [], [], [])

@@ -136,16 +136,22 @@ extern "C" int ts_plan_run(ts_plan* plan) {
 // `to_stream` waits for everything enqueued so far on `from_stream` (fork and join are the same edge)
 extern "C" int ts_stream_fork(void* from_stream, void* to_stream) {
   constexpr int kRing = 64;                       // a wait is enqueued right after its record, so reuse is safe
-  static thread_local hipEvent_t ring[kRing];
-  static thread_local int made = 0, next = 0;
-  if (made < kRing && next == made) {
-    hipError_t e = hipEventCreateWithFlags(&ring[made], hipEventDisableTiming);
+  constexpr int kMaxDev = 16;                     // an event belongs to the device it was created on: one ring per device
+  struct Ring { hipEvent_t ev[kRing]; int made = 0, next = 0; };
+  static thread_local Ring rings[kMaxDev];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return ts::fail(static_cast<int>(e), "stream_fork: %s", hipGetErrorString(e));
+  TS_REQUIRE(dev >= 0 && dev < kMaxDev, TS_ERR_UNSUPPORTED, "stream_fork: device %d", dev);
+  Ring& r = rings[dev];
+  if (r.made < kRing && r.next == r.made) {
+    e = hipEventCreateWithFlags(&r.ev[r.made], hipEventDisableTiming);
     if (e != hipSuccess) return ts::fail(static_cast<int>(e), "stream_fork: %s", hipGetErrorString(e));
-    ++made;
+    ++r.made;
   }
-  hipEvent_t ev = ring[next];
-  next = (next + 1) % kRing;
-  hipError_t e = hipEventRecord(ev, ts::as_stream(from_stream));
+  hipEvent_t ev = r.ev[r.next];
+  r.next = (r.next + 1) % kRing;
+  e = hipEventRecord(ev, ts::as_stream(from_stream));
   if (e == hipSuccess) e = hipStreamWaitEvent(ts::as_stream(to_stream), ev, 0);
   if (e != hipSuccess) return ts::fail(static_cast<int>(e), "stream_fork: %s", hipGetErrorString(e));
   return TS_OK;

@@ -52,67 +52,107 @@ class GradientBuckets:
     """Bucketed, backward-overlapped gradient averaging.
 
         gb = GradientBuckets(model.parameters())
-        loss.backward()          # hooks fire, buckets are all-reduced asynchronously
+        loss.backward()          # hooks fire, full buckets are all-reduced asynchronously
         gb.finish()              # wait, average, scatter back into .grad
-    """
+
+    One backward per finish (gradient accumulation: call backward under `gb.paused()` for all but the last
+    micro-batch).  Parameters that are not part of the autograd graph (FineAggregation.phi is declared but never
+    used, fine.py:34) would keep their bucket from ever filling, so the first step finds them -- every rank
+    agrees on the set through one MAX all-reduce of the "fired" flags -- and the buckets are rebuilt without
+    them; their .grad stays None, as it does in the reference (Lightning's DDP runs with
+    find_unused_parameters)."""
 
     def __init__(self, params, bucket_bytes=32 << 20, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_bytes = bucket_bytes
         self.params = [p for p in params if p.requires_grad]
+        self._unused_known = False
+        self._paused = False
+        self.launched_in_backward = 0         # buckets whose all-reduce went out before finish() (overlap evidence)
+        self._layout(self.params)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _layout(self, params):
         # reverse registration order ~ the order gradients become ready in backward
-        order = list(reversed(self.params))
+        order = list(reversed(params))
         self.buckets, cur, cur_bytes = [], [], 0
         for p in order:
             nbytes = p.numel() * p.element_size()
-            if cur and cur_bytes + nbytes > bucket_bytes:
+            if cur and cur_bytes + nbytes > self.bucket_bytes:
                 self.buckets.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
             self.buckets.append(cur)
-        self._where = {}
-        self._flat, self._pending, self._ready = [], [], []
+        self._where, self._flat, self._ready = {}, [], []
         for bi, bucket in enumerate(self.buckets):
             n = sum(p.numel() for p in bucket)
             self._flat.append(torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device))
             off = 0
             for p in bucket:
-                self._where[p] = (bi, off)
+                self._where[id(p)] = (bi, off)
                 off += p.numel()
             self._ready.append(0)
         self._handles = [None] * len(self.buckets)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._fired = set()
+
+    def paused(self):
+        """Context manager: backward passes inside accumulate into .grad without communication."""
+        gb = self
+
+        class _P:
+            def __enter__(self_):
+                gb._paused = True
+
+            def __exit__(self_, *exc):
+                gb._paused = False
+                return False
+        return _P()
 
     def _on_grad(self, p):
-        if self.world == 1:
+        if self.world == 1 or self._paused:
             return
-        bi, off = self._where[p]
+        if id(p) in self._fired:
+            raise RuntimeError("GradientBuckets: a second backward() before finish() -- accumulate under gb.paused()")
+        self._fired.add(id(p))
+        if id(p) not in self._where:          # declared unused on the first step, used now
+            raise RuntimeError("GradientBuckets: a parameter that received no gradient on the first step received one now")
+        bi, off = self._where[id(p)]
         self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
         self._ready[bi] += 1
         if self._ready[bi] == len(self.buckets[bi]):
             self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.launched_in_backward += 1
 
     def finish(self):
-        """Wait for every bucket, write the averaged gradients back.  Parameters that received no
-        gradient this step (unused branches) are treated as zeros so that all ranks stay in step."""
+        """Wait for every bucket, write the averaged gradients back."""
         if self.world == 1:
             return
+        first = not self._unused_known
+        if first:
+            # which parameters take part: agreed across ranks (a parameter used on any rank is reduced on all)
+            flags = torch.tensor([1.0 if id(p) in self._fired else 0.0 for p in self.params], device=self.params[0].device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+            used = [p for p, f in zip(self.params, flags.tolist()) if f > 0]
+            used_ids = {id(p) for p in used}
         for bi, bucket in enumerate(self.buckets):
             if self._handles[bi] is None:
                 for p in bucket:
-                    _, off = self._where[p]
+                    _, off = self._where[id(p)]
                     if p.grad is None:
                         self._flat[bi][off:off + p.numel()].zero_()
-                    elif self._ready[bi] < len(bucket):
+                    elif id(p) not in self._fired or self._ready[bi] < len(bucket):
                         self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
                 self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for bi, bucket in enumerate(self.buckets):
             self._handles[bi].wait()
             self._flat[bi].div_(self.world)
             for p in bucket:
-                _, off = self._where[p]
+                if first and id(p) not in used_ids:
+                    continue                                      # outside the graph on every rank: .grad stays None
+                _, off = self._where[id(p)]
                 g = self._flat[bi][off:off + p.numel()].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
@@ -120,6 +160,11 @@ class GradientBuckets:
                     p.grad.copy_(g)
             self._handles[bi] = None
             self._ready[bi] = 0
+        self._fired = set()
+        if first:
+            self._unused_known = True
+            if len(used) != len(self.params):
+                self._layout(used)
 
     def remove(self):
         for h in self._hooks:

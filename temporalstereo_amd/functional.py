@@ -19,6 +19,11 @@ _k1_probe = None
 
 
 def _require_gpu(*tensors):
+    """fp32 tensors of ONE GPU, and that GPU is the current device: the launch stream is the current device's
+    current stream (`_stream`), so an op on tensors of another device would be enqueued on the wrong GPU's queue,
+    unordered against the framework's work on theirs.  Callers on a non-current device wrap the call in
+    `with torch.cuda.device_of(tensor):` (NativeAggregator / InferenceEngine do)."""
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -27,6 +32,13 @@ def _require_gpu(*tensors):
                                "there is deliberately no CPU fallback" % t.device)
         if t.dtype != torch.float32:
             raise TypeError("temporalstereo_amd ops are fp32 (got %s)" % t.dtype)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("temporalstereo_amd op got tensors on different devices (%s and %s)" % (dev, t.device))
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError("temporalstereo_amd op on %s while the current device is cuda:%d: wrap the call in "
+                           "`with torch.cuda.device_of(tensor):`" % (dev, torch.cuda.current_device()))
 
 
 class _BlockCost(torch.autograd.Function):
@@ -754,8 +766,9 @@ def reproject_memory(prev_disp, mem_disp, mem_cost, local_map, n_local_out, K, T
 
 def project_to_3d(depth, K, inv_K=None, T_target_to_source=None, eps=1e-7):
     """project_to_3d of the reference (layers/inverse_warp.py:92-178), forward only (the project
-    calls it on detached tensors).  Returns triangular_depth / optical_flow / flow_mask /
-    src_pixel_coord; homo_points_3d is not produced (no caller on the hot path reads it)."""
+    calls it on detached tensors).  Returns triangular_depth / optical_flow / flow_mask;
+    homo_points_3d and src_pixel_coord (= optical_flow + the pixel grid) are not produced: no caller
+    on the hot path reads them."""
     if T_target_to_source is None:
         raise NotImplementedError("the hot path always passes T_target_to_source")
     _require_gpu(depth, K, T_target_to_source)

@@ -71,3 +71,38 @@ def test_shard_units():
     assert shard_units(10, 0, 4) == [0, 4, 8] and shard_units(10, 3, 4) == [3, 7]
     assert shard_units(10, 1, 4, drop_last=True) == [1, 5]
     assert sorted(sum((shard_units(7, r, 3) for r in range(3)), [])) == list(range(7))
+
+
+def _unused_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from temporalstereo_amd import dist as tsd
+    tsd.init_distributed("gloo")
+    model = _model()
+    model.phi = nn.Parameter(torch.zeros(1))          # declared, never used (FineAggregation.phi, fine.py:34)
+    model[0].norm.eval()
+    tsd.broadcast_parameters(model)
+    x, y = _data(4)
+    mine = tsd.shard_units(4, rank, world)
+    gb = tsd.GradientBuckets(model.parameters(), bucket_bytes=1 << 20)
+    launched = []
+    for step in range(2):
+        model.zero_grad(set_to_none=True)
+        ((model(x[mine]) - y[mine]) ** 2).mean().backward()
+        launched.append(gb.launched_in_backward)
+        gb.finish()
+        assert model.phi.grad is None                 # outside the graph on every rank: stays None, as in the reference
+    # step 0 cannot fill the bucket (phi never fires); from step 1 on the all-reduce goes out during backward
+    assert launched == [0, 1], launched
+    with pytest.raises(RuntimeError):                 # a second backward without finish() is refused, not silently dropped
+        ((model(x[mine]) - y[mine]) ** 2).mean().backward()
+        ((model(x[mine]) - y[mine]) ** 2).mean().backward()
+    if rank == 0:
+        torch.save({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_buckets_drop_unused_parameters_and_overlap_from_the_second_step(tmp_path):
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_unused_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert "phi" not in torch.load(out)

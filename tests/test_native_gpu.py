@@ -325,3 +325,42 @@ def test_engine_passes_in_flight_match_plain_engine(depth):
         last = eng(*bound, {})
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(last[0], want_b))
+
+
+def test_engine_refolds_after_load_state_dict_and_inplace_updates():
+    """The engine works on folded copies of the weights (and plans bake pointers to them): loading a checkpoint or
+    stepping an optimizer AFTER construction (demo.py:250 of the reference loads after building) must be seen."""
+    import synth
+    from helpers import load, dims_from_golden, synth_state, aggregator_inputs
+    import temporalstereo_amd as ts
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    dev = torch.device("cuda:0")
+    g = load("agg_tiny_single")
+    dims = dims_from_golden(g)
+    mk = lambda: ts.TEMPORALSTEREO(
+        coarse=ts.CoarseAggregation(dims['coarse']['in_planes'], dims['coarse']['C'], dims['coarse']['num_sample']),
+        fine=ts.FineAggregation(dims['fine']['in_planes'], dims['fine']['C'], 5),
+        precise=ts.PreciseAggregation(dims['precise']['in_planes'], dims['precise']['C'], 5)).to(dev).eval()
+    lf, rf, il, ir, prev = aggregator_inputs(g, dims, dev)
+    net = mk()                                                  # random initial weights
+    eng = InferenceEngine(net, backend="native", replay="plan")
+    before = eng(lf, rf, il, ir, dict(prev))[0][0].clone()
+    net.load_state_dict(synth_state(dims, int(g["seed"]), golden=g), strict=True)     # the checkpoint arrives afterwards
+    after = eng(lf, rf, il, ir, dict(prev))[0][0].clone()
+    ref = torch.from_numpy(g["disp_full"]).to(dev)
+    assert float((after - ref).abs().mean()) < 1e-3, "engine kept the weights it was built with"
+    assert float((before - ref).abs().mean()) > 1e-2
+    with torch.no_grad():                                       # an optimizer-style in-place update of every tensor
+        for p in net.parameters():
+            p.mul_(1.01)
+    moved = eng(lf, rf, il, ir, dict(prev))[0][0].clone()
+    fresh = InferenceEngine(net, backend="native", replay="plan")(lf, rf, il, ir, dict(prev))[0][0]
+    assert float((moved - fresh).abs().max()) == 0.0
+    assert float((moved - after).abs().mean()) > 0.0
+
+
+def test_ops_refuse_cpu_and_mixed_inputs():
+    import temporalstereo_amd as ts
+    x = torch.zeros(1, 8, 4, 8)
+    with pytest.raises(RuntimeError):
+        ts.block_cost(x, x, 3, 3)

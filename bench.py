@@ -76,15 +76,16 @@ def make_inputs(dev, seed, B, hw=None):
     return [to(x) for x in lf], [to(x) for x in rf], to(il), to(ir)
 
 
-def calibrate_batchnorm(net, inputs):
+def calibrate_batchnorm(net, inputs, prev_info=None):
     """One train-mode pass with momentum 1: running statistics := this input's batch statistics, so
-    the random-weight network is conditioned like a trained one (same protocol as tools/gen_golden.py)."""
+    the random-weight network is conditioned like a trained one (same protocol as tools/gen_golden.py).
+    prev_info: temporal state of the frame (a temporal model's statistics come from temporal frames)."""
     bns = [m for m in net.modules() if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))]
     for m in bns:
         m.momentum = 1.0
     net.train(True)
     with torch.no_grad():
-        net(*inputs, {})
+        net(*inputs, dict(prev_info or {}))
     for m in bns:
         m.momentum = 0.1
     net.train(False)

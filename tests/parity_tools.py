@@ -1,4 +1,4 @@
-"""Full-size parity harness shared by tests/test_stagewise_gpu.py and tools/parity_report.py (not collected).
+"""Full-size parity harness shared by tests/test_fullsize_gpu.py and tools/parity_report.py (not collected).
 
 BASELINE.json's configurations at their STATED batches, as sequences: every frame is one oracle pass (CPU, `trace` of
 every stage boundary) and one pass of the product path, with the temporal state update (`update_map`) between frames
@@ -55,11 +55,20 @@ class Case:
         self.net = bench.build_model(dev, seed, c["num_sample"])
         self.frames_cpu = [bench.make_inputs(torch.device("cpu"), seed + 1000 * t, c["B"], (c["H"], c["W"])) for t in range(c["frames"])]
         self.frames_gpu = [to_dev(f, dev) for f in self.frames_cpu]
-        bench.calibrate_batchnorm(self.net, self.frames_gpu[0])
-        self.sd = {k: v.detach().cpu() for k, v in self.net.state_dict().items()}
         self.K = torch.from_numpy(intrinsics(c))
         self.T = [torch.from_numpy(synth.small_motion(seed + t, c["B"])) for t in range(c["frames"])]
         self.eye = torch.eye(4).expand(c["B"], 4, 4).contiguous()
+        bench.calibrate_batchnorm(self.net, self.frames_gpu[0])
+        if c["frames"] > 1:
+            # A temporal model's BatchNorm statistics come from temporal frames: calibrated on frame 0 alone, `past_conv`
+            # (1 -> C on the cost memory) would have seen only the zero memory of single-frame mode (variance ~ 0) and
+            # would amplify a real memory by 1/sqrt(eps) ~ 316 -- cost logits in the thousands, nothing like a trained
+            # network.  So: frame 0 -> update_map -> calibrate on frame 1 WITH its temporal state.
+            with torch.no_grad():
+                info = self.net.eval()(*self.frames_gpu[0], {})[5]
+            info = self.native_update(1, info)
+            bench.calibrate_batchnorm(self.net, self.frames_gpu[1], state_for_aggregation(info))
+        self.sd = {k: v.detach().cpu() for k, v in self.net.state_dict().items()}
         self.cfg = dict(coarse=dict(num_sample=c["num_sample"]))
         self.max_disp = 16 * c["num_sample"]
 

@@ -5,7 +5,9 @@ for batch >= 2 with 7-8 candidates).  Each op is run twice: the hazards seen so 
 
 dif_fms thresholds the interpolated value at > 0 (dif_fms.py:40): an element whose warped value is ~1e-7 may fall
 on the other side in two fp32 implementations and then holds the fill value instead of the difference.  Those
-(measure-zero) elements are excluded; everything else must agree to 2e-3 absolute (values are O(1..10))."""
+(measure-zero) elements are excluded; everything else must agree to 1e-4 absolute + 2e-5 relative (SURVEY.md Appendix
+B.1; the kernels reproduce the reference's coordinate normalise / un-normalise float sequence, so tap positions round
+identically and what is left is summation order)."""
 import numpy as np
 import pytest
 import torch
@@ -33,15 +35,15 @@ def test_cost_volume_kernels_random_shapes():
         tag = "case %d %s" % (it, (B, C, H, W, D, sc))
         exp = oracle.block_cost(l, r, d, sc)
         for _ in range(2):
-            np.testing.assert_allclose(ts.block_cost(lg, rg, dg, sc).cpu().numpy(), exp.numpy(), rtol=0, atol=2e-3, err_msg=tag + " sampled")
-            np.testing.assert_allclose(TF.block_cost_warped(lg, rg, dg, sc).cpu().numpy(), exp[:, C:].numpy(), rtol=0, atol=2e-3, err_msg=tag + " warped")
-        np.testing.assert_allclose(ts.block_cost(lg, rg, D, sc).cpu().numpy(), oracle.block_cost(l, r, D, sc).numpy(), rtol=0, atol=2e-3, err_msg=tag + " int")
-        np.testing.assert_allclose(ts.cat_fms(lg, rg, dg).cpu().numpy(), ocv.cat_fms(l, r, d).numpy(), rtol=0, atol=2e-3, err_msg=tag + " cat")
+            np.testing.assert_allclose(ts.block_cost(lg, rg, dg, sc).cpu().numpy(), exp.numpy(), rtol=2e-5, atol=1e-4, err_msg=tag + " sampled")
+            np.testing.assert_allclose(TF.block_cost_warped(lg, rg, dg, sc).cpu().numpy(), exp[:, C:].numpy(), rtol=2e-5, atol=1e-4, err_msg=tag + " warped")
+        np.testing.assert_allclose(ts.block_cost(lg, rg, D, sc).cpu().numpy(), oracle.block_cost(l, r, D, sc).numpy(), rtol=2e-5, atol=1e-4, err_msg=tag + " int")
+        np.testing.assert_allclose(ts.cat_fms(lg, rg, dg).cpu().numpy(), ocv.cat_fms(l, r, d).numpy(), rtol=2e-5, atol=1e-4, err_msg=tag + " cat")
         tgt = ocv.warp_candidates(r, d)
         got, want = ts.dif_fms(lg, rg, dg).cpu(), ocv.dif_fms(l, r, d)
-        off = ((got - want).abs() > 2e-3) & (tgt.abs() > 1e-5)
+        off = ((got - want).abs() > 1e-4 + 2e-5 * want.abs()) & (tgt.abs() > 1e-5)
         assert int(off.sum()) == 0, tag + " dif: %d elements differ away from the threshold" % int(off.sum())
-        assert int((((got - want).abs() > 2e-3)).sum()) <= 4, tag + " dif: too many threshold flips"
+        assert int((((got - want).abs() > 1e-4 + 2e-5 * want.abs())).sum()) <= 4, tag + " dif: too many threshold flips"
 
 
 def _rel_err(a, b):

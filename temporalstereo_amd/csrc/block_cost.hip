@@ -410,7 +410,9 @@ __device__ __forceinline__ float comp(const float4& v, int i) {
 }
 
 template <bool SAMPLED, bool VEC, int NP, bool REF>   // REF: write the reference (left-repeat) half
-__global__ void __launch_bounds__(512, 4)   // <= 128 VGPRs: three 5-wave workgroups per CU
+// VEC: <= 128 VGPRs, three 5-wave workgroups per CU; ragged widths (scalar loads / stores with their own masks) get 168
+// registers instead of spilling
+__global__ void __launch_bounds__(512, VEC ? 4 : 3)
 block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
                 const float* __restrict__ disp, float* __restrict__ out,
                 float* __restrict__ P1, float* __restrict__ P2, const Shape s) {
@@ -423,42 +425,91 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
   const float* Rg = R + (static_cast<size_t>(b) * C + g * GRP) * HW;
   const int Wq = s.Wq, Wqp = s.Wqp, Wl = 4 * s.Wq;
   float4* ldsR4 = reinterpret_cast<float4*>(lds);                       // [2][TR][4][Wqp]
-  float* ldsL = lds + static_cast<size_t>(2) * TR * 4 * Wqp * 4;        // [GRP][2][Wl]
+  // left rows: two at a time with rows 2,3 carried in registers (NP <= 3: what every shipped geometry uses), or --
+  // few candidates on wide rows, where a thread would carry 4-8 float4 and spill -- all four rows in LDS
+  constexpr bool CARRY = NP <= 3;
+  constexpr int LROWS = CARRY ? 2 : 4;
+  float* ldsL = lds + static_cast<size_t>(2) * TR * 4 * Wqp * 4;        // [GRP][LROWS][Wl]
   const int tid = threadIdx.x, nthr = blockDim.x;
 
   // ---- prologue: stage right rows (channel-packed), left rows 0,1; fetch left rows 2,3 ----------
-  for (int i = tid; i < 2 * TR * Wq; i += nthr) {
-    const int j = i % Wq, hr = i / Wq;            // hr = h*TR + r
-    const int r = hr & (TR - 1), h = hr >> 2;
-    const int y = y0 + r;
-    float v[4][4];
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (y < H) t4 = ld4<VEC>(Rg + static_cast<size_t>(h * 4 + cc) * HW + static_cast<size_t>(y) * W, 4 * j, W);
-      unpack(t4, v[cc]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      ldsR4[(hr * 4 + k) * Wqp + j] = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
-  }
-  if (tid < 2 * TR) ldsR4[(tid * 4) * Wqp + Wq] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero slot of each row
+  // Load order = need order: the left rows first (they go to LDS as they are and -- REF -- straight back out as the
+  // D-fold repeat of the reference half, block_cost.py:51), then the right rows, whose transposition into the
+  // channel-packed layout happens while those stores drain.  The reference half is 47 % of the sampled volume's
+  // bytes and depends on nothing but `left`: streaming it from the staging threads puts it under the load latency
+  // of the right rows instead of in the tap loop (vmcnt is in-order: the right-row loads are older than the stores,
+  // so waiting for them does not wait for the stores).
+  const unsigned dHW = static_cast<unsigned>(D) * HW;                         // one channel (uniform)
+  // the whole [Ctot, D, H, W] slab of this batch item behind one descriptor (host checks < 4 GiB)
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + static_cast<size_t>(b) * s.Ctot * dHW,
+                                                 static_cast<unsigned>(s.Ctot) * dHW * 4u);
   const int n2 = GRP * 2 * Wq;
-  float4 lpre[NP];
+  // Branch-free requests: a lane with nothing to fetch (past the item count / below the image) asks for an
+  // out-of-range element and gets 0 back; a predicated load would be a branch with its own wait.
+  constexpr unsigned OOR = 0x3ffffff0u;            // element offset whose byte offset (+12 for the scalar forms) is beyond any descriptor
+  const __amdgpu_buffer_rsrc_t lrs = make_rsrc(Lg, static_cast<unsigned>(GRP) * HW * 4u);
+  const __amdgpu_buffer_rsrc_t rrs = make_rsrc(Rg, static_cast<unsigned>(GRP) * HW * 4u);
+  float4 lfirst[NP], lpre[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int i = tid + p * nthr;
-    lpre[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int j = i % Wq, cr = i / Wq;            // cr = c*2 + (row & 1)
+    const int ya = y0 + (cr & 1), yb = ya + 2;
+    const unsigned ea = static_cast<unsigned>(cr >> 1) * HW + static_cast<unsigned>(ya) * W + 4u * j;
+    lfirst[p] = bld4<VEC>(lrs, (i < n2 && ya < H) ? ea : OOR, 4 * j, W);
+    lpre[p] = bld4<VEC>(lrs, (i < n2 && yb < H) ? ea + 2u * W : OOR, 4 * j, W);
+  }
+  // right rows: the first pass of items is requested now (its data lands while the reference half is stored), the
+  // others -- narrow workgroups only -- follow the classic load / transpose loop
+  float rv[4][4];
+  const int nR = 2 * TR * Wq;
+  {
+    const int j = tid % Wq, hr = tid / Wq;         // hr = h*TR + r
+    const int r = hr & (TR - 1), h = hr >> 2;
+    const int y = y0 + r;
+    const unsigned er = static_cast<unsigned>(h * 4) * HW + static_cast<unsigned>(y) * W + 4u * j;
+    const bool ok = tid < nR && y < H;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) unpack(bld4<VEC>(rrs, ok ? er + cc * HW : OOR, 4 * j, W), rv[cc]);
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int i = tid + p * nthr;
+    const int j = i % Wq, cr = i / Wq;
     if (i < n2) {
-      const int j = i % Wq, cr = i / Wq;          // cr = c*2 + (row & 1)
-      const size_t off = static_cast<size_t>(cr >> 1) * HW;
+      *reinterpret_cast<float4*>(ldsL + ((cr >> 1) * LROWS + (cr & 1)) * Wl + 4 * j) = lfirst[p];
+      if constexpr (!CARRY) *reinterpret_cast<float4*>(ldsL + ((cr >> 1) * LROWS + (cr & 1) + 2) * Wl + 4 * j) = lpre[p];
+    }
+    if constexpr (SAMPLED && REF) {
       const int ya = y0 + (cr & 1), yb = ya + 2;
-      float4 first = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ya < H) first = ld4<VEC>(Lg + off + static_cast<size_t>(ya) * W, 4 * j, W);
-      if (yb < H) lpre[p] = ld4<VEC>(Lg + off + static_cast<size_t>(yb) * W, 4 * j, W);
-      *reinterpret_cast<float4*>(ldsL + cr * Wl + 4 * j) = first;
+      const unsigned e0 = static_cast<unsigned>(g * GRP + (cr >> 1)) * dHW + static_cast<unsigned>(ya) * W + 4u * j;
+      const bool oka = i < n2 && ya < H, okb = i < n2 && yb < H;
+      unsigned eA = oka ? e0 : OOR, eB = okb ? e0 + 2u * W : OOR;       // out of range = the store is dropped
+      const unsigned sA = oka ? HW : 0u, sB = okb ? HW : 0u;
+      for (int dd = 0; dd < D; ++dd, eA += sA, eB += sB) {
+        bst4<VEC>(orsrc, eA, 0u, 4 * j, W, lfirst[p]);
+        bst4<VEC>(orsrc, eB, 0u, 4 * j, W, lpre[p]);
+      }
     }
   }
+  if (tid < nR) {
+    const int j = tid % Wq, hr = tid / Wq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      ldsR4[(hr * 4 + k) * Wqp + j] = make_float4(rv[0][k], rv[1][k], rv[2][k], rv[3][k]);
+  }
+  for (int i = tid + nthr; i < nR; i += nthr) {
+    const int j = i % Wq, hr = i / Wq;
+    const int r = hr & (TR - 1), h = hr >> 2;
+    const int y = y0 + r;
+    const unsigned er = static_cast<unsigned>(h * 4) * HW + static_cast<unsigned>(y) * W + 4u * j;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) unpack(bld4<VEC>(rrs, y < H ? er + cc * HW : OOR, 4 * j, W), rv[cc]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      ldsR4[(hr * 4 + k) * Wqp + j] = make_float4(rv[0][k], rv[1][k], rv[2][k], rv[3][k]);
+  }
+  if (tid < 2 * TR) ldsR4[(tid * 4) * Wqp + Wq] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero slot of each row
   __syncthreads();
 
   // ---- one item (candidate d, 4x4 block bx) per thread ------------------------------------------
@@ -468,17 +519,18 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
   const bool live = (d < D) && (bx < s.nbx);
   const int x4 = bx * 4;
   const float Wm1 = static_cast<float>(W - 1);
-  const unsigned dHW = static_cast<unsigned>(D) * HW;                         // one channel (uniform)
-  // the whole [Ctot, D, H, W] slab of this batch item behind one descriptor (host checks < 4 GiB)
-  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + static_cast<size_t>(b) * s.Ctot * dHW,
-                                                 static_cast<unsigned>(s.Ctot) * dHW * 4u);
   const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(SAMPLED ? disp + static_cast<size_t>(b) * dHW : out, dHW * 4u);
   unsigned loff = (live ? static_cast<unsigned>(d) : 0u) * HW + static_cast<unsigned>(y0) * W + x4;
 
   float s1[GRP][2], s2[GRP];
 #pragma unroll
   for (int c = 0; c < GRP; ++c) s1[c][0] = s1[c][1] = s2[c] = 0.f;
-  const size_t pbase = ((static_cast<size_t>(b) * s.G + g) * D + (live ? d : 0));
+  // pooled maps of this (b, g): one descriptor each, a lane carries one 32-bit element offset per map
+  const size_t pplane = (static_cast<size_t>(b) * s.G + g) * D;
+  const __amdgpu_buffer_rsrc_t p1rs = make_rsrc(P1 + pplane * s.H1 * s.W1, static_cast<unsigned>(D) * s.H1 * s.W1 * 4u);
+  const __amdgpu_buffer_rsrc_t p2rs = make_rsrc(P2 + pplane * s.H2 * s.W2, static_cast<unsigned>(D) * s.H2 * s.W2 * 4u);
+  const unsigned p1off = (live ? static_cast<unsigned>(d) : 0u) * s.H1 * s.W1 + 2u * bx;
+  const unsigned p2off = (live ? static_cast<unsigned>(d) : 0u) * s.H2 * s.W2 + bx;
 
   float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (SAMPLED) {
@@ -488,14 +540,16 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
 #pragma unroll 1
   for (int r = 0; r < TR; ++r, loff += W) {
     const int y = y0 + r;
-    if (r == 2) {   // swap left rows 2,3 into the LDS slots of rows 0,1
-      __syncthreads();
+    if constexpr (CARRY) {
+      if (r == 2) {   // swap left rows 2,3 into the LDS slots of rows 0,1
+        __syncthreads();
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int i = tid + p * nthr;
-        if (i < n2) *reinterpret_cast<float4*>(ldsL + (i / Wq) * Wl + 4 * (i % Wq)) = lpre[p];
+        for (int p = 0; p < NP; ++p) {
+          const int i = tid + p * nthr;
+          if (i < n2) *reinterpret_cast<float4*>(ldsL + (i / Wq) * Wl + 4 * (i % Wq)) = lpre[p];
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     if (y < H && live) {
       float dv[4];
@@ -520,7 +574,7 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           const int c = h * 4 + cc;
-          const float4 lv4 = *reinterpret_cast<const float4*>(ldsL + (c * 2 + (r & 1)) * Wl + x4);
+          const float4 lv4 = *reinterpret_cast<const float4*>(ldsL + (c * LROWS + (CARRY ? (r & 1) : r)) * Wl + x4);
           float lv[4], tv[4], ev[4];
           unpack(lv4, lv);
 #pragma unroll
@@ -532,8 +586,7 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
           }
           const unsigned plane = static_cast<unsigned>(g * GRP + c) * dHW;        // uniform (SGPR)
           if constexpr (SAMPLED) {
-            if constexpr (REF) {
-              bst4<VEC>(orsrc, loff, plane, x4, W, lv4);                                           // reference half
+            if constexpr (REF) {   // the reference half left with the staging threads (prologue)
               bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));    // warped half
             } else {
               bst4<VEC>(orsrc, loff, plane, x4, W, pack(tv));                                     // warped half only
@@ -563,9 +616,9 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
       }
       const int py = 2 * by + (r >> 1);
       if (live && s.scales > 1 && py < s.H1) {
-        float* prow = P1 + (pbase * s.H1 + py) * s.W1;
-        if (2 * bx < s.W1) prow[2 * bx] = -a0;
-        if (2 * bx + 1 < s.W1) prow[2 * bx + 1] = -a1;
+        const unsigned o = (p1off + static_cast<unsigned>(py) * s.W1) * 4u;
+        if (2 * bx < s.W1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-a0), p1rs, o, 0, 0);
+        if (2 * bx + 1 < s.W1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-a1), p1rs, o + 4u, 0, 0);
       }
     }
   }
@@ -576,7 +629,7 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
       const float m = s2[c] * 0.0625f;
       acc += m * m;
     }
-    P2[(pbase * s.H2 + by) * s.W2 + bx] = -acc;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-acc), p2rs, (p2off + static_cast<unsigned>(by) * s.W2) * 4u, 0, 0);
   }
 }
 
@@ -907,11 +960,11 @@ int launch_fwd(const float* left, const float* right, const float* disp, float* 
   int threads = static_cast<int>(ts::round_up(static_cast<size_t>((nitems + passes - 1) / passes), ts::kWave));
   if (threads > 512) threads = 512;
   // LDS: 4 right rows (de-interleaved, padded) + 2 left rows, per channel of the group
-  const size_t lds_bytes = static_cast<size_t>(GRP) * (TR * 4 * s.Wqp + 2 * 4 * s.Wq) * sizeof(float);   // R4 + Lx
-  const int np = (GRP * 2 * s.Wq + threads - 1) / threads;     // carried left float4s per thread
+  const int np = (GRP * 2 * s.Wq + threads - 1) / threads;     // left float4s per thread and row pair
+  const size_t lds_bytes = static_cast<size_t>(GRP) * (TR * 4 * s.Wqp + (np <= 3 ? 2 : 4) * 4 * s.Wq) * sizeof(float);   // R4 + Lx
   // the fast path addresses one batch item's output slab through a 32-bit buffer descriptor
   const bool stage = lds_bytes <= 64 * 1024 && passes == 1 && np <= 8 &&
-                     static_cast<unsigned long long>(s.Ctot) * D * H * W * 4ull < (1ull << 32);
+                     static_cast<unsigned long long>(s.Ctot) * D * H * W * 4ull < 0xffffff00ull;
   const dim3 grid(s.nby, s.G, B);
   hipStream_t st = ts::as_stream(stream);
 
@@ -1187,7 +1240,7 @@ block_cost_bwd_main(const float* __restrict__ L, const float* __restrict__ R, co
 // items of a block sit in adjacent lanes) and stored plainly -- 32 atomics, 0.40 ms.
 // One item (candidate, 4x4 block) per thread.
 template <bool SAMPLED, bool VEC>
-__global__ void __launch_bounds__(512, 4)   // <= 128 VGPRs: three 5-wave workgroups per CU
+__global__ void __launch_bounds__(512, VEC ? 4 : 3)   // VEC: <= 128 VGPRs, three 5-wave workgroups per CU
 block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
                     const float* __restrict__ dout, const float* __restrict__ dP1, const float* __restrict__ dP2,
                     float* __restrict__ gL, float* __restrict__ gR, float* __restrict__ gD, const Shape s) {

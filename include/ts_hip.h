@@ -86,6 +86,31 @@ int ts_block_cost_sampled_bwd(const float* left, const float* right, const float
                               int B, int C, int H, int W, int D, int scales, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Loss side of the path's outputs.
+ * ts_wasserstein_loss_*: WarssersteinDistanceLoss.loss_per_level  architecture/modeling/losses/warsserstein_distance_loss.py:52-78
+ *   cost/offset/sample [B,D,H,W], gt [B,1,Hg,Wg] (full resolution; pooled to (H,W) after / (Wg/W): avg, or max when `sparse`).
+ *   loss[0] = mean_{b,y,x} sum_d (softmax_d(cost)+0.25) |offset+sample-gt'| [start < gt' < max_disp/scale]; gt_scaled [B,H,W] is
+ *   kept for the backward, which OVERWRITES grad_cost and grad_offset (== grad of sample); either may be NULL.
+ * ts_disp_smooth_l1_*: DispSmoothL1Loss.loss_per_level (losses/smooth_l1_loss.py:49-76) of the disparity est [B,1,h,w] after the
+ *   wrapper's rescale to the ground truth's size, F.interpolate(est * Wg / w, (Hg,Wg), bilinear, align_corners)
+ *   (projects/TemporalStereo/TemporalStereo.py:305-309), evaluated in registers; (h,w) == (Hg,Wg) is the plain loss.
+ *   loss_count[0] = mean smooth-L1 over the valid pixels (0 if none), loss_count[1] = their number (the backward reads it).
+ * grad_loss: one float on the device (d objective / d loss).  Deterministic (fixed-order reductions, gather adjoint).
+ * ---------------------------------------------------------------------------------------- */
+size_t ts_wasserstein_loss_workspace_bytes(int B, int H, int W);
+int ts_wasserstein_loss_fwd(const float* cost, const float* offset, const float* sample, const float* gt, float* loss,
+                            float* gt_scaled, void* workspace, int B, int D, int H, int W, int Hg, int Wg, float max_disp,
+                            float start_disp, int sparse, void* stream);
+int ts_wasserstein_loss_bwd(const float* cost, const float* offset, const float* sample, const float* gt_scaled,
+                            const float* grad_loss, float* grad_cost, float* grad_offset, int B, int D, int H, int W, int Wg,
+                            float max_disp, float start_disp, void* stream);
+size_t ts_disp_smooth_l1_workspace_bytes(int B, int Hg, int Wg);
+int ts_disp_smooth_l1_fwd(const float* est, const float* gt, float* loss_count, void* workspace, int B, int h, int w, int Hg,
+                          int Wg, float max_disp, float start_disp, void* stream);
+int ts_disp_smooth_l1_bwd(const float* est, const float* gt, const float* grad_loss, const float* loss_count, float* grad_est,
+                          int B, int h, int w, int Hg, int Wg, float max_disp, float start_disp, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K4  disparity regression.  cost / sample / offset are [B,D,H,W].
  * ts_topk_softargmax_*: predict_disp()  .../aggregation/TemporalStereo/coarse.py:69-75
  *   (== fine.py:70-76, precise.py:61-67): top-k (1 <= k <= 8, ties: lowest index first) ->

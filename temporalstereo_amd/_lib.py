@@ -39,6 +39,12 @@ SIGNATURES = {
     "ts_softargmin_fwd": (c_int, [c_f32p] * 3 + [c_float, c_int] + [c_int] * 4 + [c_ptr]),
     "ts_softargmin_bwd": (c_int, [c_f32p] * 6 + [c_float, c_int] + [c_int] * 4 + [c_ptr]),
     "ts_argmax_select_fwd": (c_int, [c_f32p] * 4 + [c_int] * 4 + [c_ptr]),
+    "ts_wasserstein_loss_workspace_bytes": (c_size, [c_int] * 3),
+    "ts_wasserstein_loss_fwd": (c_int, [c_f32p] * 6 + [c_ptr] + [c_int] * 6 + [c_float, c_float, c_int, c_ptr]),
+    "ts_wasserstein_loss_bwd": (c_int, [c_f32p] * 7 + [c_int] * 5 + [c_float, c_float, c_ptr]),
+    "ts_disp_smooth_l1_workspace_bytes": (c_size, [c_int] * 3),
+    "ts_disp_smooth_l1_fwd": (c_int, [c_f32p] * 3 + [c_ptr] + [c_int] * 5 + [c_float, c_float, c_ptr]),
+    "ts_disp_smooth_l1_bwd": (c_int, [c_f32p] * 5 + [c_int] * 5 + [c_float, c_float, c_ptr]),
     "ts_softsplat_sum_fwd": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_ptr]),
     "ts_softsplat_sum_fwd_deterministic": (c_int, [c_f32p] * 3 + [c_ptr] + [c_int] * 4 + [c_ptr]),
     "ts_softsplat_sum_bwd_input": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_ptr]),

@@ -76,6 +76,8 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_reproject_memory_fwd),
     TS_PLAN_OP(ts_resize_bilinear_pair_fwd),
     TS_PLAN_OP(ts_calib_stream),             TS_PLAN_OP(ts_conv_set_chunk_cap),
+    TS_PLAN_OP(ts_wasserstein_loss_fwd),     TS_PLAN_OP(ts_wasserstein_loss_bwd),
+    TS_PLAN_OP(ts_disp_smooth_l1_fwd),       TS_PLAN_OP(ts_disp_smooth_l1_bwd),
 };
 
 struct Call {

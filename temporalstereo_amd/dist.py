@@ -20,6 +20,7 @@ import os
 
 import torch
 import torch.distributed as dist
+import torch.nn as nn
 
 
 def init_distributed(backend=None):
@@ -44,8 +45,92 @@ def shard_units(n_units, rank, world, drop_last=False):
     return list(range(rank, n, world))
 
 
+class _SyncBatchNormFn(torch.autograd.Function):
+    """Train-mode BatchNorm whose statistics span every rank of the group.  Forward: ONE all_gather of the per-rank
+    [mean | biased var | count] (2C+1 floats), combined with the parallel-variance formula; backward: ONE all_reduce of
+    [sum dy | sum dy*(x-mean)] (2C floats).  Weight / bias gradients stay local: the gradient exchange averages them with the
+    rest (what torch's SyncBatchNorm and detectron2's NaiveSyncBatchNorm do)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        C = x.shape[1]
+        dims = [0] + list(range(2, x.dim()))
+        n_local = x.numel() // C
+        var_l, mean_l = torch.var_mean(x, dims, unbiased=False)
+        world = dist.get_world_size(group)
+        pack = torch.cat([mean_l, var_l, x.new_full((1,), float(n_local))])
+        allp = [torch.empty_like(pack) for _ in range(world)]
+        dist.all_gather(allp, pack, group=group)
+        allp = torch.stack(allp)                                     # [world, 2C+1]
+        cnt = allp[:, -1:]                                           # [world, 1]
+        n = cnt.sum()
+        mean = (allp[:, :C] * cnt).sum(0) / n
+        var = ((allp[:, C:2 * C] + (allp[:, :C] - mean) ** 2) * cnt).sum(0) / n
+        invstd = torch.rsqrt(var + eps)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = (x - mean.view(shape)) * invstd.view(shape)
+        ctx.save_for_backward(xhat, weight, invstd)
+        ctx.group, ctx.n, ctx.dims, ctx.shape = group, n, dims, shape
+        ctx.mark_non_differentiable(mean, var, n)
+        y = xhat * weight.view(shape) + bias.view(shape) if weight is not None else xhat
+        return y, mean, var, n
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv, _gn):
+        xhat, weight, invstd = ctx.saved_tensors
+        dims, shape = ctx.dims, ctx.shape
+        gw = (gy * xhat).sum(dims)
+        gb = gy.sum(dims)
+        pack = torch.cat([gb, gw])
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=ctx.group)
+        C = gb.numel()
+        sum_dy, sum_dy_xhat = pack[:C] / ctx.n, pack[C:] / ctx.n
+        w = weight if weight is not None else torch.ones_like(invstd)
+        gx = (gy - sum_dy.view(shape) - xhat * sum_dy_xhat.view(shape)) * (invstd * w).view(shape)
+        return gx, (gw if weight is not None else None), (gb if weight is not None else None), None, None
+
+
+class SyncBatchNorm(nn.modules.batchnorm._BatchNorm):
+    """BatchNorm{2,3}d with cross-rank batch statistics over `torch.distributed` (RCCL on the GPUs, gloo in the CPU tests) --
+    the role of `sync_batchnorm=True` in the reference's trainer (projects/TemporalStereo/dist_train.py:94).  Same parameters,
+    buffers and state-dict names as nn.BatchNorm*d; eval mode (and a single process) is plain batch_norm."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.process_group = process_group
+
+    def _check_input_dim(self, input):
+        if input.dim() < 2:
+            raise ValueError("expected at least 2D input (got {}D input)".format(input.dim()))
+
+    def forward(self, x):
+        sync = self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+        if not sync:
+            return super().forward(x)
+        y, mean, var, n = _SyncBatchNormFn.apply(x, self.weight, self.bias, self.eps, self.process_group)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                self.running_var.mul_(1 - m).add_(var * (n / (n - 1)), alpha=m)
+        return y
+
+
 def sync_batchnorm(module, process_group=None):
-    return torch.nn.SyncBatchNorm.convert_sync_batchnorm(module, process_group)
+    """Replace every nn.BatchNorm{1,2,3}d of `module` (in place, names and tensors kept) by SyncBatchNorm."""
+    out = module
+    if isinstance(module, nn.modules.batchnorm._BatchNorm) and not isinstance(module, SyncBatchNorm):
+        out = SyncBatchNorm(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats, process_group)
+        if module.affine:
+            out.weight, out.bias = module.weight, module.bias
+        out.running_mean, out.running_var, out.num_batches_tracked = module.running_mean, module.running_var, module.num_batches_tracked
+        out.training = module.training
+    for name, child in list(module.named_children()):
+        new = sync_batchnorm(child, process_group)
+        if new is not child:
+            setattr(out, name, new)
+    return out
 
 
 class GradientBuckets:
@@ -165,6 +250,34 @@ class GradientBuckets:
             self._unused_known = True
             if len(used) != len(self.params):
                 self._layout(used)
+
+    def all_reduce_now(self):
+        """Average the gradients that are in .grad right now (no hooks involved): for steps whose backward does not run
+        Python -- a replayed hipGraph of forward + backward fills .grad without firing the hooks."""
+        if self.world == 1:
+            return
+        self._fired = set()
+        for bi, bucket in enumerate(self.buckets):
+            self._handles[bi] = None
+            self._ready[bi] = 0
+        with self.paused():
+            pass
+        for bi, bucket in enumerate(self.buckets):
+            for p in bucket:
+                _, off = self._where[id(p)]
+                if p.grad is None:
+                    self._flat[bi][off:off + p.numel()].zero_()
+                else:
+                    self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
+            self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for bi, bucket in enumerate(self.buckets):
+            self._handles[bi].wait()
+            self._flat[bi].div_(self.world)
+            for p in bucket:
+                if p.grad is not None:
+                    _, off = self._where[id(p)]
+                    p.grad.copy_(self._flat[bi][off:off + p.numel()].view_as(p))
+            self._handles[bi] = None
 
     def remove(self):
         for h in self._hooks:

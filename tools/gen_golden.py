@@ -325,6 +325,51 @@ def temporal_update_cases(M):
         save(name, **arrs)
 
 
+def loss_cases(M):
+    """The reference's own loss objects (architecture/modeling/losses) on seeded outputs of the path's shape: three
+    cost / offset / sample levels + four disparities at native resolution, rescaled to full size the way the model wrapper
+    does (projects/TemporalStereo/TemporalStereo.py:305-309) before DispSmoothL1Loss sees them.  Values and autograd gradients."""
+    import torch.nn.functional as F
+    from architecture.modeling.losses import DispSmoothL1Loss, WarssersteinDistanceLoss
+    cases = {"loss_dense": dict(hw=(64, 128), sparse=False, zeros=0.0, max_disp=48, levels=((16, 32, 5), (8, 16, 7), (4, 8, 14))),
+             "loss_sparse": dict(hw=(64, 128), sparse=True, zeros=0.7, max_disp=48, levels=((16, 32, 5), (8, 16, 8), (4, 8, 14))),
+             "loss_none_valid": dict(hw=(32, 64), sparse=False, zeros=1.0, max_disp=48, levels=((8, 16, 5), (4, 8, 7))),
+             "loss_ragged": dict(hw=(50, 70), sparse=False, zeros=0.1, max_disp=64, levels=((13, 18, 5), (50, 70, 3)))}
+    for ci, (name, c) in enumerate(cases.items()):
+        seed = synth.SEED0 + 300 + ci
+        B = 2
+        H, W = c["hw"]
+        gt = synth.uniform(seed, "gt", (B, 1, H, W), -4.0, 1.3 * c["max_disp"])
+        gt = gt * (synth.uniform(seed, "keep", (B, 1, H, W)) >= c["zeros"])
+        gt_t = torch.from_numpy(gt.astype(np.float32))
+        arrs = dict(gt=gt, max_disp=c["max_disp"], sparse=int(c["sparse"]), n_levels=len(c["levels"]))
+        costs, offs, samps, ests = [], [], [], []
+        for li, (h, w, D) in enumerate(c["levels"]):
+            costs.append(torch.from_numpy(synth.normal(seed, "cost%d" % li, (B, D, h, w), 2.0)).requires_grad_(True))
+            offs.append(torch.from_numpy(synth.normal(seed, "off%d" % li, (B, D, h, w), 0.3)).requires_grad_(True))
+            base = synth.uniform(seed, "base%d" % li, (B, 1, h, w), 0.0, c["max_disp"] * w / W)
+            samps.append(torch.from_numpy((base + np.arange(D, dtype=np.float32).reshape(1, D, 1, 1) - D / 2).astype(np.float32)).requires_grad_(True))
+            ests.append(torch.from_numpy(synth.uniform(seed, "est%d" % li, (B, 1, h, w), 0.0, c["max_disp"] * w / W)).requires_grad_(True))
+        ests.append(torch.from_numpy(synth.uniform(seed, "estfull", (B, 1, H, W), 0.0, float(c["max_disp"]))).requires_grad_(True))
+        wl = WarssersteinDistanceLoss(max_disp=c["max_disp"], sparse=c["sparse"])
+        wd = wl(costs, offs, samps, gt_t)
+        sl = DispSmoothL1Loss(max_disp=c["max_disp"], sparse=c["sparse"])
+        full = [F.interpolate(d * W / d.shape[-1], size=(H, W), mode='bilinear', align_corners=True) for d in ests]
+        sd = sl(full, gt_t)
+        total = sum(wd.values()) + sum(sd.values())
+        total.backward()
+        for li in range(len(c["levels"])):
+            arrs.update({"cost%d" % li: costs[li], "off%d" % li: offs[li], "sample%d" % li: samps[li],
+                         "wars_loss%d" % li: wd["wars_loss_lvl%d" % li],
+                         "g_cost%d" % li: costs[li].grad, "g_off%d" % li: offs[li].grad, "g_sample%d" % li: samps[li].grad})
+        for li in range(len(ests)):
+            arrs.update({"est%d" % li: ests[li], "l1_loss%d" % li: sd["l1_loss_lvl%d" % li],
+                         "g_est%d" % li: ests[li].grad if ests[li].grad is not None else torch.zeros_like(ests[li]),
+                         "full%d" % li: full[li]})
+        arrs["n_est"] = len(ests)
+        save(name, **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -336,9 +381,13 @@ def main():
     if "--only-temporal" in sys.argv:
         temporal_update_cases(M)
         return
+    if "--only-losses" in sys.argv:
+        loss_cases(M)
+        return
     functional_cases(M)
     sibling_cases(M)
     temporal_update_cases(M)
+    loss_cases(M)
     aggregator_case("agg_tiny_single", TINY, synth.SEED0 + 100, 2, 96, 160, temporal=False, store_inputs=True)
     aggregator_case("agg_tiny_temporal", TINY, synth.SEED0 + 101, 2, 96, 160, temporal=True, store_inputs=True)
     aggregator_case("agg_tiny_train", TINY, synth.SEED0 + 102, 2, 96, 160, temporal=False, store_inputs=True,

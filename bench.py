@@ -193,6 +193,63 @@ def cpu_baseline(seed, budget_s=20.0):
                        "(torch %s CPU kernels, %d threads; first pass %.2fs excluded)" % (n, torch.__version__, cores, first)), out, sd
 
 
+def training_leg(dev, rank, world, steps, warmup, batch, graph, seed):
+    """Data-parallel TRAINING steps of the same path (temporalstereo_amd.train.TrainStep: T=2 frame loop with the previous frame
+    in eval()/no_grad, update_map, train-mode forward, fused smooth-L1 + Wasserstein losses, backward through the HIP kernels,
+    bucketed gradient all-reduce over RCCL + SyncBatchNorm, clip 0.1, RMSprop), FlyingThings3D 544x960 D=192, `batch` pairs per GPU.
+    Returns the `training` object of the JSON line (whole-job pairs/s over the max-over-ranks time)."""
+    import torch.distributed as dist
+    from temporalstereo_amd.train import TrainStep
+    net = build_model(dev, seed)
+    frames = []
+    for t in range(2):
+        lf, rf, il, ir = make_inputs(dev, seed + rank + 1000 * t, batch)
+        if t == 1:
+            lf, rf = [x.requires_grad_(True) for x in lf], [x.requires_grad_(True) for x in rf]
+        frames.append((lf, rf, il, ir))
+    calibrate_batchnorm(net, frames[0])
+    gt = torch.from_numpy(synth.smooth(synth.normal(seed + rank, "gt", (batch, 1, RUN_H, RUN_W))) * 20.0 + 70.0).to(dev)
+    K = torch.from_numpy(synth.sceneflow_intrinsics(batch, RUN_H, RUN_W)).to(dev)
+    T = torch.from_numpy(synth.small_motion(seed + rank, batch)).to(dev)
+    eye = torch.eye(4, device=dev).expand(batch, 4, 4).contiguous()
+    poses = [(eye, eye), (T, eye)]
+    step = TrainStep(net, max_disp=MAX_DISP, local_map_size=1, graph=graph)
+    for _ in range(warmup):
+        loss = step(frames, gt, K, poses)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    exch = 0.0
+    for _ in range(steps):
+        loss = step(frames, gt, K, poses)
+        exch += step.timings["exchange_ms"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    nparam = sum(p.numel() for p in step.params)
+    return dict(value=world * batch * steps / el, unit="pairs/s", ms_per_step=el / steps * 1e3, steps=steps, batch_per_gpu=batch,
+                frames=2, mode="hipGraph of forward+backward" if graph else "eager autograd", sync_bn=step.sync_bn,
+                gradient_exchange_ms=exch / steps, gradient_bytes=4 * nparam, final_loss=float(loss),
+                buckets_launched_in_backward=(step.buckets.launched_in_backward if step.buckets is not None else None),
+                note="training step of the aggregation path (features given, requires_grad): previous frame eval/no_grad + update_map + "
+                     "train-mode forward + fused losses + backward + bucketed all-reduce (RCCL) + clip 0.1 + RMSprop")
+
+
+def sequence_leg(iters=10):
+    """Temporal-sequence throughput at BASELINE configs[2]-[4] (their stated batches, T=2; tools/sequence_bench.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sequence_bench
+    return [sequence_bench.run(i, 2, iters) for i in (2, 3, 4)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,13 +257,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (config 2: 1)")
     ap.add_argument("--mode", default="native",
-                    choices=["native", "native-eager", "native-graph", "module", "module-graph", "module-hip"],
+                    choices=["native", "native-eager", "native-graph", "module", "module-graph", "module-hip", "train", "train-graph"],
                     help="native: all-HIP inference path (aggregation.native) replayed from a recorded native "
                          "launch plan; native-eager: the same, issued op by op from Python; module: nn.Module "
                          "forward with the framework's own (MIOpen) convolutions; module-hip: nn.Module forward "
                          "with the HIP convolution Functions (unfused BatchNorm / activation); -graph: replayed "
                          "as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `training` and `sequence` objects of the default line")
     ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3),
                     help="native mode: N > 1 = the engine keeps N independent passes in flight on N sets of launch-plan "
                          "buffers, each pass a three-stage pipeline over the engine's streams; 1 = one pass at a time")
@@ -249,6 +307,20 @@ def main():
             dist.init_process_group(backend=backend)
 
     seed = synth.SEED0 + 2                      # config index 2
+    if a.mode in ("train", "train-graph"):
+        tr = training_leg(dev, rank, world, a.steps, a.warmup, a.batch, a.mode == "train-graph", seed)
+        if rank == 0:
+            print(json.dumps(dict(metric="stereo pairs/sec, TRAINING step, FlyingThings3D 540x960 D=192 T=2 (aggregation hot path)",
+                                  value=tr["value"], unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                                  ms_per_step=tr["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                                  data="synthetic",
+                                  config=dict(workload="FlyingThings3D 540x960 (run 544x960) D=192 temporal T=2 training step, batch %d/GPU" % a.batch,
+                                              run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
+                                              parallelism="dp%d" % world, exec_mode=a.mode),
+                                  training=tr)), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     net = build_model(dev, seed)
     inputs = make_inputs(dev, seed + rank, a.batch)
     calibrate_batchnorm(net, inputs)
@@ -349,6 +421,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    training = None
+    if mode == "native" and not a.no_extras:
+        try:        # every rank takes part (gradient all-reduce, SyncBatchNorm); short: it must not dominate the run
+            training = training_leg(dev, rank, world, 8, 3, 1, False, seed)
+        except Exception as e:      # the headline number must survive a failure of the extra leg
+            training = dict(error="%s: %s" % (type(e).__name__, e))
+
     result = None
     if rank == 0:
         pairs = world * a.batch * a.steps
@@ -401,6 +480,13 @@ def main():
             result["one_pass_at_a_time"] = one_at_a_time
         if concurrent is not None:
             result["concurrent_pairs"] = concurrent
+        if training is not None:
+            result["training"] = training
+        if world == 1 and mode == "native" and not a.no_extras:
+            try:
+                result["sequence"] = sequence_leg()
+            except Exception as e:
+                result["sequence"] = dict(error="%s: %s" % (type(e).__name__, e))
         if world == 1 and not a.no_cpu_baseline:
             base, ref_out, _ = cpu_baseline(seed)
             # parity on the very same inputs: needs the calibrated BN statistics on the oracle side too

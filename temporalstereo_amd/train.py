@@ -1,0 +1,115 @@
+"""One data-parallel training step of the aggregation path, the counterpart of the reference's
+`TemporalStereo.training_step` + `multi_frame_forward` (projects/TemporalStereo/TemporalStereo.py:130-168, :250-280) under
+`pl.Trainer(strategy='ddp', sync_batchnorm=True, gradient_clip_val=0.1)` (dist_train.py:82-96):
+
+    for every previous frame (FRAME_IDXS < 0; PREVIOUS_WITH_GRADIENT False):   eval() + no_grad forward      :268-274
+        update_map: the temporal state moves into the next frame                                               :326-461
+    current frame: train() forward with the carried state                                                      :276-278
+    loss = smooth-L1 of the four disparities (rescaled to full size) + Wasserstein loss of the three levels    :139-150
+    backward -> gradient averaging over the ranks -> clip 0.1 -> RMSprop step                                   sceneflow.yaml:21-24
+
+The aggregation's inputs are the backbone's feature pyramids (out of scope: features are given, and `requires_grad` so that the
+cost volume's backward towards them runs as it would under the backbone).  Everything on the data path is a HIP kernel behind
+an autograd Function except train-mode BatchNorm / activations (framework ops; SyncBatchNorm of dist.py across ranks).
+
+`graph=True`: previous frames + state update + forward + loss + backward are captured ONCE into a hipGraph and replayed per
+step (static input buffers): the step is host-bound through the framework's autograd otherwise (~300 Python-level ops).  The
+gradient exchange, clipping and the optimizer stay outside the graph; with more than one rank the captured BatchNorm is the
+per-rank one (collectives are not captured), which the step reports as `sync_bn: False`.
+"""
+import time
+
+import torch
+
+from . import dist as tsd
+from . import temporal
+from .losses import DispSmoothL1Loss, WarssersteinDistanceLoss
+
+
+class TrainStep:
+    def __init__(self, net, max_disp=192, local_map_size=1, lr=1e-4, clip=0.1, sync_bn=True, bucket_bytes=32 << 20, graph=False,
+                 baseline=1.0):
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.graph = graph
+        self.sync_bn = bool(sync_bn) and self.world > 1 and not graph
+        if self.sync_bn:
+            net = tsd.sync_batchnorm(net)
+        self.net = net
+        tsd.broadcast_parameters(net)
+        self.l1 = DispSmoothL1Loss(max_disp=max_disp, rescale=True)
+        self.wars = WarssersteinDistanceLoss(max_disp=max_disp)
+        self.local_map_size, self.clip, self.baseline = local_map_size, clip, baseline
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.opt = torch.optim.RMSprop(self.params, lr=lr)
+        self.buckets = tsd.GradientBuckets(self.params, bucket_bytes=bucket_bytes) if self.world > 1 else None
+        self._g = None
+        self.timings = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _forward_backward(self, frames, gt, K, poses):
+        """frames: list of (left_feats, right_feats, left_image, right_image), oldest first; poses[t] = (T_now, inv_T_past)."""
+        net = self.net
+        info = {}
+        for t, fr in enumerate(frames[:-1]):
+            net.eval()
+            with torch.no_grad():
+                info = net(fr[0], fr[1], fr[2], fr[3], dict(info))[5]
+                H, W = fr[2].shape[-2:]
+                info = temporal.update_map(dict(info), K, poses[t + 1][0], poses[t + 1][1], self.baseline, H, W,
+                                           use_past_cost=True, local_map_size=self.local_map_size)
+        net.train()
+        cur = frames[-1]
+        state = {k: v for k, v in info.items() if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}
+        disps, costs, samples, offs, _, _ = net(cur[0], cur[1], cur[2], cur[3], state)
+        losses = {}
+        losses.update(self.l1(disps, gt))
+        losses.update(self.wars(costs, offs, samples, gt))
+        total = sum(losses.values())
+        total.backward()
+        return total.detach()
+
+    def _capture(self, frames, gt, K, poses):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                                      # warm-up: allocator, MIOpen solver choice, lazy inits
+                self.opt.zero_grad(set_to_none=True)
+                self._forward_backward(frames, gt, K, poses)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._forward_backward(frames, gt, K, poses)
+        self._g, self._loss = g, loss
+        self._static = (frames, gt, K, poses)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def __call__(self, frames, gt, K, poses):
+        """One optimisation step.  Returns the (local) loss as a 0-d device tensor.  With graph=True the first call captures on
+        these very tensors; later calls must pass the same tensors (the data loader writes the next batch into them)."""
+        t0 = time.perf_counter()
+        if self.graph:
+            if self._g is None:
+                self._capture(frames, gt, K, poses)
+            elif frames is not self._static[0]:
+                raise RuntimeError("TrainStep(graph=True) replays on the tensors of its first call: pass the same objects")
+            self._g.replay()
+            loss = self._loss
+            t1 = time.perf_counter()
+            if self.buckets is not None:
+                self.buckets.all_reduce_now()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+            loss = self._forward_backward(frames, gt, K, poses)
+            t1 = time.perf_counter()
+            if self.buckets is not None:
+                self.buckets.finish()
+        t2 = time.perf_counter()
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+        self.opt.step()
+        t3 = time.perf_counter()
+        # host-side issue times (the device runs behind them); the exchange entry includes waiting for the reduced buckets
+        self.timings = dict(forward_backward_issue_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3, clip_step_issue_ms=(t3 - t2) * 1e3)
+        return loss

@@ -106,3 +106,80 @@ def test_buckets_drop_unused_parameters_and_overlap_from_the_second_step(tmp_pat
     out = str(tmp_path / "g.pt")
     mp.spawn(_unused_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert "phi" not in torch.load(out)
+
+
+# ------------------------------------------------------------------------------------------------ the real aggregator, ws 2
+def _tiny_aggregator(setattr_=setattr):
+    """The registered TEMPORALSTEREO module at the tiny fixture dimensions, fp64, with the two GPU-only ops of its forward bound
+    to the oracle (tests may use it): the module graph, its BatchNorm layers and the data-parallel wiring are what is under test."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle
+    from helpers import load, dims_from_golden, synth_state, aggregator_inputs
+    import temporalstereo_amd as ts
+    from temporalstereo_amd import functional as TF
+    setattr_(TF, "block_cost", oracle.block_cost)              # (the test process passes monkeypatch.setattr: undone afterwards)
+    setattr_(TF, "topk_softargmax", oracle.topk_softargmax)
+    g = load("agg_tiny_single")
+    dims = dims_from_golden(g)
+    net = ts.TEMPORALSTEREO(
+        coarse=ts.CoarseAggregation(dims['coarse']['in_planes'], dims['coarse']['C'], dims['coarse']['num_sample']),
+        fine=ts.FineAggregation(dims['fine']['in_planes'], dims['fine']['C'], 5),
+        precise=ts.PreciseAggregation(dims['precise']['in_planes'], dims['precise']['C'], 5))
+    net.load_state_dict(synth_state(dims, int(g["seed"]), golden=g), strict=True)
+    lf, rf, il, ir, _ = aggregator_inputs(g, dims)
+    d = lambda x: x.double()
+    return net.double().train(), ([d(x) for x in lf], [d(x) for x in rf], d(il), d(ir))
+
+
+def _objective(out):
+    disps, costs, samples, offs = out[0], out[1], out[2], out[3]
+    return sum(x.mean() for x in disps) + sum((c * 0.01).tanh().mean() for c in costs) + sum(o.mean() for o in offs)
+
+
+def _train_two_steps(net, inputs, buckets=None):
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        _objective(net(*inputs, {})).backward()
+        if buckets is not None:
+            buckets.finish()
+        opt.step()
+    return {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+
+def _agg_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from temporalstereo_amd import dist as tsd
+    tsd.init_distributed("gloo")
+    net, (lf, rf, il, ir) = _tiny_aggregator()
+    net = tsd.sync_batchnorm(net)
+    assert sum(isinstance(m, tsd.SyncBatchNorm) for m in net.modules()) > 80
+    tsd.broadcast_parameters(net)
+    mine = slice(rank, rank + 1)                           # the fixture's batch of 2: one pair per rank
+    inputs = ([x[mine] for x in lf], [x[mine] for x in rf], il[mine], ir[mine])
+    gb = tsd.GradientBuckets(net.parameters(), bucket_bytes=256 << 10)
+    sd = _train_two_steps(net, inputs, gb)
+    assert gb.launched_in_backward > 0                     # second step: buckets went out during backward
+    if rank == 0:
+        torch.save(sd, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_aggregator_two_ranks_sync_batchnorm_matches_single_process(tmp_path, monkeypatch):
+    """Two optimisation steps of the tiny REAL aggregator, one pair per rank, SyncBatchNorm + bucketed gradient averaging ==
+    the same two steps in one process on the batch of two with plain BatchNorm (parameters AND running statistics)."""
+    out = str(tmp_path / "sd.pt")
+    mp.spawn(_agg_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    net, inputs = _tiny_aggregator(monkeypatch.setattr)
+    want = _train_two_steps(net, inputs)
+    assert set(got) == set(want)
+    for k in want:
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(want[k]), k
+            continue
+        torch.testing.assert_close(got[k], want[k], rtol=1e-7, atol=1e-9, msg=lambda m, k=k: "%s: %s" % (k, m))

@@ -251,34 +251,6 @@ class GradientBuckets:
             if len(used) != len(self.params):
                 self._layout(used)
 
-    def all_reduce_now(self):
-        """Average the gradients that are in .grad right now (no hooks involved): for steps whose backward does not run
-        Python -- a replayed hipGraph of forward + backward fills .grad without firing the hooks."""
-        if self.world == 1:
-            return
-        self._fired = set()
-        for bi, bucket in enumerate(self.buckets):
-            self._handles[bi] = None
-            self._ready[bi] = 0
-        with self.paused():
-            pass
-        for bi, bucket in enumerate(self.buckets):
-            for p in bucket:
-                _, off = self._where[id(p)]
-                if p.grad is None:
-                    self._flat[bi][off:off + p.numel()].zero_()
-                else:
-                    self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
-            self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        for bi, bucket in enumerate(self.buckets):
-            self._handles[bi].wait()
-            self._flat[bi].div_(self.world)
-            for p in bucket:
-                if p.grad is not None:
-                    _, off = self._where[id(p)]
-                    p.grad.copy_(self._flat[bi][off:off + p.numel()].view_as(p))
-            self._handles[bi] = None
-
     def remove(self):
         for h in self._hooks:
             h.remove()

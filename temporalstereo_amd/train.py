@@ -12,10 +12,12 @@ The aggregation's inputs are the backbone's feature pyramids (out of scope: feat
 cost volume's backward towards them runs as it would under the backbone).  Everything on the data path is a HIP kernel behind
 an autograd Function except train-mode BatchNorm / activations (framework ops; SyncBatchNorm of dist.py across ranks).
 
-`graph=True`: previous frames + state update + forward + loss + backward are captured ONCE into a hipGraph and replayed per
-step (static input buffers): the step is host-bound through the framework's autograd otherwise (~300 Python-level ops).  The
-gradient exchange, clipping and the optimizer stay outside the graph; with more than one rank the captured BatchNorm is the
-per-rank one (collectives are not captured), which the step reports as `sync_bn: False`.
+The step is host-bound through the framework's autograd (~300 Python-level ops per frame: 31.7 ms at 544x960, batch 1, T=2 on
+MI355X).  Capturing previous frame + update + forward + loss + backward into one hipGraph was tried: 18.8 ms per replay -- ROCm
+7.2 replays a captured chain of ~1500 small kernels no faster than it issues them -- and not bit-safe (NaN loss after the first
+optimizer step), so it is not offered.  What gets this step to the kernels' own time is a recorded native plan of forward AND
+backward as for inference (aggregation/engine.py), which needs HIP kernels for train-mode BatchNorm + activation and the backward
+of the 2-D upsamplers first.
 """
 import time
 
@@ -27,11 +29,9 @@ from .losses import DispSmoothL1Loss, WarssersteinDistanceLoss
 
 
 class TrainStep:
-    def __init__(self, net, max_disp=192, local_map_size=1, lr=1e-4, clip=0.1, sync_bn=True, bucket_bytes=32 << 20, graph=False,
-                 baseline=1.0):
+    def __init__(self, net, max_disp=192, local_map_size=1, lr=1e-4, clip=0.1, sync_bn=True, bucket_bytes=32 << 20, baseline=1.0):
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        self.graph = graph
-        self.sync_bn = bool(sync_bn) and self.world > 1 and not graph
+        self.sync_bn = bool(sync_bn) and self.world > 1
         if self.sync_bn:
             net = tsd.sync_batchnorm(net)
         self.net = net
@@ -42,7 +42,6 @@ class TrainStep:
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.opt = torch.optim.RMSprop(self.params, lr=lr)
         self.buckets = tsd.GradientBuckets(self.params, bucket_bytes=bucket_bytes) if self.world > 1 else None
-        self._g = None
         self.timings = {}
 
     # ------------------------------------------------------------------------------------------------------------
@@ -68,43 +67,15 @@ class TrainStep:
         total.backward()
         return total.detach()
 
-    def _capture(self, frames, gt, K, poses):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):                                      # warm-up: allocator, MIOpen solver choice, lazy inits
-                self.opt.zero_grad(set_to_none=True)
-                self._forward_backward(frames, gt, K, poses)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.opt.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            loss = self._forward_backward(frames, gt, K, poses)
-        self._g, self._loss = g, loss
-        self._static = (frames, gt, K, poses)
-
     # ------------------------------------------------------------------------------------------------------------
     def __call__(self, frames, gt, K, poses):
-        """One optimisation step.  Returns the (local) loss as a 0-d device tensor.  With graph=True the first call captures on
-        these very tensors; later calls must pass the same tensors (the data loader writes the next batch into them)."""
+        """One optimisation step.  Returns the (local) loss as a 0-d device tensor."""
         t0 = time.perf_counter()
-        if self.graph:
-            if self._g is None:
-                self._capture(frames, gt, K, poses)
-            elif frames is not self._static[0]:
-                raise RuntimeError("TrainStep(graph=True) replays on the tensors of its first call: pass the same objects")
-            self._g.replay()
-            loss = self._loss
-            t1 = time.perf_counter()
-            if self.buckets is not None:
-                self.buckets.all_reduce_now()
-        else:
-            self.opt.zero_grad(set_to_none=True)
-            loss = self._forward_backward(frames, gt, K, poses)
-            t1 = time.perf_counter()
-            if self.buckets is not None:
-                self.buckets.finish()
+        self.opt.zero_grad(set_to_none=True)
+        loss = self._forward_backward(frames, gt, K, poses)
+        t1 = time.perf_counter()
+        if self.buckets is not None:
+            self.buckets.finish()
         t2 = time.perf_counter()
         if self.clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)

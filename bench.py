@@ -162,7 +162,7 @@ class K1Probe:
         return {k: float(np.mean(v)) for k, v in per.items()}
 
 
-def cpu_baseline(seed, budget_s=20.0):
+def cpu_baseline(seed, budget_s=20.0, all_cores=False):
     """The oracle aggregation (torch CPU ops, all host cores) on the same config-2 inputs."""
     from oracle import aggregation as oagg
     import temporalstereo_amd as ts
@@ -188,7 +188,18 @@ def cpu_baseline(seed, budget_s=20.0):
             oagg.aggregate(sd, lf, rf, il, ir, {}, cfg=cfg)
             t_acc += time.perf_counter() - t0
             n += 1
-    return dict(value=n / t_acc, unit="pairs/s", cores=cores, kind="port",
+    extra = {}
+    if all_cores and (os.cpu_count() or 1) > cores:
+        # once, for the record (SURVEY.md section 8(d) asks for all host cores): on these small tensors every thread beyond
+        # ~16 only adds synchronisation, which is why the reported baseline uses 16
+        torch.set_num_threads(os.cpu_count())
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            oagg.aggregate(sd, lf, rf, il, ir, {}, cfg=cfg)
+            ta = time.perf_counter() - t0
+        torch.set_num_threads(cores)
+        extra = dict(all_host_threads=dict(cores=os.cpu_count(), value=1.0 / ta, unit="pairs/s", sample="1 pass"))
+    return dict(value=n / t_acc, unit="pairs/s", cores=cores, kind="port", **extra,
                 sample="%d forward passes of the config-2 aggregation (544x960, D=192, B=1) through oracle/ "
                        "(torch %s CPU kernels, %d threads; first pass %.2fs excluded)" % (n, torch.__version__, cores, first)), out, sd
 
@@ -264,7 +275,11 @@ def main():
                          "with the HIP convolution Functions (unfused BatchNorm / activation); -graph: replayed "
                          "as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="cpu_baseline: also one pass on ALL host threads (slow: oversubscribed)")
     ap.add_argument("--no-extras", action="store_true", help="skip the `training` and `sequence` objects of the default line")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also launch the known-size read / fill / copy streams of csrc/calib.hip (1 GiB each) once, so that a PMC "
+                         "pass of this command carries its own FETCH_SIZE / WRITE_SIZE calibration (tools/k1_traffic.py)")
     ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3),
                     help="native mode: N > 1 = the engine keeps N independent passes in flight on N sets of launch-plan "
                          "buffers, each pass a three-stage pipeline over the engine's streams; 1 = one pass at a time")
@@ -361,6 +376,39 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         k1_times = k1.measure(max(a.steps, 20)) if rank == 0 else {}
+        k1_b4 = None
+        if rank == 0 and mode.startswith("native"):
+            # the same launch on four pairs: 930 MB per launch, beyond the 256 MiB Infinity Cache (SURVEY.md section 8(d) hygiene)
+            from temporalstereo_amd import functional as TF
+            key1 = (a.batch, 2 * DIMS['precise']['in_planes'], RUN_H // 4, RUN_W // 4, 5, "warped")
+            if key1 in k1.calls:
+                _, l1, r1, d1, sc1 = k1.calls[key1]
+                rep = max(1, 4 // a.batch)
+                l4, r4, d4 = (x.repeat(rep, 1, 1, 1).contiguous() for x in (l1, r1, d1))
+                with torch.no_grad():
+                    for _ in range(3):
+                        TF.block_cost(l4, r4, d4, sc1)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        TF.block_cost(l4, r4, d4, sc1)
+                    e1.record()
+                    torch.cuda.synchronize()
+                t4 = e0.elapsed_time(e1) / 20 * 1e-3
+                nb4 = k1_algorithmic_bytes(l4.shape[0], l4.shape[1], l4.shape[2], l4.shape[3], 5, True)
+                k1_b4 = dict(batch=int(l4.shape[0]), algorithmic_bytes=nb4, mean_us=t4 * 1e6, achieved=nb4 / t4 / 1e9, frac=nb4 / t4 / HBM_PEAK,
+                             note="same launch on 4 pairs (930 MB per launch: beyond the 256 MiB Infinity Cache); this box's plain fill of that "
+                                  "size runs at 4.6-5.4 TB/s, i.e. 0.58-0.68 of the spec figure is the write ceiling")
+                del l4, r4, d4
+        if a.calibrate and rank == 0:
+            from temporalstereo_amd import _lib
+            nbytes = 1 << 30
+            ca, cb = torch.empty(nbytes // 4, device=dev), torch.ones(nbytes // 4, device=dev)
+            stc = _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for kind in (0, 1, 2):
+                _lib.check(_lib.lib().ts_calib_stream(kind, _lib.ptr(ca), _lib.ptr(cb), nbytes, stc), "ts_calib_stream")
+            torch.cuda.synchronize()
+            del ca, cb
 
     # one pass at a time (what a latency-bound caller sees), next to the several-in-flight headline
     one_at_a_time = None
@@ -445,7 +493,7 @@ def main():
             all_t = sum(k1_times[k] for k in used)
             traffic = None
             try:    # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected in-process)
-                with open(os.path.join(ROOT, "profiles", "r01_k1_hbm_traffic_pmc.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r02_k1_hbm_traffic_pmc.json")) as fh:
                     pm = json.load(fh)
                 if list(pm["workload_key"]) == list(pkey):
                     traffic = pm["hbm_bytes_per_launch"]
@@ -466,7 +514,10 @@ def main():
                                                    frac=k1_algorithmic_bytes(*wkey) / k1_times[wkey] / HBM_PEAK)
                                               if wkey in k1_times else None),
                             all_levels=dict(algorithmic_bytes=all_b, mean_us=all_t * 1e6,
-                                            achieved=all_b / all_t / 1e9, frac=all_b / all_t / HBM_PEAK))
+                                            achieved=all_b / all_t / 1e9, frac=all_b / all_t / HBM_PEAK),
+                            beyond_infinity_cache=k1_b4,
+                            traffic_source="profiles/r02_k1_hbm_traffic_pmc.json: FETCH_SIZE / WRITE_SIZE passes of this command under "
+                                           "rocprofv3 (tools/k1_traffic.py); a PMC pass cannot run inside the timed process")
         result = dict(metric="stereo pairs/sec, FlyingThings3D 540x960 D=192 (aggregation hot path)",
                       value=pairs / elapsed, unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                       ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling="weak",
@@ -488,7 +539,7 @@ def main():
             except Exception as e:
                 result["sequence"] = dict(error="%s: %s" % (type(e).__name__, e))
         if world == 1 and not a.no_cpu_baseline:
-            base, ref_out, _ = cpu_baseline(seed)
+            base, ref_out, _ = cpu_baseline(seed, all_cores=a.cpu_all_cores)
             # parity on the very same inputs: needs the calibrated BN statistics on the oracle side too
             sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
             from oracle import aggregation as oagg

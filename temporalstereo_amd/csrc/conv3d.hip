@@ -17,6 +17,8 @@
 // its scalar loads AND its LDS read -- and reached 3-15 TFLOP/s.  The implicit-GEMM MFMA kernel
 // below replaced it (6-70 TFLOP/s on the same layers).
 // Weights are pre-laid out [Cin][taps][CoutPad] (output channel contiguous) by the host.
+#include <cstdlib>
+
 #include "ts_common.hpp"
 
 namespace {
@@ -100,16 +102,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ig_rsrc(const void* base, unsi
 
 // ST / DL: stride and dilation of MODE_HW as compile-time constants, so that every LDS fragment read is
 // `base register + immediate` (no address arithmetic between MFMAs).  NC: input channels per K chunk.
-template <int CB, int MODE, int KT, int ST, int DL, int NC>
+// PR (row pairing, Cout <= 8 on a stride-1 (1,3,3) layer): half of a 16-wide MFMA would multiply zero-padded channels
+// 8..15.  Instead the 16 rows of the A operand are (output row, channel): rows 0-7 = channels 0-7 of output row R+DL, rows
+// 8-15 = channels 0-7 of output row R.  The two output rows share input rows (R+DL and R+2DL of the tile), so one B fragment
+// feeds both: per kx, input row R+rho*DL (rho = 0..3) is multiplied by [ W[ky=rho-1] | W[ky=rho] ] (zero where ky is
+// outside 0..2) -- 12 "virtual taps" with 18 useful (tap, row) products in 24 half-tiles instead of 18 in 36, i.e. a third
+// fewer MFMAs and a third fewer B-fragment reads.  The paired weight rows are assembled while the weights are staged.
+template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0>
 __global__ void __launch_bounds__(256)
 ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                const float* __restrict__ shift, float* __restrict__ y, const IG p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(!PR || (MODE == MODE_HW && KT == 9 && ST == 1 && CB == 1 && NC >= 8), "row pairing: stride-1 (1,3,3), Cout <= 8");
   using G = Geom<MODE, KT, ST, DL>;
   constexpr int WP = (CB * 16) | 16;                  // weight row pitch (k-slots on disjoint banks)
   constexpr int NTR = G::NTR, RQ = (MODE == MODE_D) ? NTR : G::RQ_HW;
   constexpr int in_rows = G::in_rows, in_cols = G::in_cols, pitch = G::pitch, chan_elems = G::chan_elems;
-  constexpr int WV = KT * NC * CB * 4;                // 16-byte weight vectors per chunk
+  constexpr int KTW = PR ? 12 : KT;                   // taps as staged in LDS (virtual taps when pairing)
+  constexpr int NPB = PR ? 2 : 4;                     // 16-pixel blocks per wave
+  constexpr int WV = KTW * NC * CB * 4;               // 16-byte weight vectors per chunk
   constexpr int RWN = (WV + 255) / 256;
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -190,10 +201,17 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     const int v = threadIdx.x + 256 * q;
     const int co4 = v % (CB * 4), r = v / (CB * 4);
     const int ci = r % NC, tap = r / NC;
-    const bool ok = v < WV && co0 + co4 * 4 < p.coutp;
-    woff[q] = ok ? static_cast<unsigned>((ci * KT + tap) * p.coutp + co0 + co4 * 4) * 4u : kOOB;
+    if constexpr (PR) {
+      // virtual tap (rho, kx); vectors 0,1 = rows 0-7 (output row R+DL, ky = rho-1), vectors 2,3 = rows 8-15 (row R, ky = rho)
+      const int rho = tap / 3, kx = tap % 3, ky = rho - ((co4 >> 1) ? 0 : 1);
+      const bool ok = v < WV && ky >= 0 && ky <= 2;
+      woff[q] = ok ? static_cast<unsigned>((ci * KT + ky * 3 + kx) * p.coutp + (co4 & 1) * 4) * 4u : kOOB;
+    } else {
+      const bool ok = v < WV && co0 + co4 * 4 < p.coutp;
+      woff[q] = ok ? static_cast<unsigned>((ci * KT + tap) * p.coutp + co0 + co4 * 4) * 4u : kOOB;
+    }
     wci[q] = ci;
-    wl[q] = v < WV ? r * WP + co4 * 4 : KT * NC * WP;
+    wl[q] = v < WV ? r * WP + co4 * 4 : KTW * NC * WP;
   }
   const __amdgpu_buffer_rsrc_t xr = ig_rsrc(x + static_cast<long long>(b) * p.in_bstride, p.in_bytes);   // signed: the batch stride may be the distance between two allocations
   const __amdgpu_buffer_rsrc_t wr = ig_rsrc(w, p.w_bytes);
@@ -205,7 +223,11 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
     if (MODE == MODE_D) boff[pb] = kq * chan_elems + wave * 64 + pb * 16 + j;
-    else {
+    else if (PR) {
+      // output rows (base, base + DL) of the 8-row tile: DL 1 -> (2w, 2w+1); DL 2 -> (w&1) + 4(w>>1) + {0, 2}
+      const int base = (DL == 1) ? wave * 2 : (wave & 1) + 4 * (wave >> 1);
+      boff[pb] = kq * chan_elems + base * pitch + (pb & 1) * 16 + j;
+    } else {
       const int row = wave * 2 + (pb >> 1), col = (pb & 1) * 16 + j;
       constexpr int st = (MODE == MODE_HW) ? ST : 1;
       boff[pb] = kq * chan_elems + row * st * pitch + col * st;
@@ -225,7 +247,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = min(co0 + cb * 16 + kq * 4 + r, p.coutp - 1);     // clamped: unconditional loads, no branches
+      const int co = min(PR ? (kq & 1) * 4 + r : co0 + cb * 16 + kq * 4 + r, p.coutp - 1);     // clamped: unconditional loads, no branches
       esc[cb][r] = scale ? scale[co] : 1.f;              // null: raw convolution (training / backward-data)
       esh[cb][r] = shift ? shift[co] : 0.f;
     }
@@ -269,15 +291,15 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       if (MODE == MODE_HW) {
         // 18 steps (tap, 4 channels); the fragments of step s+1 are read from LDS before the MFMAs of
         // step s issue, so the matrix pipe never waits on an LDS round trip
-        constexpr int NS = (NC == 4) ? 9 : 18;
+        constexpr int NS = (NC == 4) ? 9 : 2 * KTW;
         float a[2][CB], bv[2][4];
         auto frag = [&](int s, int slot) {
           const int tap = (NC == 4) ? s : (s >> 1), cq = (NC == 4) ? 0 : (s & 1);
-          const int toff = (tap / 3) * DL * pitch + (tap % 3) * DL;
+          const int toff = (tap / 3) * DL * pitch + (tap % 3) * DL;          // PR: tap = (rho, kx), the same arithmetic
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb) a[slot][cb] = wt0[(tap * NC + cq * 4) * WP + cb * 16];
 #pragma unroll
-          for (int pb = 0; pb < 4; ++pb) bv[slot][pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
+          for (int pb = 0; pb < NPB; ++pb) bv[slot][pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
         };
         frag(0, 0);
 #pragma unroll
@@ -286,7 +308,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb)
+            for (int pb = 0; pb < NPB; ++pb)
               acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][cb], bv[s & 1][pb], acc[cb][pb], 0, 0, 0);
         }
       } else if (MODE == MODE_HWT) {
@@ -356,10 +378,17 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   const unsigned ocs = split ? oplane * 4u : static_cast<unsigned>(p.out_cstride) * 4u;
   const float* ab = (MODE == MODE_HW && p.addend) ? p.addend + static_cast<size_t>(b) * p.add_bstride : nullptr;
 #pragma unroll
-  for (int pb = 0; pb < 4; ++pb) {
+  for (int pb = 0; pb < NPB; ++pb) {
     unsigned opix, ppix = 0;          // element index inside a channel of y / inside one depth plane
     bool inside;
-    if (MODE == MODE_D) {
+    if (PR) {
+      // rows 0-7 of the accumulator tile (kq 0,1) = output row base + DL, rows 8-15 (kq 2,3) = output row base
+      const int base = (DL == 1) ? wave * 2 : (wave & 1) + 4 * (wave >> 1);
+      const int oy = ty0 + base + ((kq < 2) ? DL : 0), ox = tx0 + (pb & 1) * 16 + j;
+      inside = oy < p.Ho && ox < p.Wo;
+      ppix = static_cast<unsigned>(oy) * p.Wo + ox;
+      opix = static_cast<unsigned>(od) * static_cast<unsigned>(hw_o) + ppix;
+    } else if (MODE == MODE_D) {
       const unsigned px = px0 + wave * 64 + pb * 16 + j;
       inside = px < HW;
       opix = static_cast<unsigned>(od) * HW + px;
@@ -377,7 +406,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int co = co0 + cb * 16 + kq * 4 + r;
+        const int co = PR ? (kq & 1) * 4 + r : co0 + cb * 16 + kq * 4 + r;
         const unsigned off = (inside && co < p.Cout) ? opix * 4u + static_cast<unsigned>(co) * ocs : kOOB;   // per lane: VGPR
         float v = acc[cb][pb][r];
         if (!split) {
@@ -415,15 +444,18 @@ conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ 
 // Upper bound on the K chunk (8 | 16 | 32) for the launches that follow on this host thread, see
 // ts_conv_set_chunk_cap.
 thread_local int g_chunk_cap = 32;
+// TS_CONV_ROW_PAIRING=0 switches the Cout <= 8 row pairing off (A/B measurements)
+const bool g_row_pairing = [] { const char* e = getenv("TS_CONV_ROW_PAIRING"); return !(e && e[0] == '0'); }();
 
-template <int CB, int MODE, int KT, int ST, int DL, int NC>
+template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0>
 int launch_one(const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
                dim3 grid, hipStream_t st) {
   using G = Geom<MODE, KT, ST, DL>;
   constexpr int WP = (CB * 16) | 16;
-  constexpr size_t lds = (static_cast<size_t>(NC) * G::chan_elems + static_cast<size_t>(KT) * NC * WP + 4) * sizeof(float);
+  constexpr int KTW = PR ? 12 : KT;
+  constexpr size_t lds = (static_cast<size_t>(NC) * G::chan_elems + static_cast<size_t>(KTW) * NC * WP + 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "ig_conv_kernel: tile does not fit the LDS");
-  auto kern = &ig_conv_kernel<CB, MODE, KT, ST, DL, NC>;
+  auto kern = &ig_conv_kernel<CB, MODE, KT, ST, DL, NC, PR>;
   if (lds > 64 * 1024) {
     static bool raised = false;      // per instantiation
     if (!raised) {
@@ -451,6 +483,15 @@ int launch_nc(long long wgs, const float* x, const float* w, const float* scale,
     if (p.Cin <= 4 && p.ksplit == 1) return launch_one<CB, MODE, KT, ST, DL, 4>(x, w, scale, shift, y, p, grid, st);
   }
   const int max_nc = g_chunk_cap;
+  if constexpr (MODE == MODE_HW && KT == 9 && ST == 1 && CB == 1) {
+    if (p.Cout <= 8 && g_row_pairing) {           // both output rows of a wave in one 16-row MFMA (see ig_conv_kernel, PR)
+      constexpr size_t per_ch2 = (static_cast<size_t>(G::chan_elems) + 12 * WP) * sizeof(float);
+      auto fits2 = [&](int nc) { return nc <= max_nc && (nc * per_ch2 + 16) * per_cu <= lds_cu && p.kspan >= nc; };
+      if (fits2(32)) return launch_one<CB, MODE, KT, ST, DL, 32, 1>(x, w, scale, shift, y, p, grid, st);
+      if (fits2(16)) return launch_one<CB, MODE, KT, ST, DL, 16, 1>(x, w, scale, shift, y, p, grid, st);
+      return launch_one<CB, MODE, KT, ST, DL, 8, 1>(x, w, scale, shift, y, p, grid, st);
+    }
+  }
   auto fits = [&](int nc) { return nc <= max_nc && (nc * per_ch + 16) * per_cu <= lds_cu && p.kspan >= nc; };
   if constexpr (32 * per_ch + 16 <= lds_cu) { if (fits(32)) return launch_one<CB, MODE, KT, ST, DL, 32>(x, w, scale, shift, y, p, grid, st); }
   if constexpr (16 * per_ch + 16 <= lds_cu) { if (fits(16)) return launch_one<CB, MODE, KT, ST, DL, 16>(x, w, scale, shift, y, p, grid, st); }

@@ -470,8 +470,10 @@ def main():
         elapsed = float(tt.item())
 
     training = None
-    if mode == "native" and not a.no_extras:
-        try:        # every rank takes part (gradient all-reduce, SyncBatchNorm); short: it must not dominate the run
+    if mode == "native" and not a.no_extras and world == 1:
+        # (one GPU only: with several ranks the training step's collectives -- SyncBatchNorm, bucketed all-reduce -- would put
+        # the headline line at the mercy of a rank that fails inside them; `--mode train --gpus N` is the multi-GPU training run)
+        try:
             training = training_leg(dev, rank, world, 8, 3, 1, seed)
         except Exception as e:      # the headline number must survive a failure of the extra leg
             training = dict(error="%s: %s" % (type(e).__name__, e))

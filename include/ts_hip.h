@@ -70,6 +70,18 @@ size_t ts_dif_fms_workspace_bytes(void);
 int ts_dif_fms_fwd(const float* left, const float* right, const float* disp, float* out, void* workspace, int B, int C,
                    int H, int W, int D, void* stream);
 
+/* Correlation volumes, the native counterpart of the third-party SpatialCorrelationSampler the
+ * reference imports optionally (aggregation/utils/correlation.py:4-7; unvendored and unpinned, so parity is pinned by the
+ * sampler's published definition -- sum over channels, zeros outside the image -- through oracle/correlation.py):
+ *   out[b, k, y, x] = leaky_relu_0.1( sum_c left[b,c,y,x] * right[b,c, y + k/pW - pH/2, x + k%pW - pW/2] ),  k < keep
+ *   correlation   (correlation.py:10-29): patch (p, p), keep = p*p
+ *   correlation1d (correlation.py:32-57): patch (1, 2*max_disp-1), keep = max_disp  (plane k = disparity max_disp-1-k)
+ * Backward OVERWRITES grad_left / grad_right [B,C,H,W] (either may be NULL); deterministic. */
+int ts_correlation_fwd(const float* left, const float* right, float* out, int B, int C, int H, int W, int patch_h, int patch_w,
+                       int keep, void* stream);
+int ts_correlation_bwd(const float* left, const float* right, const float* out, const float* grad_out, float* grad_left,
+                       float* grad_right, int B, int C, int H, int W, int patch_h, int patch_w, int keep, void* stream);
+
 /* Backward of the two paths (autograd of the reference's torch ops).  grad_out has the layout
  * of `out`.  grad_left/grad_right [B,C,H,W] and grad_disp [B,D,H,W] are OVERWRITTEN (any may be
  * NULL to skip).  grad_right / grad_disp accumulate with fp32 atomics (order not deterministic,

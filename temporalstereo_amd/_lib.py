@@ -30,6 +30,8 @@ SIGNATURES = {
     "ts_cat_fms_fwd": (c_int, [c_f32p] * 4 + [c_int] * 5 + [c_ptr]),
     "ts_dif_fms_workspace_bytes": (c_size, []),
     "ts_dif_fms_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 5 + [c_ptr]),
+    "ts_correlation_fwd": (c_int, [c_f32p] * 3 + [c_int] * 7 + [c_ptr]),
+    "ts_correlation_bwd": (c_int, [c_f32p] * 6 + [c_int] * 7 + [c_ptr]),
     "ts_block_cost_bwd_workspace_bytes": (c_size, [c_int] * 6),
     "ts_block_cost_int_bwd": (c_int, [c_f32p] * 5 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_bwd": (c_int, [c_f32p] * 7 + [c_ptr] + [c_int] * 6 + [c_ptr]),

@@ -78,6 +78,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_calib_stream),             TS_PLAN_OP(ts_conv_set_chunk_cap),
     TS_PLAN_OP(ts_wasserstein_loss_fwd),     TS_PLAN_OP(ts_wasserstein_loss_bwd),
     TS_PLAN_OP(ts_disp_smooth_l1_fwd),       TS_PLAN_OP(ts_disp_smooth_l1_bwd),
+    TS_PLAN_OP(ts_correlation_fwd),          TS_PLAN_OP(ts_correlation_bwd),
 };
 
 struct Call {

@@ -200,6 +200,57 @@ def dif_fms(reference_fm, target_fm, disp_sample):
     return _DifFms.apply(reference_fm, target_fm, disp_sample)
 
 
+class _Correlation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left, right, ph, pw, keep):
+        _require_gpu(left, right)
+        if left.dim() != 4 or left.shape != right.shape:
+            raise ValueError("reference_fm / target_fm must be [B,C,H,W] of equal shape")
+        left, right = _lib.contiguous(left), _lib.contiguous(right)
+        B, C, H, W = left.shape
+        out = torch.empty((B, keep, H, W), device=left.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ts_correlation_fwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(out), B, C, H, W, ph, pw, keep, _stream()),
+                   "ts_correlation_fwd")
+        ctx.save_for_backward(left, right, out)
+        ctx.meta = (ph, pw, keep)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        left, right, out = ctx.saved_tensors
+        ph, pw, keep = ctx.meta
+        B, C, H, W = left.shape
+        gl = torch.empty_like(left) if ctx.needs_input_grad[0] else None
+        gr = torch.empty_like(right) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.lib().ts_correlation_bwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(out), _lib.ptr(_lib.contiguous(g)),
+                                                 _lib.ptr(gl), _lib.ptr(gr), B, C, H, W, ph, pw, keep, _stream()), "ts_correlation_bwd")
+        return gl, gr, None, None, None
+
+
+def _corr_args(kernel_size, stride, padding, dilation, dilation_patch):
+    if (kernel_size, stride, padding, dilation, dilation_patch) != (1, 1, 0, 1, 1):
+        raise NotImplementedError("native correlation: kernel_size=1, stride=1, padding=0, dilation=1, dilation_patch=1 "
+                                  "(what the reference's callers pass)")
+
+
+def correlation(reference_fm, target_fm, patch_size=1, kernel_size=1, stride=1, padding=0, dilation=1, dilation_patch=1):
+    """aggregation/utils/correlation.py:10-29 (same arguments): [B, patch_size^2, H, W], plane ph*p+pw = correlation with the
+    right pixel at (y + ph - p//2, x + pw - p//2), leaky_relu(0.1) applied.  Native replacement of the third-party sampler."""
+    _corr_args(kernel_size, stride, padding, dilation, dilation_patch)
+    if patch_size < 1 or patch_size % 2 != 1:
+        raise ValueError("patch_size must be odd")
+    return _Correlation.apply(reference_fm, target_fm, patch_size, patch_size, patch_size * patch_size)
+
+
+def correlation1d(reference_fm, target_fm, max_disp=1, kernel_size=1, stride=1, padding=0, dilation=1, dilation_patch=1):
+    """aggregation/utils/correlation.py:32-57 (same arguments): [B, max_disp, H, W]; plane k correlates the left pixel x with
+    the right pixel x + k - (max_disp - 1), i.e. disparity max_disp - 1 - k."""
+    _corr_args(kernel_size, stride, padding, dilation, dilation_patch)
+    if max_disp < 1:
+        raise ValueError("max_disp must be >= 1")
+    return _Correlation.apply(reference_fm, target_fm, 1, 2 * max_disp - 1, max_disp)
+
+
 # --------------------------------------------------------------------------------------- K3 convolutions
 def _pad_last(t, n):
     if t.shape[-1] == n:

@@ -217,6 +217,66 @@ class InferenceEngine:
         with torch.cuda.device(self.device):
             return self._run(left_feats, right_feats, left_image, right_image, prev_info)
 
+    # ------------------------------------------------------------------------------------------------ two-phase calls
+    def begin(self, left_feats, right_feats, left_image, right_image):
+        """First half of a pass: everything that depends on the frame's features / images only (see NativeAggregator.begin).
+        For temporal sequences: call begin(frame t+1) right after finish(frame t) was issued, then update_map, then
+        finish(handle, state) -- on the device the early part of t+1 overlaps the tail and the state update of t.
+        Needs backend='native', replay='plan', inputs='bind' (the bound tensors must be complete on the device when begin is
+        called, and stay untouched until finish has been issued)."""
+        if not (self.backend == "native" and self.replay == "plan" and self.bind):
+            raise RuntimeError("begin/finish need backend='native', replay='plan', inputs='bind'")
+        if self._stale or self._weights_stamp() != self._stamp:
+            self.refresh()
+        with torch.cuda.device(self.device):
+            args = (list(left_feats), list(right_feats), left_image, right_image)
+            key = _sig_of(args) + (_ptrs_of(args),) + (torch.cuda.current_stream().cuda_stream,)
+            turn = self._turn.get(key, 0)
+            self._turn[key] = (turn + 1) % 2                      # two buffer sets, used alternately
+            key = key + ("begin", turn)
+            cap = self._graphs.get(key)
+            if cap is None:
+                from .. import _lib
+                slots = (_new_event_slot(), _new_event_slot())
+                with torch.no_grad():
+                    self.net.begin(*args, slots)                    # allocator growth, lazy initialisation
+                    torch.cuda.synchronize()
+                    rec = _lib.Recorder()
+                    with rec:
+                        ctx = self.net.begin(*args, slots)
+                torch.cuda.synchronize()
+                cap = self._graphs[key] = _Recorded(rec, args, ctx)
+                cap.late = {}
+            else:
+                cap.replay()
+            return cap
+
+    def finish(self, handle, prev_info):
+        """Second half: candidate merges, fine level, 1/4-level tail.  Returns what __call__ returns."""
+        with torch.cuda.device(self.device):
+            state = {k: v for k, v in prev_info.items()
+                     if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}
+            sig = _sig_of(state)
+            late = handle.late.get(sig)
+            if late is None:
+                from .. import _lib
+                static_state = _clone_static(state)
+                with torch.no_grad():
+                    self.net.finish(handle.static_out, dict(static_state))
+                    torch.cuda.synchronize()
+                    rec = _lib.Recorder()
+                    with rec:
+                        out = self.net.finish(handle.static_out, dict(static_state))
+                torch.cuda.synchronize()
+                late = handle.late[sig] = _Recorded(rec, static_state, out)
+            else:
+                _copy_into(late.static_in, state)
+                late.replay()
+            disps, costs, samples, offs, ranges, info = late.static_out
+            out_info = dict(prev_info)
+            out_info.update(info)
+            return disps, costs, samples, offs, ranges, out_info
+
     def _run(self, left_feats, right_feats, left_image, right_image, prev_info):
         state = {k: v for k, v in prev_info.items()
                  if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}

@@ -561,9 +561,14 @@ class _MergingLevel(_LevelBase):
 
 
 class NativeCoarse(_MergingLevel):
-    def __call__(self, left, right, prev_info, mask=None, next_range=None):
-        raw = TF.block_cost(left, right, int(self.mod.num_sample), self.scales)
-        return self.merge_fuse_predict(self.init3d(raw), None, prev_info, left, resize_memory=True, mask=mask, next_range=next_range)
+    def early(self, left, right):
+        """Everything of the level that does not look at the temporal state (coarse.py:79-83): cost volume + init3d."""
+        return self.init3d(TF.block_cost(left, right, int(self.mod.num_sample), self.scales))
+
+    def __call__(self, left, right, prev_info, mask=None, next_range=None, vol=None):
+        if vol is None:
+            vol = self.early(left, right)
+        return self.merge_fuse_predict(vol, None, prev_info, left, resize_memory=True, mask=mask, next_range=next_range)
 
 
 class NativeFine(_MergingLevel):
@@ -688,12 +693,12 @@ class NativeAggregator:
         result is a private COPY of the parameters: call again (InferenceEngine.refresh does) after they change."""
         self.coarse, self.fine, self.precise = NativeCoarse(net.coarse), NativeFine(net.fine), NativePrecise(net.precise)
 
-    def _coarse_level(self, l16, r16, prev_info, out, mask=None):
+    def _coarse_level(self, l16, r16, prev_info, out, mask=None, vol=None):
         rng = 4
         disps, costs, offs, samples, ranges = out
         lm = prev_info.get('local_map', None)                       # fine.py:89-93: local-map candidates go first
         nl = lm.shape[1] if (lm is not None and prev_info.get('local_map_size', 0) > 0) else 0
-        (d, low, high, ds), c, o, s = self.coarse(_lib.contiguous(l16), _lib.contiguous(r16), prev_info, mask, (rng, nl))
+        (d, low, high, ds), c, o, s = self.coarse(_lib.contiguous(l16), _lib.contiguous(r16), prev_info, mask, (rng, nl), vol=vol)
         if nl:
             resize_bilinear(lm, d.shape[-2:], d.shape[-1] / lm.shape[-1], out=ds[:, :nl])
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
@@ -736,6 +741,64 @@ class NativeAggregator:
         finally:
             _chunk_cap(32)
         return res
+
+    # ---------------------------------------------------------------------------------------------- two-phase pass
+    # A temporal sequence has a true dependency from frame to frame -- but only from the candidate merge of the coarse level
+    # onwards (coarse.py:84-105: the cost memory enters there; the local map at the fine level's candidates, fine.py:89-93).
+    # Everything before it looks at the NEW frame only: the coarse cost volume + init3d, the upsampling logits, the fine
+    # level's left term and the whole disparity-independent half of the refinement UNet (~40 % of a pass's kernel time).
+    # `begin` issues that part on the two helper streams, `finish` the rest once the state is there; between the two the
+    # caller runs update_map for the previous frame.  On the device, begin(t+1) overlaps the 1/4-level tail of frame t and its
+    # update_map, which run on the caller's stream.  The engine alternates two buffer sets so that begin(t+1) never writes
+    # what finish(t) still reads; `slots` = (set-is-free event, logits-are-ready event).
+    @torch.no_grad()
+    def begin(self, left_feats, right_feats, left_image, right_image, slots):
+        with torch.cuda.device(self.device):
+            L = _lib.lib()
+            P = lambda st: _lib.ctypes.c_void_p(st.cuda_stream)
+            l4, l8, l16 = left_feats
+            r4, r8, r16 = right_feats
+            left_image, right_image = _lib.contiguous(left_image), _lib.contiguous(right_image)
+            _lib.check(L.ts_event_wait(slots[0], P(self.fast)), "ts_event_wait")       # the pass that last used this set is done
+            _lib.check(L.ts_event_wait(slots[0], P(self.aux)), "ts_event_wait")
+            try:
+                _chunk_cap(8)
+                with torch.cuda.stream(self.aux):
+                    mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
+                    ltf = self.fine.left_term(_lib.contiguous(l8))
+                    _lib.check(L.ts_event_record(slots[1], P(self.aux)), "ts_event_record")
+                with torch.cuda.stream(self.fast):
+                    vol = self.coarse.early(_lib.contiguous(l16), _lib.contiguous(r16))
+                with torch.cuda.stream(self.aux):
+                    both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
+            finally:
+                _chunk_cap(32)
+            return dict(mc=mc, mf=mf, ltf=ltf, vol=vol, both=both, mask=mask, feats=(l8, l16, r8, r16), slots=slots)
+
+    @torch.no_grad()
+    def finish(self, ctx, prev_info):
+        with torch.cuda.device(self.device):
+            L = _lib.lib()
+            P = lambda st: _lib.ctypes.c_void_p(st.cuda_stream)
+            main = torch.cuda.current_stream()
+            l8, l16, r8, r16 = ctx["feats"]
+            out = ([], [], [], [], [])
+            disps, costs, offs, samples, ranges = out
+            _edge(main, self.fast)                       # the state (update_map, copies) was produced on the caller's stream
+            try:
+                _chunk_cap(8)
+                with torch.cuda.stream(self.fast):
+                    _lib.check(L.ts_event_wait(ctx["slots"][1], P(self.fast)), "ts_event_wait")     # logits + left term (not the UNet half)
+                    ds = self._coarse_level(l16, r16, prev_info, out, ctx["mc"], vol=ctx["vol"])
+                    ds = self._fine_level(l8, r8, ds, prev_info, out, ctx["mf"], ctx["ltf"])
+                _edge(self.fast, main)
+                _edge(self.aux, main)                    # the UNet half of begin()
+                full, d, c, o, s = self.precise(ctx["both"], ctx["mask"], ds, prev_info)
+                _lib.check(L.ts_event_record(ctx["slots"][0], P(main)), "ts_event_record")
+            finally:
+                _chunk_cap(32)
+            disps += [d, full]; costs.append(c); offs.append(o); samples.append(s)
+            return disps[::-1], costs[::-1], samples[::-1], offs[::-1], ranges[::-1], prev_info
 
     @torch.no_grad()
     def __call__(self, left_feats, right_feats, left_image, right_image, prev_info):

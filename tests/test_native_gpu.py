@@ -364,3 +364,59 @@ def test_ops_refuse_cpu_and_mixed_inputs():
     x = torch.zeros(1, 8, 4, 8)
     with pytest.raises(RuntimeError):
         ts.block_cost(x, x, 3, 3)
+
+
+def test_two_phase_sequence_is_bit_identical_to_single_calls():
+    """engine.begin / finish (frame t+1's state-independent half issued before frame t's state update; two alternating buffer
+    sets) against plain calls of the same engine kind, over a four-frame temporal sequence with growing local maps."""
+    import synth
+    import bench
+    from temporalstereo_amd import temporal
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    dev = torch.device("cuda:0")
+    seed = synth.SEED0 + 77
+    B, H, W = 2, 192, 320
+    net = bench.build_model(dev, seed, 6)
+    frames = [bench.make_inputs(dev, seed + 10 * t, B, (H, W)) for t in range(4)]
+    bench.calibrate_batchnorm(net, frames[0])
+    K = torch.from_numpy(synth.sceneflow_intrinsics(B, H, W)).to(dev)
+    T = torch.from_numpy(synth.small_motion(seed, B)).to(dev)
+    eye = torch.eye(4, device=dev).expand(B, 4, 4).contiguous()
+
+    def update(info):
+        return temporal.update_map(dict(info), K, T, eye, 0.54, H, W, use_past_cost=True, local_map_size=3)
+
+    def clone(out):
+        return [d.clone() for d in out[0]], {k: (v.clone() if torch.is_tensor(v) else ({a: b.clone() for a, b in v.items()} if isinstance(v, dict) else v))
+                                            for k, v in out[5].items()}
+    plain = InferenceEngine(net, backend="native", replay="plan")
+    want, states, info = [], [], {}
+    for t in range(4):
+        # the splat inside update_map accumulates with fp32 atomics (run-to-run rounding differs, as in the reference): both
+        # engines are fed the SAME updated states
+        state = {} if t == 0 else update(info)
+        states.append({k: (v.clone() if torch.is_tensor(v) else ({a: b.clone() for a, b in v.items()} if isinstance(v, dict) else v)) for k, v in state.items()})
+        d, info = clone(plain(*frames[t], state))
+        want.append(d)
+    # the frames live in ONE set of bound tensors that the producer refills (begin(t+1) is issued after finish(t) was issued;
+    # the copy into the bound tensors is ordered on the caller's stream and begin's streams do not wait for it -> synchronise)
+    bound = [[x.clone() for x in frames[0][0]], [x.clone() for x in frames[0][1]], frames[0][2].clone(), frames[0][3].clone()]
+
+    def load(t):
+        torch.cuda.synchronize()
+        for dst, src in zip(bound[0] + bound[1] + bound[2:], frames[t][0] + frames[t][1] + list(frames[t][2:])):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+    eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind")
+    for rep in range(2):                                   # second repetition: every plan is a replay
+        load(0)
+        out = eng.finish(eng.begin(*bound), {})
+        d, info = clone(out)
+        assert all(float((a - b).abs().max()) == 0.0 for a, b in zip(d, want[0])), "frame 0"
+        for t in range(1, 4):
+            load(t)
+            h = eng.begin(*bound)
+            update(info)                                     # the state update the early half overlaps (its result is replaced by
+            out = eng.finish(h, dict(states[t]))             # the recorded one, see above)
+            d, info = clone(out)
+            assert all(float((a - b).abs().max()) == 0.0 for a, b in zip(d, want[t])), "frame %d (repetition %d)" % (t, rep)

@@ -27,7 +27,7 @@ CONFIGS = {
 }
 
 
-def run(idx, frames, iters):
+def run(idx, frames, iters, two_phase=True):
     from temporalstereo_amd import temporal
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     c = CONFIGS[idx]
@@ -37,7 +37,7 @@ def run(idx, frames, iters):
     net = bench.build_model(dev, seed, c["num_sample"])
     inputs = bench.make_inputs(dev, seed, B, (H, W))
     bench.calibrate_batchnorm(net, inputs)
-    eng = InferenceEngine(net, backend="native", replay="plan")
+    eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind" if two_phase else "copy")
     K = torch.from_numpy(synth.sceneflow_intrinsics(B, H, W)).to(dev)
     T = torch.from_numpy(synth.small_motion(seed, B)).to(dev)
     Ti = torch.inverse(T)
@@ -46,9 +46,17 @@ def run(idx, frames, iters):
         return temporal.update_map(info, K, T, Ti, 0.54, H, W, use_past_cost=True, local_map_size=c["local"])
 
     def sequence():
-        out = eng(*inputs, {})
+        if not two_phase:
+            out = eng(*inputs, {})
+            for _ in range(frames - 1):
+                out = eng(*inputs, update(out[5]))
+            return out
+        # two-phase: the state-independent half of frame t+1 is issued before frame t's state update, so that on the device
+        # it overlaps frame t's 1/4-level tail and update_map (engine.begin / finish)
+        out = eng.finish(eng.begin(*inputs), {})
         for _ in range(frames - 1):
-            out = eng(*inputs, update(out[5]))
+            h = eng.begin(*inputs)
+            out = eng.finish(h, update(out[5]))
         return out
 
     with torch.no_grad():
@@ -71,7 +79,9 @@ def run(idx, frames, iters):
         t_temporal = timed(lambda: eng(*inputs, state), iters)
     return dict(config=idx, workload=c["name"], frames=frames, batch=B, ms_per_sequence=t_seq * 1e3,
                 pairs_per_s=B * frames / t_seq, ms_single_pass=t_single * 1e3, ms_update_map=t_update * 1e3,
-                ms_temporal_pass=t_temporal * 1e3, local_map_size=c["local"])
+                ms_temporal_pass=t_temporal * 1e3, local_map_size=c["local"],
+                schedule="two-phase (begin/finish: frame t+1's state-independent half overlaps frame t's tail and update_map)" if two_phase
+                else "one pass at a time")
 
 
 if __name__ == "__main__":
@@ -79,6 +89,7 @@ if __name__ == "__main__":
     ap.add_argument("--configs", type=int, nargs="+", default=[2, 3, 4])
     ap.add_argument("--frames", type=int, default=2)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--one-at-a-time", action="store_true")
     a = ap.parse_args()
     for i in a.configs:
-        print(json.dumps(run(i, a.frames, a.iters)), flush=True)
+        print(json.dumps(run(i, a.frames, a.iters, not a.one_at_a_time)), flush=True)

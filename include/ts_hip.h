@@ -98,6 +98,31 @@ int ts_block_cost_sampled_bwd(const float* left, const float* right, const float
                               int B, int C, int H, int W, int D, int scales, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * BatchNorm (+ activation) of the convolution wrappers in TRAIN mode (layers/basic_layers.py:194-235: conv -> norm ->
+ * activation).  x / out / dy / dx are [B,C,N] with N = D*H*W contiguous and explicit batch / channel strides (elements).
+ *   ts_bn_stats_fwd       mean[C], var[C] (biased) of x over (B,N); deterministic.  running_mean / running_var (may be NULL) are
+ *                         updated with `momentum` (running_var with the unbiased estimate, as nn.BatchNorm)
+ *   ts_bn_apply_act_fwd   out = act((x - mean) * rsqrt(var + eps) * gamma + beta);  act 0 none | 1 SiLU | 2 ReLU
+ *   ts_bn_act_bwd_reduce  sum_dz[C] = sum dz, sum_dz_xhat[C] = sum dz * xhat with dz = dy * act'(z)  (= grad beta, grad gamma)
+ *   ts_bn_act_bwd_apply   train: dx = (dz - sum_dz/count - xhat * sum_dz_xhat/count) * invstd * gamma; eval: dx = dz * invstd * gamma
+ * mean / var / the two sums are arguments so that cross-rank statistics (SyncBatchNorm) can be exchanged in between.
+ * ---------------------------------------------------------------------------------------- */
+size_t ts_bn_workspace_bytes(int B, int C, long long N);
+int ts_bn_stats_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                    void* workspace, int B, int C, long long N, long long bstride, long long cstride, void* stream);
+int ts_bn_apply_act_fwd(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* out,
+                        int B, int C, long long N, long long x_bstride, long long x_cstride, long long out_bstride,
+                        long long out_cstride, float eps, int act, void* stream);
+int ts_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float* sum_dz, float* sum_dz_xhat, void* workspace, int B, int C, long long N,
+                         long long x_bstride, long long x_cstride, long long dy_bstride, long long dy_cstride, float eps, int act,
+                         void* stream);
+int ts_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* var, const float* gamma,
+                        const float* beta, const float* sum_dz, const float* sum_dz_xhat, float* dx, int B, int C, long long N,
+                        long long x_bstride, long long x_cstride, long long dy_bstride, long long dy_cstride, float eps, int act,
+                        int train, float count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Loss side of the path's outputs.
  * ts_wasserstein_loss_*: WarssersteinDistanceLoss.loss_per_level  architecture/modeling/losses/warsserstein_distance_loss.py:52-78
  *   cost/offset/sample [B,D,H,W], gt [B,1,Hg,Wg] (full resolution; pooled to (H,W) after / (Wg/W): avg, or max when `sparse`).

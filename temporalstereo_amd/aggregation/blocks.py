@@ -105,7 +105,13 @@ class ConvexUpsample(nn.Module):
         r, k = self.upscale_factor, self.window_size
         if k % 2 != 1:
             raise ValueError("window_size must be odd, got %d" % k)
-        w = torch.softmax(self.mask(input).view(B, 1, k * k, r, r, H, W), dim=2)
+        if _on_hip(input):        # conv 3x3 + BatchNorm + SiLU as one fused node, the 1x1 conv on the (k,1,1) family
+            m0, bn, m3 = self.mask[0], self.mask[1], self.mask[3]
+            m = TF.conv_bn_act(input.unsqueeze(2), m0.weight.unsqueeze(2), m0.bias, bn, "SiLU", "hw", (1, 1, False))
+            logits = TF.conv3d(m, m3.weight.unsqueeze(2), m3.bias, (1, 1, 1), (0, 0, 0), (1, 1, 1)).squeeze(2)
+        else:
+            logits = self.mask(input)
+        w = torch.softmax(logits.view(B, 1, k * k, r, r, H, W), dim=2)
         scale = r if disp_scale is None else disp_scale
         nb = F.unfold(disp * scale, kernel_size=(k, k), padding=(k // 2, k // 2)).view(B, C, k * k, 1, 1, H, W)
         up = torch.sum(w * nb, dim=2).permute(0, 1, 4, 2, 5, 3).contiguous()

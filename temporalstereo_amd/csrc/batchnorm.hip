@@ -1,0 +1,275 @@
+// Train-mode BatchNorm + activation for the convolution wrappers of the path (training form), gfx950.
+//
+// The reference's Conv3d / Conv2d / ConvTranspose wrappers are conv -> BatchNorm -> activation
+// (architecture/modeling/layers/basic_layers.py:194-235: `self.norm`, `self.activation` applied in forward); in train()
+// mode BatchNorm uses the batch statistics and cannot be folded into the convolution.  As framework ops that is a
+// statistics kernel, a normalisation kernel and an activation kernel per layer forward, and their three autograd
+// nodes backward -- 88 layers per frame.  Here:
+//   bn_stats      per channel mean / biased variance of x [B,C,N] in two deterministic stages (per-chunk sums of
+//                 x - pivot and (x - pivot)^2, pivot = the channel's first element, so that E[x'^2] - E[x']^2 does
+//                 not cancel; fixed-order finish in double), optionally updating the running statistics
+//   bn_apply_act  out = act((x - mean) * rsqrt(var + eps) * gamma + beta)            (act: none | SiLU | ReLU)
+//   bn_bwd_reduce s1[c] = sum dz, s2[c] = sum dz * xhat,  dz = dy * act'(z), z recomputed from x (no z / xhat kept)
+//   bn_bwd_apply  dx = (dz - s1/n - xhat * s2/n) * invstd * gamma     (train);  dx = dz * invstd * gamma   (eval)
+// HBM-bound element kernels: 16 bytes per lane where the plane length allows it.  Cross-rank statistics
+// (SyncBatchNorm, dist.py) enter between bn_stats and bn_apply_act / between bn_bwd_reduce and bn_bwd_apply as
+// all-reduced [C] vectors: the kernels take mean / var / s1 / s2 / n as arguments.
+#include "ts_common.hpp"
+
+namespace {
+
+enum { BN_ACT_NONE = 0, BN_ACT_SILU = 1, BN_ACT_RELU = 2 };
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == BN_ACT_SILU) return z / (1.f + expf(-z));
+  if (act == BN_ACT_RELU) return fmaxf(z, 0.f);
+  return z;
+}
+
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == BN_ACT_SILU) {
+    const float s = 1.f / (1.f + expf(-z));
+    return s * (1.f + z * (1.f - s));
+  }
+  if (act == BN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ void block_sum2(float& a, float& b) {      // 256 threads -> thread 0
+  __shared__ float sa[4], sb[4];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = sa[0] + sa[1] + sa[2] + sa[3];
+    b = sb[0] + sb[1] + sb[2] + sb[3];
+  }
+}
+
+struct BN {
+  int B, C;
+  long long N;                  // elements per (batch, channel) plane block (D*H*W), contiguous
+  long long bstride, cstride;   // of x (elements)
+  int nchunk;                   // chunks per (batch item, channel)
+  long long chunk;              // elements per chunk
+};
+
+// grid (nchunk, C, B): partial[(c * B + b) * nchunk + k] = (sum x', sum x'^2), x' = x - x[b=0, c, 0]
+__global__ void __launch_bounds__(256)
+bn_stats_partial(const float* __restrict__ x, float2* __restrict__ partial, const BN p) {
+  const int k = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const float pivot = x[static_cast<size_t>(c) * p.cstride];
+  const float* xp = x + static_cast<size_t>(b) * p.bstride + static_cast<size_t>(c) * p.cstride;
+  const long long lo = k * p.chunk, hi = min(p.N, lo + p.chunk);
+  float s = 0.f, q = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = xp[i] - pivot;
+    s += v;
+    q += v * v;
+  }
+  block_sum2(s, q);
+  if (threadIdx.x == 0) partial[(static_cast<size_t>(c) * p.B + b) * p.nchunk + k] = make_float2(s, q);
+}
+
+// one workgroup per channel: fixed-order sum in double -> mean, biased variance; optional running update
+// (running_var takes the unbiased estimate, as nn.BatchNorm does)
+__global__ void __launch_bounds__(64)
+bn_stats_finish(const float* __restrict__ x, const float2* __restrict__ partial, float* __restrict__ mean, float* __restrict__ var,
+                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, const BN p) {
+  const int c = blockIdx.x;
+  const int n = p.B * p.nchunk;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const float2 v = partial[static_cast<size_t>(c) * n + i];
+    s += v.x;
+    q += v.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (threadIdx.x == 0) {
+    const double cnt = static_cast<double>(p.B) * static_cast<double>(p.N);
+    const double m1 = s / cnt;
+    const double v = fmax(q / cnt - m1 * m1, 0.0);
+    const float m = static_cast<float>(m1 + static_cast<double>(x[static_cast<size_t>(c) * p.cstride]));
+    mean[c] = m;
+    var[c] = static_cast<float>(v);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      const double unb = cnt > 1.0 ? v * cnt / (cnt - 1.0) : v;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * static_cast<float>(unb);
+    }
+  }
+}
+
+struct BNA {
+  int B, C;
+  long long N;
+  long long xb, xc, ob, oc;     // strides (elements) of x / dy and of out / dx
+  int act, train;
+  float eps, inv_n;
+};
+
+// grid (chunks of 1024 elements, C, B)
+__global__ void __launch_bounds__(256)
+bn_apply_act_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out, const BNA p) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float m = mean[c], is = rsqrtf(var[c] + p.eps);
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float sc = is * g, sh = be - m * sc;
+  const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+  float* op = out + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
+  const long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i0 + k < p.N) op[i0 + k] = act_fwd(xp[i0 + k] * sc + sh, p.act);
+}
+
+// grid (nchunk, C, B): partial sums of dz and dz * xhat
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                     const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                     float2* __restrict__ partial, const BNA p, int nchunk, long long chunk) {
+  const int k = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const float m = mean[c], is = rsqrtf(var[c] + p.eps);
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+  const float* gp = dy + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
+  const long long lo = k * chunk, hi = min(p.N, lo + chunk);
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float xh = (xp[i] - m) * is;
+    const float dz = gp[i] * act_grad(xh * g + be, p.act);
+    s1 += dz;
+    s2 += dz * xh;
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) partial[(static_cast<size_t>(c) * p.B + b) * nchunk + k] = make_float2(s1, s2);
+}
+
+__global__ void __launch_bounds__(64)
+bn_bwd_finish_kernel(const float2* __restrict__ partial, float* __restrict__ s1, float* __restrict__ s2, int n) {
+  const int c = blockIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const float2 v = partial[static_cast<size_t>(c) * n + i];
+    a += v.x;
+    b += v.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if (threadIdx.x == 0) { s1[c] = static_cast<float>(a); s2[c] = static_cast<float>(b); }
+}
+
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                    const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    const float* __restrict__ s1, const float* __restrict__ s2, float* __restrict__ dx, const BNA p) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float m = mean[c], is = rsqrtf(var[c] + p.eps);
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float a1 = p.train ? s1[c] * p.inv_n : 0.f, a2 = p.train ? s2[c] * p.inv_n : 0.f;
+  const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+  const float* gp = dy + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
+  float* op = dx + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+  const long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i0 + k < p.N) {
+      const float xh = (xp[i0 + k] - m) * is;
+      const float dz = gp[i0 + k] * act_grad(xh * g + be, p.act);
+      op[i0 + k] = (dz - a1 - xh * a2) * is * g;
+    }
+}
+
+int chunks_for(long long N, int B, int C, long long& chunk) {
+  // enough workgroups to fill the chip (C * B * nchunk >= ~1024) without making chunks shorter than 1024 elements
+  int n = static_cast<int>((1024 + static_cast<long long>(B) * C - 1) / (static_cast<long long>(B) * C));
+  const long long maxn = (N + 1023) / 1024;
+  if (n > maxn) n = static_cast<int>(maxn);
+  if (n < 1) n = 1;
+  chunk = (N + n - 1) / n;
+  return n;
+}
+
+}  // namespace
+
+extern "C" size_t ts_bn_workspace_bytes(int B, int C, long long N) {
+  if (B <= 0 || C <= 0 || N <= 0) return 0;
+  long long chunk;
+  const int n = chunks_for(N, B, C, chunk);
+  return ts::round_up(static_cast<size_t>(B) * C * n * sizeof(float2), 256);
+}
+
+extern "C" int ts_bn_stats_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                               void* workspace, int B, int C, long long N, long long bstride, long long cstride, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535, TS_ERR_SHAPE, "bn_stats: bad size");
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(workspace);
+  BN p{B, C, N, bstride, cstride, 0, 0};
+  p.nchunk = chunks_for(N, B, C, p.chunk);
+  float2* partial = reinterpret_cast<float2*>(workspace);
+  hipLaunchKernelGGL(bn_stats_partial, dim3(p.nchunk, C, B), dim3(256), 0, ts::as_stream(stream), x, partial, p);
+  if (int rc = ts::launched("bn_stats_partial")) return rc;
+  hipLaunchKernelGGL(bn_stats_finish, dim3(C), dim3(64), 0, ts::as_stream(stream), x, partial, mean, var, running_mean, running_var,
+                     momentum, p);
+  return ts::launched("bn_stats_finish");
+}
+
+extern "C" int ts_bn_apply_act_fwd(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                                   float* out, int B, int C, long long N, long long x_bstride, long long x_cstride,
+                                   long long out_bstride, long long out_cstride, float eps, int act, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535, TS_ERR_SHAPE, "bn_apply: bad size");
+  TS_REQUIRE(act >= 0 && act <= 2, TS_ERR_UNSUPPORTED, "bn_apply: activation %d", act);
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(out);
+  const BNA p{B, C, N, x_bstride, x_cstride, out_bstride, out_cstride, act, 0, eps, 0.f};
+  hipLaunchKernelGGL(bn_apply_act_kernel, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0, ts::as_stream(stream),
+                     x, mean, var, gamma, beta, out, p);
+  return ts::launched("bn_apply_act_kernel");
+}
+
+extern "C" int ts_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* var, const float* gamma,
+                                    const float* beta, float* sum_dz, float* sum_dz_xhat, void* workspace, int B, int C,
+                                    long long N, long long x_bstride, long long x_cstride, long long dy_bstride,
+                                    long long dy_cstride, float eps, int act, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535, TS_ERR_SHAPE, "bn_bwd: bad size");
+  TS_REQUIRE(act >= 0 && act <= 2, TS_ERR_UNSUPPORTED, "bn_bwd: activation %d", act);
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(dy); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(sum_dz);
+  TS_REQUIRE_PTR(sum_dz_xhat); TS_REQUIRE_PTR(workspace);
+  const BNA p{B, C, N, x_bstride, x_cstride, dy_bstride, dy_cstride, act, 1, eps, 0.f};
+  long long chunk;
+  const int n = chunks_for(N, B, C, chunk);
+  float2* partial = reinterpret_cast<float2*>(workspace);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(n, C, B), dim3(256), 0, ts::as_stream(stream), x, dy, mean, var, gamma, beta, partial,
+                     p, n, chunk);
+  if (int rc = ts::launched("bn_bwd_reduce_kernel")) return rc;
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(64), 0, ts::as_stream(stream), partial, sum_dz, sum_dz_xhat, B * n);
+  return ts::launched("bn_bwd_finish_kernel");
+}
+
+extern "C" int ts_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* var, const float* gamma,
+                                   const float* beta, const float* sum_dz, const float* sum_dz_xhat, float* dx, int B, int C,
+                                   long long N, long long x_bstride, long long x_cstride, long long dy_bstride,
+                                   long long dy_cstride, float eps, int act, int train, float count, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535, TS_ERR_SHAPE, "bn_bwd: bad size");
+  TS_REQUIRE(act >= 0 && act <= 2, TS_ERR_UNSUPPORTED, "bn_bwd: activation %d", act);
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(dy); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(dx);
+  if (train) { TS_REQUIRE_PTR(sum_dz); TS_REQUIRE_PTR(sum_dz_xhat); TS_REQUIRE(count > 0.f, TS_ERR_SHAPE, "bn_bwd: count"); }
+  const BNA p{B, C, N, x_bstride, x_cstride, dy_bstride, dy_cstride, act, train, eps, train ? 1.f / count : 0.f};
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0, ts::as_stream(stream),
+                     x, dy, mean, var, gamma, beta, sum_dz, sum_dz_xhat, dx, p);
+  return ts::launched("bn_bwd_apply_kernel");
+}

@@ -79,6 +79,8 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_wasserstein_loss_fwd),     TS_PLAN_OP(ts_wasserstein_loss_bwd),
     TS_PLAN_OP(ts_disp_smooth_l1_fwd),       TS_PLAN_OP(ts_disp_smooth_l1_bwd),
     TS_PLAN_OP(ts_correlation_fwd),          TS_PLAN_OP(ts_correlation_bwd),
+    TS_PLAN_OP(ts_bn_stats_fwd),             TS_PLAN_OP(ts_bn_apply_act_fwd),
+    TS_PLAN_OP(ts_bn_act_bwd_reduce),        TS_PLAN_OP(ts_bn_act_bwd_apply),
 };
 
 struct Call {

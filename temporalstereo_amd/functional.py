@@ -264,6 +264,70 @@ def _cpad(n):
     return int(_lib.lib().ts_conv_cout_pad(n))
 
 
+def _shift_vec(bias, n):
+    """[coutp] epilogue shift holding the bias (the kernels add it to the raw sum: scale stays 1)."""
+    if bias is None:
+        return None
+    v = torch.zeros(n, device=bias.device, dtype=torch.float32)
+    v[:bias.numel()] = bias.detach()
+    return v
+
+
+def _hw_forward(x, weight, stride, dilation, transposed, bias=None):
+    """Raw Conv3d (1,3,3) [padding == dilation] / ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1 (+ bias)."""
+    _require_gpu(x, weight)
+    x = x.contiguous()
+    B, Cin, D, H, W = x.shape
+    w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
+    if transposed:                                   # weight [Cin, Cout, 1, 3, 3]
+        Cout = weight.shape[1]
+        w_t = _pad_last(w9.permute(0, 2, 1), _cpad(Cout))                       # [ci][t][co]
+        Ho, Wo = 2 * H, 2 * W
+    else:                                            # weight [Cout, Cin, 1, 3, 3]
+        Cout = weight.shape[0]
+        w_t = _pad_last(w9.permute(1, 2, 0), _cpad(Cout))
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Cout, D, Ho, Wo), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, Cout, D, H, W, stride, int(transposed)))
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
+    sh = _shift_vec(bias, _cpad(Cout))
+    rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(w_t), None, _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, D, H, W, stride, dilation,
+                            int(transposed), 0, 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
+                            None, 0, _lib.ptr(ws), wsb, _stream())
+    _lib.check(rc, "ts_conv3d_hw_fwd")
+    return x, y, (B, Cin, Cout, D, H, W, stride, dilation, transposed)
+
+
+def _hw_backward(x, weight, dy, geom, need_x, need_w):
+    B, Cin, Cout, D, H, W, stride, dilation, transposed = geom
+    dy = dy.contiguous()
+    L = _lib.lib()
+    dx = dw = None
+    w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
+    if need_x:
+        if transposed:
+            w_b = _pad_last(w9.permute(1, 2, 0), _cpad(Cin))                    # [co][t][ci] = W_T[ci][co][t]
+        elif stride == 2:
+            w_b = _pad_last(w9.permute(0, 2, 1), _cpad(Cin))                    # [co][t][ci], taps as they are
+        else:
+            w_b = _pad_last(w9.flip(2).permute(0, 2, 1), _cpad(Cin))            # taps flipped
+        dx = torch.empty_like(x)
+        rc = L.ts_conv3d_hw_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, D, H, W, stride, dilation,
+                                     int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
+        _lib.check(rc, "ts_conv3d_hw_bwd_data")
+    if need_w:
+        dw = torch.empty_like(weight)
+        if transposed:     # roles exchanged: a stride-2 convolution maps dy (2H x 2W) to x
+            rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, D, 2 * H, 2 * W, 2, 1,
+                                           dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _stream())
+        else:
+            rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, D, H, W, stride, dilation,
+                                           x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _stream())
+        _lib.check(rc, "ts_conv3d_hw_bwd_weight")
+    return dx, dw
+
+
 class _Conv3dHW(torch.autograd.Function):
     """Raw Conv3d (1,3,3) [padding == dilation] / ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1.
     forward ts_conv3d_hw_fwd (no scale / shift / activation), backward ts_conv3d_hw_bwd_{data,weight}.
@@ -272,59 +336,68 @@ class _Conv3dHW(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, dilation, transposed):
-        _require_gpu(x, weight)
-        x = x.contiguous()
-        B, Cin, D, H, W = x.shape
-        w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
-        if transposed:                                   # weight [Cin, Cout, 1, 3, 3]
-            Cout = weight.shape[1]
-            w_t = _pad_last(w9.permute(0, 2, 1), _cpad(Cout))                       # [ci][t][co]
-            Ho, Wo = 2 * H, 2 * W
-        else:                                            # weight [Cout, Cin, 1, 3, 3]
-            Cout = weight.shape[0]
-            w_t = _pad_last(w9.permute(1, 2, 0), _cpad(Cout))
-            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-        y = torch.empty((B, Cout, D, Ho, Wo), device=x.device, dtype=torch.float32)
-        L = _lib.lib()
-        wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, Cout, D, H, W, stride, int(transposed)))
-        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
-        rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(w_t), None, None, _lib.ptr(y), B, Cin, Cout, D, H, W, stride, dilation,
-                                int(transposed), 0, 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
-                                None, 0, _lib.ptr(ws), wsb, _stream())
-        _lib.check(rc, "ts_conv3d_hw_fwd")
+        x, y, ctx.geom = _hw_forward(x, weight, stride, dilation, transposed)
         ctx.save_for_backward(x, weight)
-        ctx.geom = (B, Cin, Cout, D, H, W, stride, dilation, transposed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        B, Cin, Cout, D, H, W, stride, dilation, transposed = ctx.geom
-        dy = dy.contiguous()
-        L = _lib.lib()
-        dx = dw = None
-        w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
-        if ctx.needs_input_grad[0]:
-            if transposed:
-                w_b = _pad_last(w9.permute(1, 2, 0), _cpad(Cin))                    # [co][t][ci] = W_T[ci][co][t]
-            elif stride == 2:
-                w_b = _pad_last(w9.permute(0, 2, 1), _cpad(Cin))                    # [co][t][ci], taps as they are
-            else:
-                w_b = _pad_last(w9.flip(2).permute(0, 2, 1), _cpad(Cin))            # taps flipped
-            dx = torch.empty_like(x)
-            rc = L.ts_conv3d_hw_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, D, H, W, stride, dilation,
-                                         int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
-            _lib.check(rc, "ts_conv3d_hw_bwd_data")
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            if transposed:     # roles exchanged: a stride-2 convolution maps dy (2H x 2W) to x
-                rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, D, 2 * H, 2 * W, 2, 1,
-                                               dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _stream())
-            else:
-                rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, D, H, W, stride, dilation,
-                                               x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _stream())
-            _lib.check(rc, "ts_conv3d_hw_bwd_weight")
+        dx, dw = _hw_backward(x, weight, dy, ctx.geom, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dx, dw, None, None, None
+
+
+def _d_forward(x, weight, stride, dilation, padding, transposed, bias=None):
+    """Raw Conv3d (k,1,1) / ConvTranspose3d (3,1,1) stride 2, padding 1, output_padding 1 along D (+ bias)."""
+    _require_gpu(x, weight)
+    x = x.contiguous()
+    B, Cin, Din, H, W = x.shape
+    k = weight.shape[2]
+    wk = weight.reshape(weight.shape[0], weight.shape[1], k)
+    if transposed:
+        Cout = weight.shape[1]
+        w_t = _pad_last(wk.permute(0, 2, 1), _cpad(Cout))
+        Dout = 2 * Din
+    else:
+        Cout = weight.shape[0]
+        w_t = _pad_last(wk.permute(1, 2, 0), _cpad(Cout))
+        Dout = (Din + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    y = torch.empty((B, Cout, Dout, H, W), device=x.device, dtype=torch.float32)
+    sh = _shift_vec(bias, _cpad(Cout))
+    rc = _lib.lib().ts_conv3d_d_fwd(_lib.ptr(x), _lib.ptr(w_t), None, _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, Din, H, W, k, stride,
+                                    dilation, padding, int(transposed), 0, 0.0, x.stride(0), x.stride(1), y.stride(0),
+                                    y.stride(1), _stream())
+    _lib.check(rc, "ts_conv3d_d_fwd")
+    return x, y, (B, Cin, Cout, Din, H, W, k, stride, dilation, padding, transposed)
+
+
+def _d_backward(x, weight, dy, geom, need_x, need_w):
+    B, Cin, Cout, Din, H, W, k, stride, dilation, padding, transposed = geom
+    dy = dy.contiguous()
+    L = _lib.lib()
+    dx = dw = None
+    wk = weight.reshape(weight.shape[0], weight.shape[1], k)
+    if need_x:
+        if transposed:
+            w_b = _pad_last(wk.permute(1, 2, 0), _cpad(Cin))
+        elif stride == 2:
+            w_b = _pad_last(wk.permute(0, 2, 1), _cpad(Cin))
+        else:
+            w_b = _pad_last(wk.flip(2).permute(0, 2, 1), _cpad(Cin))
+        dx = torch.empty_like(x)
+        rc = L.ts_conv3d_d_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, Din, H, W, k, stride, dilation,
+                                    padding, int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
+        _lib.check(rc, "ts_conv3d_d_bwd_data")
+    if need_w:
+        dw = torch.empty_like(weight)
+        if transposed:
+            rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, 2 * Din, H, W, 3, 2, 1, 1,
+                                          dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _stream())
+        else:
+            rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, Din, H, W, k, stride, dilation,
+                                          padding, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _stream())
+        _lib.check(rc, "ts_conv3d_d_bwd_weight")
+    return dx, dw
 
 
 class _Conv3dD(torch.autograd.Function):
@@ -332,57 +405,121 @@ class _Conv3dD(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, dilation, padding, transposed):
-        _require_gpu(x, weight)
-        x = x.contiguous()
-        B, Cin, Din, H, W = x.shape
-        k = weight.shape[2]
-        wk = weight.reshape(weight.shape[0], weight.shape[1], k)
-        if transposed:
-            Cout = weight.shape[1]
-            w_t = _pad_last(wk.permute(0, 2, 1), _cpad(Cout))
-            Dout = 2 * Din
-        else:
-            Cout = weight.shape[0]
-            w_t = _pad_last(wk.permute(1, 2, 0), _cpad(Cout))
-            Dout = (Din + 2 * padding - dilation * (k - 1) - 1) // stride + 1
-        y = torch.empty((B, Cout, Dout, H, W), device=x.device, dtype=torch.float32)
-        rc = _lib.lib().ts_conv3d_d_fwd(_lib.ptr(x), _lib.ptr(w_t), None, None, _lib.ptr(y), B, Cin, Cout, Din, H, W, k, stride,
-                                        dilation, padding, int(transposed), 0, 0.0, x.stride(0), x.stride(1), y.stride(0),
-                                        y.stride(1), _stream())
-        _lib.check(rc, "ts_conv3d_d_fwd")
+        x, y, ctx.geom = _d_forward(x, weight, stride, dilation, padding, transposed)
         ctx.save_for_backward(x, weight)
-        ctx.geom = (B, Cin, Cout, Din, H, W, k, stride, dilation, padding, transposed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        B, Cin, Cout, Din, H, W, k, stride, dilation, padding, transposed = ctx.geom
-        dy = dy.contiguous()
-        L = _lib.lib()
-        dx = dw = None
-        wk = weight.reshape(weight.shape[0], weight.shape[1], k)
-        if ctx.needs_input_grad[0]:
-            if transposed:
-                w_b = _pad_last(wk.permute(1, 2, 0), _cpad(Cin))
-            elif stride == 2:
-                w_b = _pad_last(wk.permute(0, 2, 1), _cpad(Cin))
-            else:
-                w_b = _pad_last(wk.flip(2).permute(0, 2, 1), _cpad(Cin))
-            dx = torch.empty_like(x)
-            rc = L.ts_conv3d_d_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, Din, H, W, k, stride, dilation,
-                                        padding, int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
-            _lib.check(rc, "ts_conv3d_d_bwd_data")
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            if transposed:
-                rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, 2 * Din, H, W, 3, 2, 1, 1,
-                                              dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _stream())
-            else:
-                rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, Din, H, W, k, stride, dilation,
-                                              padding, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _stream())
-            _lib.check(rc, "ts_conv3d_d_bwd_weight")
+        dx, dw = _d_backward(x, weight, dy, ctx.geom, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dx, dw, None, None, None, None
+
+
+BN_ACT = {None: 0, "SiLU": 1, "ReLU": 2}
+
+
+class _ConvBNAct(torch.autograd.Function):
+    """conv -> BatchNorm -> activation of the reference's wrappers (layers/basic_layers.py:194-235: conv, then `self.norm`, then
+    `self.activation`) as ONE autograd node on HIP kernels: the convolution of _Conv3dHW / _Conv3dD (bias in its epilogue),
+    ts_bn_stats_fwd (train mode: batch statistics, running statistics updated in the same launch), ts_bn_apply_act_fwd; backward
+    ts_bn_act_bwd_{reduce,apply} (the pre-activation is recomputed from the raw convolution output: nothing but that output is
+    kept), then the convolution's data / weight gradients.  `group`: a torch.distributed process group -- statistics and the two
+    backward sums are exchanged across its ranks (SyncBatchNorm of dist.py, one all_gather forward, one all_reduce backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, family, geom, eps, momentum, act, training, group):
+        if family == "hw":
+            x, y, cg = _hw_forward(x, weight, geom[0], geom[1], geom[2], bias)
+        else:
+            x, y, cg = _d_forward(x, weight, geom[0], geom[1], geom[2], geom[3], bias)
+        B, C = y.shape[0], y.shape[1]
+        N = y[0, 0].numel()
+        L = _lib.lib()
+        n_total = float(B * N)
+        if training:
+            mean = torch.empty(C, device=y.device, dtype=torch.float32)
+            var = torch.empty_like(mean)
+            ws = torch.empty(int(L.ts_bn_workspace_bytes(B, C, N)), device=y.device, dtype=torch.uint8)
+            local_update = group is None and running_mean is not None
+            _lib.check(L.ts_bn_stats_fwd(_lib.ptr(y), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(running_mean if local_update else None),
+                                         _lib.ptr(running_var if local_update else None), float(momentum), _lib.ptr(ws), B, C, N,
+                                         y.stride(0), y.stride(1), _stream()), "ts_bn_stats_fwd")
+            if group is not None:
+                import torch.distributed as dist
+                world = dist.get_world_size(group)
+                pack = torch.cat([mean, var, mean.new_full((1,), n_total)])
+                allp = [torch.empty_like(pack) for _ in range(world)]
+                dist.all_gather(allp, pack, group=group)
+                allp = torch.stack(allp)
+                cnt = allp[:, -1:]
+                n_total_t = cnt.sum()
+                gmean = (allp[:, :C] * cnt).sum(0) / n_total_t
+                var = ((allp[:, C:2 * C] + (allp[:, :C] - gmean) ** 2) * cnt).sum(0) / n_total_t
+                mean = gmean
+                n_total = float(n_total_t)           # (one host read per layer; the sync path is collective-bound anyway)
+                if running_mean is not None:
+                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(var * (n_total / max(n_total - 1.0, 1.0)), alpha=momentum)
+        else:
+            mean, var = running_mean, running_var
+        out = torch.empty_like(y)
+        _lib.check(L.ts_bn_apply_act_fwd(_lib.ptr(y), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out),
+                                         B, C, N, y.stride(0), y.stride(1), out.stride(0), out.stride(1), float(eps), int(act),
+                                         _stream()), "ts_bn_apply_act_fwd")
+        ctx.save_for_backward(x, weight, y, mean, var, gamma, beta)
+        ctx.meta = (family, cg, float(eps), int(act), bool(training), group, n_total, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y, mean, var, gamma, beta = ctx.saved_tensors
+        family, cg, eps, act, training, group, n_total, has_bias = ctx.meta
+        g = g.contiguous()
+        B, C = y.shape[0], y.shape[1]
+        N = y[0, 0].numel()
+        L = _lib.lib()
+        s1 = torch.empty(C, device=y.device, dtype=torch.float32)
+        s2 = torch.empty_like(s1)
+        ws = torch.empty(int(L.ts_bn_workspace_bytes(B, C, N)), device=y.device, dtype=torch.uint8)
+        _lib.check(L.ts_bn_act_bwd_reduce(_lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta),
+                                          _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(ws), B, C, N, y.stride(0), y.stride(1), g.stride(0),
+                                          g.stride(1), eps, act, _stream()), "ts_bn_act_bwd_reduce")
+        ggamma, gbeta = (s2, s1) if gamma is not None else (None, None)          # local sums: the gradient exchange averages them
+        t1, t2 = s1, s2
+        if training and group is not None:
+            import torch.distributed as dist
+            pack = torch.cat([s1, s2])
+            dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
+            t1, t2 = pack[:C].contiguous(), pack[C:].contiguous()
+        dy = torch.empty_like(y)
+        _lib.check(L.ts_bn_act_bwd_apply(_lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta),
+                                         _lib.ptr(t1), _lib.ptr(t2), _lib.ptr(dy), B, C, N, y.stride(0), y.stride(1), g.stride(0),
+                                         g.stride(1), eps, act, int(training), n_total, _stream()), "ts_bn_act_bwd_apply")
+        if family == "hw":
+            dx, dw = _hw_backward(x, weight, dy, cg, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        else:
+            dx, dw = _d_backward(x, weight, dy, cg, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gbias = None
+        if has_bias and ctx.needs_input_grad[2]:
+            gbias = dy.sum(dim=[0] + list(range(2, dy.dim())))     # == 0 up to rounding in train mode (BatchNorm removes the mean)
+        return dx, dw, gbias, ggamma, gbeta, None, None, None, None, None, None, None, None, None
+
+
+def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False):
+    """Fused wrapper forward (see _ConvBNAct).  `bn`: an nn.BatchNorm*d / dist.SyncBatchNorm module; `activation`: None | 'SiLU' |
+    'ReLU'; family 'hw' geom (stride, dilation, transposed) / family 'd' geom (stride, dilation, padding, transposed)."""
+    training = bn.training or bn.running_mean is None
+    group = None
+    if training and getattr(bn, "process_group", "absent") != "absent":
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
+            group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _ConvBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, family, geom, bn.eps, momentum,
+                            BN_ACT[activation], training, group)
 
 
 def conv3d_supported(weight_shape, stride, padding, dilation, groups, transposed=False, output_padding=(0, 0, 0)):

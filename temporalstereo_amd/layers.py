@@ -92,6 +92,20 @@ class _NormAct:
             x = self.activation(x)
         return x
 
+    def _fusable(self):
+        """Name of the activation when conv -> BatchNorm -> activation can run as the one fused HIP node
+        (functional.conv_bn_act: BatchNorm with affine parameters and running statistics; no activation, SiLU or ReLU)."""
+        bn = self.norm
+        if not isinstance(bn, nn.modules.batchnorm._BatchNorm) or not bn.affine or not bn.track_running_stats:
+            return False
+        if self.activation is None:
+            return None
+        if isinstance(self.activation, nn.SiLU):
+            return "SiLU"
+        if isinstance(self.activation, nn.ReLU):
+            return "ReLU"
+        return False
+
 
 class Conv2d(nn.Conv2d, _NormAct):
     def __init__(self, *args, **kwargs):
@@ -100,6 +114,15 @@ class Conv2d(nn.Conv2d, _NormAct):
         self.norm, self.activation = norm, act
 
     def forward(self, x):
+        if _hip_conv(x):
+            from . import functional as TF
+            w5 = self.weight.unsqueeze(2)
+            st, pd, dl = (1,) + tuple(self.stride), (0,) + tuple(self.padding), (1,) + tuple(self.dilation)
+            if TF.conv3d_supported(tuple(w5.shape), st, pd, dl, self.groups) == "hw":      # a (1,3,3) convolution on one plane
+                act = self._fusable()
+                if act is not False:
+                    return TF.conv_bn_act(x.unsqueeze(2), w5, self.bias, self.norm, act, "hw", (st[1], dl[1], False)).squeeze(2)
+                return self._finish(TF.conv3d(x.unsqueeze(2), w5, self.bias, st, pd, dl).squeeze(2))
         return self._finish(F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups))
 
 
@@ -112,7 +135,13 @@ class Conv3d(nn.Conv3d, _NormAct):
     def forward(self, x):
         if _hip_conv(x):
             from . import functional as TF
-            if TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups):
+            kind = TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups)
+            if kind:
+                act = self._fusable()
+                if act is not False:      # conv -> BatchNorm (train or eval statistics) -> activation as one autograd node
+                    geom = (self.stride[1], self.dilation[1], False) if kind == "hw" else \
+                        (self.stride[0], self.dilation[0], self.padding[0], False)
+                    return TF.conv_bn_act(x, self.weight, self.bias, self.norm, act, kind, geom)
                 return self._finish(TF.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation))
         return self._finish(F.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups))
 
@@ -143,7 +172,12 @@ class ConvTranspose3d(nn.ConvTranspose3d, _NormAct):
         op = self._output_padding(x, output_size, self.stride, self.padding, self.kernel_size, 3, self.dilation)
         if _hip_conv(x):
             from . import functional as TF
-            if TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups, True, tuple(op)):
+            kind = TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups, True, tuple(op))
+            if kind:
+                act = self._fusable()
+                if act is not False:
+                    geom = (2, 1, True) if kind == "hw" else (2, 1, 1, True)
+                    return TF.conv_bn_act(x, self.weight, self.bias, self.norm, act, kind, geom)
                 return self._finish(TF.conv_transpose3d(x, self.weight, self.bias, self.stride, self.padding, tuple(op)))
         return self._finish(F.conv_transpose3d(x, self.weight, self.bias, self.stride, self.padding, op,
                                                self.groups, self.dilation))

@@ -155,3 +155,66 @@ def test_sort_gather_autograd_is_the_stable_sort():
     gv, gs = t(synth.normal(33, "gv", tuple(vol.shape)), dev), t(synth.normal(34, "gs", tuple(smp.shape)), dev)
     ((ov1 * gv).sum() + (os1 * gs).sum()).backward(); ((ov2 * gv).sum() + (os2 * gs).sum()).backward()
     assert torch.equal(v1.grad, v2.grad) and torch.equal(s1.grad, s2.grad)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_fused_conv_batchnorm_activation_matches_framework(case):
+    """layers.Conv3d / ConvTranspose3d / Conv2d with BatchNorm + activation: the fused HIP node (functional.conv_bn_act: own
+    statistics / normalise+activate / backward kernels) against the same module on the framework's convolution, BatchNorm and
+    activation -- outputs, all five gradients and the running statistics, train and eval mode."""
+    import copy
+    from temporalstereo_amd import layers
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(40 + case)
+    act = [None, "SiLU", "ReLU"][case % 3]
+    train = case % 4 != 3
+    B = int(rng.choice([1, 2, 3]))
+    kind = ["hw", "hw_s2", "hw_d2", "d3", "d5", "d_s2", "hwT", "dT", "2d", "2d_s2"][case]
+    cin, cout = int(rng.choice([3, 8, 16])), int(rng.choice([4, 8, 32]))
+    D, H, W = int(rng.randint(2, 6)), int(rng.randint(5, 20)), int(rng.randint(6, 40))
+    bias = bool(case % 2)
+    if kind in ("2d", "2d_s2"):
+        m = layers.Conv2d(cin, cout, 3, 2 if kind == "2d_s2" else 1, 1, bias=bias, norm=("BN", cout), activation=act)
+        x = torch.from_numpy(synth.normal(60 + case, "x", (B, cin, H, W)))
+    elif kind == "hwT":
+        m = layers.ConvTranspose3d(cin, cout, (1, 3, 3), (1, 2, 2), (0, 1, 1), (0, 1, 1), bias=bias, norm=("BN3d", cout), activation=act)
+        x = torch.from_numpy(synth.normal(60 + case, "x", (B, cin, D, H, W)))
+    elif kind == "dT":
+        m = layers.ConvTranspose3d(cin, cout, (3, 1, 1), (2, 1, 1), (1, 0, 0), (1, 0, 0), bias=bias, norm=("BN3d", cout), activation=act)
+        x = torch.from_numpy(synth.normal(60 + case, "x", (B, cin, D, H, W)))
+    else:
+        args = {"hw": ((1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)), "hw_s2": ((1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),
+                "hw_d2": ((1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)), "d3": ((3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),
+                "d5": ((5, 1, 1), (1, 1, 1), (2, 0, 0), (1, 1, 1)), "d_s2": ((3, 1, 1), (2, 1, 1), (1, 0, 0), (1, 1, 1))}[kind]
+        m = layers.Conv3d(cin, cout, args[0], args[1], args[2], args[3], bias=bias, norm=("BN3d", cout), activation=act)
+        x = torch.from_numpy(synth.normal(60 + case, "x", (B, cin, D, H, W)))
+    with torch.no_grad():
+        m.norm.weight.copy_(torch.from_numpy(synth.uniform(60 + case, "g", (cout,), 0.5, 1.5)))
+        m.norm.bias.copy_(torch.from_numpy(synth.normal(60 + case, "b", (cout,), 0.2)))
+        m.norm.running_mean.copy_(torch.from_numpy(synth.normal(60 + case, "rm", (cout,), 0.2)))
+        m.norm.running_var.copy_(torch.from_numpy(synth.uniform(60 + case, "rv", (cout,), 0.5, 1.5)))
+    m = m.to(dev).train(train)
+    ref = copy.deepcopy(m)
+    xa, xb = x.to(dev).requires_grad_(True), x.to(dev).requires_grad_(True)
+    ya = m(xa)
+    layers.set_conv_backend("torch")
+    try:
+        yb = ref(xb)
+    finally:
+        layers.set_conv_backend("hip")
+    g = torch.from_numpy(synth.normal(70 + case, "gy", tuple(yb.shape))).to(dev)
+    ya.backward(g)
+    yb.backward(g)
+    tag = "%s act=%s train=%s" % (kind, act, train)
+    scale = float(yb.abs().max()) + 1e-6
+    assert float((ya - yb).abs().max()) / scale < 2e-5, tag
+    for (na, pa), (_, pb) in zip([("x", xa)] + list(m.named_parameters()), [("x", xb)] + list(ref.named_parameters())):
+        ga, gb = pa.grad, pb.grad
+        tol = 2e-4 * (float(gb.abs().max()) + 1e-4)
+        if na == "bias" and train:          # BatchNorm removes the mean: the true gradient is 0, both sides return rounding noise
+            tol = 1e-3 * float(g.abs().sum())
+        assert float((ga - gb).abs().max()) <= tol, "%s grad %s: %.3g vs tol %.3g" % (tag, na, float((ga - gb).abs().max()), tol)
+    for k in ("running_mean", "running_var"):
+        a, b = getattr(m.norm, k), getattr(ref.norm, k)
+        assert float((a - b).abs().max()) <= 2e-5 * (1 + float(b.abs().max())), "%s %s" % (tag, k)
+    assert int(m.norm.num_batches_tracked) == int(ref.norm.num_batches_tracked)

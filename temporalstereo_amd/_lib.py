@@ -221,13 +221,21 @@ def check(rc, what):
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
+    """Device pointer of a tensor (None -> NULL), as the plain integer ctypes takes for a void* argument."""
     if t is None:
         return None
     rec = getattr(_tls, "recorder", None)
     if rec is not None:
         rec.keep.append(t)
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+def current_stream_handle():
+    """hipStream_t of the current device's current stream as an integer.  The raw-handle query of the framework's C layer:
+    `torch.cuda.current_stream()` builds a Stream object and walks the device-index helpers on every call (~9 us; an eager
+    pass or a training step asks ~2500 times)."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def contiguous(t):

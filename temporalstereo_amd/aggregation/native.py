@@ -28,7 +28,7 @@ ACT_NONE, ACT_SILU, ACT_RELU, ACT_TANH_OFFSET, ACT_HEAD_PAIR = 0, 1, 2, 3, 4
 
 
 def _stream():
-    return _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.current_stream_handle()
 
 
 # ------------------------------------------------------------------------- independent branches

@@ -10,7 +10,7 @@ from . import _lib
 
 
 def _stream():
-    return _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.current_stream_handle()
 
 
 # Measurement hook (bench.py): when set, called as probe(key, launch) around the K1 C-ABI call so

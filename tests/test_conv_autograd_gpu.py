@@ -91,7 +91,8 @@ def test_layers_use_the_hip_convolutions_on_gpu():
         if fn is not None:
             names.add(type(fn).__name__)
             todo += [f for f, _ in fn.next_functions]
-    assert any(n.startswith("_Conv3dHW") for n in names), names
+    # conv -> BatchNorm -> SiLU is ONE node of ours (functional._ConvBNAct); nothing of the framework's in between
+    assert names <= {"_ConvBNActBackward", "AccumulateGrad"} and "_ConvBNActBackward" in names, names
     y.square().mean().backward()
     g_hip = m.weight.grad.clone(); gx_hip = x.grad.clone()
     m.zero_grad(); x.grad = None
@@ -194,8 +195,10 @@ def test_fused_conv_batchnorm_activation_matches_framework(case):
         m.norm.running_mean.copy_(torch.from_numpy(synth.normal(60 + case, "rm", (cout,), 0.2)))
         m.norm.running_var.copy_(torch.from_numpy(synth.uniform(60 + case, "rv", (cout,), 0.5, 1.5)))
     m = m.to(dev).train(train)
-    ref = copy.deepcopy(m)
-    xa, xb = x.to(dev).requires_grad_(True), x.to(dev).requires_grad_(True)
+    # the arbiter is the same module in fp64 on the framework's ops: the framework's own fp32 BatchNorm / strided-convolution
+    # backward is 1-6 % off the fp64 result on some of these geometries (tools/exp/dbg_bn.py: d_s2, B=3), ours 1e-7
+    ref = copy.deepcopy(m).double()
+    xa, xb = x.to(dev).requires_grad_(True), x.to(dev).double().requires_grad_(True)
     ya = m(xa)
     layers.set_conv_backend("torch")
     try:
@@ -204,17 +207,16 @@ def test_fused_conv_batchnorm_activation_matches_framework(case):
         layers.set_conv_backend("hip")
     g = torch.from_numpy(synth.normal(70 + case, "gy", tuple(yb.shape))).to(dev)
     ya.backward(g)
-    yb.backward(g)
+    yb.backward(g.double())
     tag = "%s act=%s train=%s" % (kind, act, train)
-    scale = float(yb.abs().max()) + 1e-6
-    assert float((ya - yb).abs().max()) / scale < 2e-5, tag
+    rel = lambda a, b: float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-9)
+    assert rel(ya.detach(), yb.detach()) < 5e-6, tag
     for (na, pa), (_, pb) in zip([("x", xa)] + list(m.named_parameters()), [("x", xb)] + list(ref.named_parameters())):
-        ga, gb = pa.grad, pb.grad
-        tol = 2e-4 * (float(gb.abs().max()) + 1e-4)
-        if na == "bias" and train:          # BatchNorm removes the mean: the true gradient is 0, both sides return rounding noise
-            tol = 1e-3 * float(g.abs().sum())
-        assert float((ga - gb).abs().max()) <= tol, "%s grad %s: %.3g vs tol %.3g" % (tag, na, float((ga - gb).abs().max()), tol)
+        if na == "bias" and train:          # BatchNorm removes the mean: the true gradient is 0; ours is rounding noise around it
+            assert float(pa.grad.abs().max()) <= 1e-4 * float(g.abs().sum()), "%s grad bias" % tag
+            continue
+        assert rel(pa.grad, pb.grad) < 2e-5, "%s grad %s: %.3g" % (tag, na, rel(pa.grad, pb.grad))
     for k in ("running_mean", "running_var"):
         a, b = getattr(m.norm, k), getattr(ref.norm, k)
-        assert float((a - b).abs().max()) <= 2e-5 * (1 + float(b.abs().max())), "%s %s" % (tag, k)
+        assert rel(a, b) < 1e-5, "%s %s" % (tag, k)
     assert int(m.norm.num_batches_tracked) == int(ref.norm.num_batches_tracked)

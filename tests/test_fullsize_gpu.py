@@ -188,8 +188,8 @@ def test_every_stage_and_level_teacher_forced_at_stated_batch(name):
         rep.dump("parity_stagewise.json")
 
 
-# seeds per configuration: 8 on the headline configuration, 18 sequences in all
-_SEEDS = dict(zip(PT.CONFIGS, (8, 4, 2, 4)))
+# seeds per configuration: 8 on the headline configuration, 13 sequences in all (each frame also runs the fp64 oracle)
+_SEEDS = dict(zip(PT.CONFIGS, (8, 2, 1, 2)))
 
 
 @pytest.mark.parametrize("name", list(PT.CONFIGS))

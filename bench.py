@@ -142,24 +142,44 @@ class K1Probe:
         return rc
 
     def measure(self, iters):
-        self.timing = True
-        with torch.no_grad():
-            calls = dict(self.calls)
-            for key, (fn, l, r, d, sc) in self.calls.items():
-                if key[5] == "warped":     # also time the complete op on the same tensors: SURVEY.md section 8(d)'s
-                    calls.setdefault(key[:5] + (True,), (self._orig["block_cost"], l, r, d, sc))   # unfused-boundary figure
-            for key, (fn, l, r, d, sc) in calls.items():
-                for _ in range(3):
-                    fn(l, r, d, sc)
-                self.records = [rec for rec in self.records if rec[0] != key]
-                for _ in range(iters):
-                    fn(l, r, d, sc)
-        torch.cuda.synchronize()
-        self.timing = False
-        per = {}
-        for key, s, e in self.records:
-            per.setdefault(key, []).append(s.elapsed_time(e) * 1e-3)
-        return {k: float(np.mean(v)) for k, v in per.items()}
+        """Mean duration of each remembered K1 launch: the C-ABI entry point on the pipeline's own input tensors with
+        preallocated output / workspace, `iters` launches back to back between ONE pair of HIP events on the launch stream (an
+        event pair per launch would time the host gap in front of every launch; the queue stays full this way).  The rocprofv3
+        kernel trace of this command gives the same figure as main kernel + expansion kernel (profiles/)."""
+        from temporalstereo_amd import _lib
+        L = _lib.lib()
+        st = torch.cuda.current_stream().cuda_stream
+        calls = dict(self.calls)
+        for key, (fn, l, r, d, sc) in self.calls.items():
+            if key[5] == "warped":     # also time the complete op on the same tensors: SURVEY.md section 8(d)'s
+                calls.setdefault(key[:5] + (True,), (None, l, r, d, sc))            # unfused-boundary figure
+        out_t = {}
+        for key, (_, l, r, d, sc) in calls.items():
+            B, C, H, W, D, kind = key
+            l, r = l.contiguous(), r.contiguous()
+            ctot = {True: 2 * C, "warped": C, False: C}[kind] + sc * (C // 8)
+            out = torch.empty((B, ctot, D, H, W), device=l.device, dtype=torch.float32)
+            ws = torch.empty(max(int(L.ts_block_cost_workspace_bytes(B, C, H, W, D, sc)), 256), device=l.device, dtype=torch.uint8)
+            if kind is False:
+                launch = lambda: L.ts_block_cost_int_fwd(l.data_ptr(), r.data_ptr(), out.data_ptr(), ws.data_ptr(), B, C, H, W, D, sc, st)
+            elif kind is True:
+                dd = d.contiguous()
+                launch = lambda: L.ts_block_cost_sampled_fwd(l.data_ptr(), r.data_ptr(), dd.data_ptr(), out.data_ptr(), ws.data_ptr(), B, C, H, W, D, sc, st)
+            else:
+                dd = d.contiguous()
+                launch = lambda: L.ts_block_cost_sampled_warped_fwd(l.data_ptr(), r.data_ptr(), dd.data_ptr(), out.data_ptr(), ws.data_ptr(), B, C, H, W, D, sc, st)
+            for _ in range(5):
+                _lib.check(launch(), "K1")
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                launch()
+            e1.record()
+            torch.cuda.synchronize()
+            out_t[key] = e0.elapsed_time(e1) / iters * 1e-3
+            del out, ws
+        return out_t
 
 
 def cpu_baseline(seed, budget_s=20.0, all_cores=False):
@@ -375,7 +395,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        k1_times = k1.measure(max(a.steps, 20)) if rank == 0 else {}
+        k1_times = k1.measure(max(a.steps, 50)) if rank == 0 else {}
         k1_b4 = None
         if rank == 0 and mode.startswith("native"):
             # the same launch on four pairs: 930 MB per launch, beyond the 256 MiB Infinity Cache (SURVEY.md section 8(d) hygiene)
@@ -503,8 +523,8 @@ def main():
                 pass
             roofline = dict(bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
                             traffic=traffic,
-                            measured="HIP events on the launch stream around the C-ABI call, %d back-to-back "
-                                     "launches on the pipeline's own tensors right after the timed steps" % max(a.steps, 20),
+                            measured="HIP events on the launch stream around %d back-to-back C-ABI launches on the pipeline's "
+                                     "own input tensors, right after the timed steps" % max(a.steps, 50),
                             kernel="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample_direct) on "
                                    "[%d,%d,%d,%d] x %d candidates" % pkey[:5],
                             algorithmic_bytes=nbytes, mean_us=k1_times[pkey] * 1e6,

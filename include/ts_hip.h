@@ -311,6 +311,13 @@ int ts_convex_upsample_candidates_fwd(const float* mask, const float* disp, floa
                                       int channel_offset, int channels_total, void* stream);
 int ts_unet_upsample_fwd(const float* mask, const float* disp, float* out, int B, int h, int w, int Ho, int Wo,
                          void* stream);
+/* Backward of the two upsamplers (training form).  grad_out has the output's shape; grad_mask / grad_disp are OVERWRITTEN
+ * (ts_convex_upsample_bwd: either may be NULL; ts_unet_upsample_bwd: grad_disp may be NULL; workspace B*9*Ho*Wo floats).
+ * Gather formulations: deterministic, no atomics. */
+int ts_convex_upsample_bwd(const float* mask, const float* disp, const float* grad_out, float* grad_mask, float* grad_disp,
+                           int B, int H, int W, int factor, float disp_scale, void* stream);
+int ts_unet_upsample_bwd(const float* mask, const float* disp, const float* grad_out, float* grad_mask, float* grad_disp,
+                         void* workspace, int B, int h, int w, int Ho, int Wo, void* stream);
 int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
                          int B, int Cin, int Cout, int H, int W, int act, long long out_bstride, void* stream);
 int ts_resize_bilinear_fwd(const float* x, float* out, int B, int C, int h, int w, int Ho, int Wo, float value_scale,

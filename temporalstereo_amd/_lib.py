@@ -74,6 +74,8 @@ SIGNATURES = {
     "ts_convex_upsample_fwd": (c_int, [c_f32p] * 3 + [c_int] * 4 + [c_float, c_ptr]),
     "ts_convex_upsample_candidates_fwd": (c_int, [c_f32p] * 6 + [c_int] * 4 + [c_float, c_float, c_int, c_int, c_ptr]),
     "ts_unet_upsample_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [c_ptr]),
+    "ts_convex_upsample_bwd": (c_int, [c_f32p] * 5 + [c_int] * 4 + [c_float, c_ptr]),
+    "ts_unet_upsample_bwd": (c_int, [c_f32p] * 5 + [c_ptr] + [c_int] * 5 + [c_ptr]),
     "ts_deconv2d_k4s2_fwd": (c_int, [c_f32p] * 5 + [c_int] * 6 + [ctypes.c_longlong, c_ptr]),
     "ts_resize_bilinear_fwd": (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_float, ctypes.c_longlong, c_ptr]),
     "ts_resize_bilinear_pair_fwd": (c_int, [c_f32p] * 4 + [c_int] * 6 + [c_float, c_float, c_ptr]),

@@ -109,6 +109,8 @@ class ConvexUpsample(nn.Module):
             m0, bn, m3 = self.mask[0], self.mask[1], self.mask[3]
             m = TF.conv_bn_act(input.unsqueeze(2), m0.weight.unsqueeze(2), m0.bias, bn, "SiLU", "hw", (1, 1, False))
             logits = TF.conv3d(m, m3.weight.unsqueeze(2), m3.bias, (1, 1, 1), (0, 0, 0), (1, 1, 1)).squeeze(2)
+            if k == 3 and C == 1:             # softmax + 3x3 gather + weighted sum: one kernel each way
+                return TF.convex_upsample(logits, disp, r, r if disp_scale is None else disp_scale)
         else:
             logits = self.mask(input)
         w = torch.softmax(logits.view(B, 1, k * k, r, r, H, W), dim=2)
@@ -186,6 +188,8 @@ class UNet(nn.Module):
         return [s2l, s4l], [s2r, s4r]
 
     def upsample(self, mask, disp):
+        if _on_hip(mask) and mask.shape[1] == 9 and disp.shape[1] == 1:
+            return TF.unet_upsample(mask, disp)
         mask = F.softmax(mask, dim=1)
         b, _, h, w = mask.shape
         dh, dw = disp.shape[-2:]

@@ -26,6 +26,9 @@ unsigned grid_for(long long n, int threads) {
   return static_cast<unsigned>(blocks);
 }
 
+// one 256-thread workgroup per 256 elements, uncapped (kernels without a grid-stride loop)
+unsigned exact_grid(long long n) { return static_cast<unsigned>((n + 255) / 256); }
+
 // source index / weight of torch's align_corners=True linear interpolation
 __device__ __forceinline__ void lin_src(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
   const float s = scale * static_cast<float>(dst);
@@ -650,6 +653,198 @@ extern "C" int ts_merge_candidates_fwd(const float* volume, const float* sample,
   else TS_MERGE(MERGE_DMAX);
 #undef TS_MERGE
   return ts::launched("merge_candidates_kernel");
+}
+
+// ---- backward of the two softmax-weighted upsamplers (training form) -------------------------------------------------
+// ConvexUpsample: out = sum_k p_k v_k, p = softmax_k(logits), v_k = disp(y + k/3 - 1, x + k%3 - 1) * scale (0 outside).
+//   d logit_k = g p_k (v_k - out): every logit belongs to exactly one output pixel -> one lane per output pixel, plain stores
+//   d disp    = scale * sum over the 9 r^2 (tap, output pixel) pairs that read the pixel, softmax recomputed -> one lane per
+//               low-resolution pixel gathers (deterministic, no atomics)
+namespace {
+__global__ void __launch_bounds__(256)
+convex_upsample_bwd_mask_kernel(const float* __restrict__ mask, const float* __restrict__ disp, const float* __restrict__ g,
+                                float* __restrict__ gmask, int B, int H, int W, int r, float disp_scale) {
+  const int HW = H * W, Ho = H * r, Wo = W * r;
+  const long long n = static_cast<long long>(B) * Ho * Wo;
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ox = static_cast<int>(i % Wo);
+  const long long t = i / Wo;
+  const int oy = static_cast<int>(t % Ho), b = static_cast<int>(t / Ho);
+  const int y = oy / r, ry = oy - y * r, x = ox / r, rx = ox - x * r;
+  const size_t base = (static_cast<size_t>(b) * 9 * r * r + ry * r + rx) * HW + static_cast<size_t>(y) * W + x;
+  const float* dp = disp + static_cast<size_t>(b) * HW;
+  float m[9], v[9], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { m[k] = mask[base + static_cast<size_t>(k) * r * r * HW]; mx = fmaxf(mx, m[k]); }
+  float den = 0.f, acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    m[k] = expf(m[k] - mx);
+    den += m[k];
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    const float dv = dp[min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+    v[k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? dv * disp_scale : 0.f;
+    acc += m[k] * v[k];
+  }
+  const float inv = 1.f / den, out = acc * inv, gv = g[i];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) gmask[base + static_cast<size_t>(k) * r * r * HW] = gv * m[k] * inv * (v[k] - out);
+}
+
+__global__ void __launch_bounds__(256)
+convex_upsample_bwd_disp_kernel(const float* __restrict__ mask, const float* __restrict__ g, float* __restrict__ gdisp, int B, int H,
+                                int W, int r, float disp_scale) {
+  const int HW = H * W, Ho = H * r, Wo = W * r;
+  const long long n = static_cast<long long>(B) * HW;
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int xx = static_cast<int>(i % W);
+  const long long t = i / W;
+  const int yy = static_cast<int>(t % H), b = static_cast<int>(t / H);
+  float acc = 0.f;
+  for (int k = 0; k < 9; ++k) {
+    const int y = yy - (k / 3 - 1), x = xx - (k % 3 - 1);           // the pixel whose tap k reads (yy, xx)
+    if (y < 0 || y >= H || x < 0 || x >= W) continue;
+    for (int q = 0; q < r * r; ++q) {
+      const size_t base = (static_cast<size_t>(b) * 9 * r * r + q) * HW + static_cast<size_t>(y) * W + x;
+      float mx = -INFINITY, mk = 0.f;
+      float e[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) { e[j] = mask[base + static_cast<size_t>(j) * r * r * HW]; mx = fmaxf(mx, e[j]); }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) { e[j] = expf(e[j] - mx); den += e[j]; mk = (j == k) ? e[j] : mk; }
+      const int oy = y * r + q / r, ox = x * r + q % r;
+      acc += g[(static_cast<size_t>(b) * Ho + oy) * Wo + ox] * mk / den;
+    }
+  }
+  gdisp[i] = acc * disp_scale;
+}
+
+// UNet.upsample: out = sum_k p_k bil_k, p = softmax over the 9 logit planes at the output pixel, bil_k = bilinear (align_corners)
+// sample of nb_k(y, x) = disp(y + k/3 - 1, x + k%3 - 1) * Wo / w.
+//   pass 1 (one lane per output pixel): d logit_k = g p_k (bil_k - out), and gp_k = g p_k into the workspace
+//   pass 2 (one lane per low-resolution pixel): d disp = Wo/w * sum_k sum_{output pixels in the bilinear footprint of
+//           (yy - dy_k, xx - dx_k)} gp_k * weight   (gather, deterministic)
+__global__ void __launch_bounds__(256)
+unet_upsample_bwd_mask_kernel(const float* __restrict__ mask, const float* __restrict__ disp, const float* __restrict__ g,
+                              float* __restrict__ gmask, float* __restrict__ gp, int B, int h, int w, int Ho, int Wo, float sh,
+                              float sw) {
+  const long long n = static_cast<long long>(B) * Ho * Wo;
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t HWo = static_cast<size_t>(Ho) * Wo;
+  const int ox = static_cast<int>(i % Wo);
+  const long long t = i / Wo;
+  const int oy = static_cast<int>(t % Ho), b = static_cast<int>(t / Ho);
+  const size_t mbase = static_cast<size_t>(b) * 9 * HWo + static_cast<size_t>(oy) * Wo + ox;
+  const float* dp = disp + static_cast<size_t>(b) * h * w;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  lin_src(sh, oy, h, y0, y1, ly);
+  lin_src(sw, ox, w, x0, x1, lx);
+  const float vs = static_cast<float>(Wo) / static_cast<float>(w);
+  float m[9], bil[9], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { m[k] = mask[mbase + k * HWo]; mx = fmaxf(mx, m[k]); }
+  float den = 0.f, acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int dy = k / 3 - 1, dx = k % 3 - 1;
+    auto nb = [&](int y, int x) {
+      const int yy = y + dy, xx = x + dx;
+      const float dv = dp[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+      return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dv * vs : 0.f;
+    };
+    const float top = (1.f - lx) * nb(y0, x0) + lx * nb(y0, x1);
+    const float bot = (1.f - lx) * nb(y1, x0) + lx * nb(y1, x1);
+    bil[k] = (1.f - ly) * top + ly * bot;
+    m[k] = expf(m[k] - mx);
+    den += m[k];
+    acc += m[k] * bil[k];
+  }
+  const float inv = 1.f / den, out = acc * inv, gv = g[i];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const float pk = m[k] * inv;
+    gmask[mbase + k * HWo] = gv * pk * (bil[k] - out);
+    gp[mbase + k * HWo] = gv * pk;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+unet_upsample_bwd_disp_kernel(const float* __restrict__ gp, float* __restrict__ gdisp, int B, int h, int w, int Ho, int Wo, float sh,
+                              float sw) {
+  const long long n = static_cast<long long>(B) * h * w;
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t HWo = static_cast<size_t>(Ho) * Wo;
+  const int xx = static_cast<int>(i % w);
+  const long long t = i / w;
+  const int yy = static_cast<int>(t % h), b = static_cast<int>(t / h);
+  const float ih = sh > 0.f ? 1.f / sh : 0.f, iw = sw > 0.f ? 1.f / sw : 0.f;
+  float acc = 0.f;
+  for (int k = 0; k < 9; ++k) {
+    const int y = yy - (k / 3 - 1), x = xx - (k % 3 - 1);           // the nb_k pixel that holds disp(yy, xx)
+    if (y < 0 || y >= h || x < 0 || x >= w) continue;
+    int oy0 = sh > 0.f ? static_cast<int>(floorf((static_cast<float>(y) - 1.f) * ih)) : 0;
+    int oy1 = sh > 0.f ? static_cast<int>(ceilf((static_cast<float>(y) + 1.f) * ih)) : Ho - 1;
+    int ox0 = sw > 0.f ? static_cast<int>(floorf((static_cast<float>(x) - 1.f) * iw)) : 0;
+    int ox1 = sw > 0.f ? static_cast<int>(ceilf((static_cast<float>(x) + 1.f) * iw)) : Wo - 1;
+    oy0 = max(oy0, 0); oy1 = min(oy1, Ho - 1); ox0 = max(ox0, 0); ox1 = min(ox1, Wo - 1);
+    const float* gk = gp + (static_cast<size_t>(b) * 9 + k) * HWo;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      int a0, a1;
+      float ly;
+      lin_src(sh, oy, h, a0, a1, ly);
+      const float wy = (a0 == y ? 1.f - ly : 0.f) + (a1 == y ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        int c0, c1;
+        float lx;
+        lin_src(sw, ox, w, c0, c1, lx);
+        const float wx = (c0 == x ? 1.f - lx : 0.f) + (c1 == x ? lx : 0.f);
+        if (wx != 0.f) acc += gk[static_cast<size_t>(oy) * Wo + ox] * wy * wx;
+      }
+    }
+  }
+  gdisp[i] = acc * static_cast<float>(Wo) / static_cast<float>(w);
+}
+}  // namespace
+
+extern "C" int ts_convex_upsample_bwd(const float* mask, const float* disp, const float* grad_out, float* grad_mask,
+                                      float* grad_disp, int B, int H, int W, int factor, float disp_scale, void* stream) {
+  TS_REQUIRE(B > 0 && H > 0 && W > 0 && factor >= 1, TS_ERR_SHAPE, "convex_upsample_bwd: bad size");
+  TS_REQUIRE_PTR(mask); TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(grad_out);
+  if (grad_mask) {
+    hipLaunchKernelGGL(convex_upsample_bwd_mask_kernel, dim3(exact_grid(static_cast<long long>(B) * H * W * factor * factor)),
+                       dim3(256), 0, ts::as_stream(stream), mask, disp, grad_out, grad_mask, B, H, W, factor, disp_scale);
+    if (int rc = ts::launched("convex_upsample_bwd_mask_kernel")) return rc;
+  }
+  if (grad_disp) {
+    hipLaunchKernelGGL(convex_upsample_bwd_disp_kernel, dim3(exact_grid(static_cast<long long>(B) * H * W)), dim3(256), 0,
+                       ts::as_stream(stream), mask, grad_out, grad_disp, B, H, W, factor, disp_scale);
+    if (int rc = ts::launched("convex_upsample_bwd_disp_kernel")) return rc;
+  }
+  return TS_OK;
+}
+
+// workspace: B * 9 * Ho * Wo floats (the softmax-weighted output gradient per tap)
+extern "C" int ts_unet_upsample_bwd(const float* mask, const float* disp, const float* grad_out, float* grad_mask, float* grad_disp,
+                                    void* workspace, int B, int h, int w, int Ho, int Wo, void* stream) {
+  TS_REQUIRE(B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, TS_ERR_SHAPE, "unet_upsample_bwd: bad size");
+  TS_REQUIRE_PTR(mask); TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(grad_out); TS_REQUIRE_PTR(grad_mask); TS_REQUIRE_PTR(workspace);
+  float* gp = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(unet_upsample_bwd_mask_kernel, dim3(exact_grid(static_cast<long long>(B) * Ho * Wo)), dim3(256), 0,
+                     ts::as_stream(stream), mask, disp, grad_out, grad_mask, gp, B, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo));
+  if (int rc = ts::launched("unet_upsample_bwd_mask_kernel")) return rc;
+  if (grad_disp) {
+    hipLaunchKernelGGL(unet_upsample_bwd_disp_kernel, dim3(exact_grid(static_cast<long long>(B) * h * w)), dim3(256), 0,
+                       ts::as_stream(stream), gp, grad_disp, B, h, w, Ho, Wo, ac_scale(h, Ho), ac_scale(w, Wo));
+    if (int rc = ts::launched("unet_upsample_bwd_disp_kernel")) return rc;
+  }
+  return TS_OK;
 }
 
 extern "C" int ts_convex_upsample_fwd(const float* mask, const float* disp, float* out, int B, int H, int W, int factor,

@@ -716,6 +716,74 @@ def block_cost(reference_fm, target_fm, disp_sample, block_cost_scale=3):
     return _BlockCost.apply(reference_fm, target_fm, disp_sample, 0, scales)
 
 
+# --------------------------------------------------------------------------------------------- K5 (training form)
+class _ConvexUpsample(torch.autograd.Function):
+    """ConvexUpsample's combination step (module.py:337-353): softmax over the k*k logits of every output pixel, weighted sum of
+    the 3x3 neighbourhood of `disp * scale`.  logits [B, 9*r*r, H, W], disp [B,1,H,W] -> [B,1,H*r,W*r]."""
+
+    @staticmethod
+    def forward(ctx, logits, disp, r, scale):
+        _require_gpu(logits, disp)
+        logits, disp = _lib.contiguous(logits), _lib.contiguous(disp)
+        B, _, H, W = disp.shape
+        if logits.shape[1] != 9 * r * r or disp.shape[1] != 1:
+            raise ValueError("convex upsample: logits must be [B, 9*r*r, H, W] and disp [B,1,H,W]")
+        out = torch.empty((B, 1, H * r, W * r), device=disp.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ts_convex_upsample_fwd(_lib.ptr(logits), _lib.ptr(disp), _lib.ptr(out), B, H, W, r, float(scale), _stream()),
+                   "ts_convex_upsample_fwd")
+        ctx.save_for_backward(logits, disp)
+        ctx.meta = (r, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, disp = ctx.saved_tensors
+        r, scale = ctx.meta
+        B, _, H, W = disp.shape
+        gl = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        gd = torch.empty_like(disp) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.lib().ts_convex_upsample_bwd(_lib.ptr(logits), _lib.ptr(disp), _lib.ptr(_lib.contiguous(g)), _lib.ptr(gl), _lib.ptr(gd),
+                                                     B, H, W, r, scale, _stream()), "ts_convex_upsample_bwd")
+        return gl, gd, None, None
+
+
+def convex_upsample(logits, disp, upscale_factor, disp_scale):
+    return _ConvexUpsample.apply(logits, disp, int(upscale_factor), float(disp_scale))
+
+
+class _UNetUpsample(torch.autograd.Function):
+    """UNet.upsample (module.py:468-482): softmax over the 9 logit planes, bilinear (align_corners) upsampling of the unfolded
+    disparity * Wo / w, weighted sum.  logits [B,9,Ho,Wo], disp [B,1,h,w] -> [B,1,Ho,Wo]."""
+
+    @staticmethod
+    def forward(ctx, logits, disp):
+        _require_gpu(logits, disp)
+        logits, disp = _lib.contiguous(logits), _lib.contiguous(disp)
+        B, _, Ho, Wo = logits.shape
+        h, w = disp.shape[-2:]
+        out = torch.empty((B, 1, Ho, Wo), device=disp.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ts_unet_upsample_fwd(_lib.ptr(logits), _lib.ptr(disp), _lib.ptr(out), B, h, w, Ho, Wo, _stream()),
+                   "ts_unet_upsample_fwd")
+        ctx.save_for_backward(logits, disp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, disp = ctx.saved_tensors
+        B, _, Ho, Wo = logits.shape
+        h, w = disp.shape[-2:]
+        gl = torch.empty_like(logits)
+        gd = torch.empty_like(disp) if ctx.needs_input_grad[1] else None
+        ws = torch.empty_like(logits)
+        _lib.check(_lib.lib().ts_unet_upsample_bwd(_lib.ptr(logits), _lib.ptr(disp), _lib.ptr(_lib.contiguous(g)), _lib.ptr(gl), _lib.ptr(gd),
+                                                   _lib.ptr(ws), B, h, w, Ho, Wo, _stream()), "ts_unet_upsample_bwd")
+        return gl, gd
+
+
+def unet_upsample(logits, disp):
+    return _UNetUpsample.apply(logits, disp)
+
+
 # --------------------------------------------------------------------------------------------- K4
 class _TopkSoftArgmax(torch.autograd.Function):
     """K4a.  ts_topk_softargmax_{fwd,bwd}; returns (disp, topk_disp, topk_cost)."""

@@ -18,6 +18,8 @@
 // HBM-bound: algorithmic bytes = inputs once + output once; the only
 // extra traffic is the pooled maps (< 2 % of the output).  There is no inter-workgroup reuse, so
 // no XCD-aware block remap is needed here (cdna guide T1: 0 % on ops without shared panels).
+#include <cstdlib>
+
 #include "ts_common.hpp"
 
 namespace {
@@ -904,6 +906,81 @@ block_cost_upsample_direct(const float* __restrict__ P1, const float* __restrict
   }
 }
 
+// The same expansion with RB output rows per lane: the pooled rows a run of RB output rows touches (at most RB/2+2 of
+// level 1, RB/4+2 of level 2) are fetched ONCE and interpolated along W once per pooled row instead of twice per output row
+// (an eighth of the loads and of the W-lerps per stored float4 at RB = 8); per output row what is left is the choice of its two
+// pooled rows (compare-selects: no dynamic register indexing) and the H-lerp.  Same arithmetic order, bit-identical values.
+template <bool VEC, int RB>
+__global__ void __launch_bounds__(256)
+block_cost_upsample_rows(const float* __restrict__ P1, const float* __restrict__ P2, float* __restrict__ out, const Shape s) {
+  constexpr int NR1 = RB / 2 + 2, NR2 = RB / 4 + 2;
+  const int plane = blockIdx.y;
+  const int d = plane % s.D;
+  const int bg = plane / s.D;
+  const int g = bg % s.G, b = bg / s.G;
+  const size_t HW = static_cast<size_t>(s.H) * s.W;
+  const int item = blockIdx.x * blockDim.x + threadIdx.x;
+  const int runs = (s.H + RB - 1) / RB;
+  if (item >= runs * s.nbx) return;
+  const int yb = (item / s.nbx) * RB;
+  const int x4 = (item - (item / s.nbx) * s.nbx) * 4;
+#pragma unroll
+  for (int lvl = 1; lvl <= 2; ++lvl) {
+    if (lvl >= s.scales) break;
+    constexpr int NRmax = NR1;
+    const int NR = (lvl == 1) ? NR1 : NR2;
+    const float* P = (lvl == 1) ? P1 : P2;
+    const int Hs = (lvl == 1) ? s.H1 : s.H2, Ws = (lvl == 1) ? s.W1 : s.W2;
+    const float rh = (lvl == 1) ? s.rh1 : s.rh2, rw = (lvl == 1) ? s.rw1 : s.rw2;
+    const float* Pp = P + static_cast<size_t>(plane) * Hs * Ws;
+    const int hlo = min(static_cast<int>(rh * static_cast<float>(yb)), Hs - 1);
+    const int c0 = min(static_cast<int>(rw * static_cast<float>(x4)), Ws - 1);
+    float cell[NRmax][4];
+#pragma unroll
+    for (int r = 0; r < NRmax; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        cell[r][c] = (r < NR) ? Pp[static_cast<size_t>(min(hlo + r, Hs - 1)) * Ws + min(c0 + c, Ws - 1)] : 0.f;
+    // along W, once per pooled row
+    float rowv[NRmax][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float wr = rw * static_cast<float>(min(x4 + k, s.W - 1));
+      const int w1 = static_cast<int>(wr);
+      const int wp = (w1 < Ws - 1) ? 1 : 0;
+      const float wl = wr - static_cast<float>(w1);
+      const int i0 = w1 - c0, i1 = i0 + wp;
+#pragma unroll
+      for (int r = 0; r < NRmax; ++r) {
+        float a0 = cell[r][0], a1 = a0;
+#pragma unroll
+        for (int c = 1; c < 4; ++c) { a0 = (i0 == c) ? cell[r][c] : a0; a1 = (i1 == c) ? cell[r][c] : a1; }
+        rowv[r][k] = (1.f - wl) * a0 + wl * a1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int y = yb + q;
+      if (y >= s.H) break;
+      const float hr = rh * static_cast<float>(y);
+      const int h1 = min(static_cast<int>(hr), Hs - 1);
+      const int hp = (h1 < Hs - 1) ? 1 : 0;
+      const float hl = hr - static_cast<float>(h1);
+      const int i0 = h1 - hlo, i1 = i0 + hp;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float top = rowv[0][k], bot = top;
+#pragma unroll
+        for (int r = 1; r < NRmax; ++r) { top = (i0 == r) ? rowv[r][k] : top; bot = (i1 == r) ? rowv[r][k] : bot; }
+        v[k] = (1.f - hl) * top + hl * bot;
+      }
+      float* pl = out + ((static_cast<size_t>(b) * s.Ctot + s.mainC + lvl * s.G + g) * s.D + d) * HW + static_cast<size_t>(y) * s.W;
+      st4<VEC>(pl, x4, s.W, make_float4(v[0], v[1], v[2], v[3]));
+    }
+  }
+}
+
 int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales, bool omit_ref = false, int min_hw = 4) {
   TS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, TS_ERR_SHAPE, "block_cost: non-positive size");
   TS_REQUIRE(C % GRP == 0, TS_ERR_SHAPE, "block_cost: C=%d is not a multiple of 8 (block_cost.py:9)", C);
@@ -991,7 +1068,21 @@ int launch_fwd(const float* left, const float* right, const float* disp, float* 
 #undef TS_LAUNCH_WIDE
   if (int rc = ts::launched("block_cost_main")) return rc;
 
-  if (scales > 1 && static_cast<long long>(B) * s.G * D <= 65535) {
+  // output rows per lane of the expansion: 4 (measured at the 1/4 level: 2 rows 9.9 us, 4 rows 7.6 us, 8 rows 8.9 us -- too few
+  // lanes); TS_K1_UPSAMPLE_ROWS=2|8 for the A/B
+  static const int up_rows = [] { const char* e = getenv("TS_K1_UPSAMPLE_ROWS"); return e ? atoi(e) : 4; }();
+  if (scales > 1 && static_cast<long long>(B) * s.G * D <= 65535 && (up_rows == 4 || up_rows == 8)) {
+    const int rb = up_rows;
+    const dim3 dgrid((((H + rb - 1) / rb) * s.nbx + 255) / 256, B * s.G * D);
+    if (rb == 8) {
+      if (vec) hipLaunchKernelGGL((block_cost_upsample_rows<true, 8>), dgrid, dim3(256), 0, st, P1, P2, out, s);
+      else hipLaunchKernelGGL((block_cost_upsample_rows<false, 8>), dgrid, dim3(256), 0, st, P1, P2, out, s);
+    } else {
+      if (vec) hipLaunchKernelGGL((block_cost_upsample_rows<true, 4>), dgrid, dim3(256), 0, st, P1, P2, out, s);
+      else hipLaunchKernelGGL((block_cost_upsample_rows<false, 4>), dgrid, dim3(256), 0, st, P1, P2, out, s);
+    }
+    if (int rc = ts::launched("block_cost_upsample_rows")) return rc;
+  } else if (scales > 1 && static_cast<long long>(B) * s.G * D <= 65535) {
     const dim3 dgrid((((H + 1) / 2) * s.nbx + 255) / 256, B * s.G * D);
     if (vec) hipLaunchKernelGGL(block_cost_upsample_direct<true>, dgrid, dim3(256), 0, st, P1, P2, out, s);
     else hipLaunchKernelGGL(block_cost_upsample_direct<false>, dgrid, dim3(256), 0, st, P1, P2, out, s);

@@ -240,6 +240,10 @@ int ts_reproject_memory_fwd(const float* prev_disp, long long disp_bstride, int 
  *   PredictionHeads (:369-378), 1x1 convolutions (k = 1).
  * ---------------------------------------------------------------------------------------- */
 int ts_conv_cout_pad(int cout);
+/* out[a][t][b] = b < nb ? w[a*stride_a + b*stride_b + (flip ? T-1-t : t)*stride_t] : 0, out [A][T][bpad]: the [Cin][taps][CoutPad]
+ * layouts of ts_conv3d_*_fwd / *_bwd_data from a framework weight ([Cout][Cin][taps] or [Cin][Cout][taps]) in one launch. */
+int ts_conv_weight_layout(const float* w, float* out, int A, int T, int nb, int bpad, long long stride_a, long long stride_b,
+                          long long stride_t, int flip, void* stream);
 /* Upper bound (8 | 16 | 32, default 32) on the input-channel chunk -- hence the LDS footprint -- of the
  * convolution launches that follow on this host thread: short chunks when kernels of several streams
  * should share the CUs, long chunks for a lone dependent chain.  Recordable in a plan. */

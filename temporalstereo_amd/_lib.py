@@ -59,6 +59,7 @@ SIGNATURES = {
     "ts_softsplat_softmax_workspace_bytes": (c_size, [c_int] * 4),
     "ts_softsplat_softmax_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 4 + [c_ptr]),
     "ts_conv_cout_pad": (c_int, [c_int]),
+    "ts_conv_weight_layout": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_longlong] * 3 + [c_int, c_ptr]),
     "ts_conv_set_chunk_cap": (c_int, [c_int]),
     "ts_conv3d_hw_fwd": (c_int, [c_f32p] * 5 + [c_int] * 10 + [c_float] + [ctypes.c_longlong] * 4 +
                          [c_f32p, ctypes.c_longlong, c_ptr, c_size, c_ptr]),

@@ -524,6 +524,22 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   return launch_nc<1, MODE, KT, ST, DL>(wgs, x, w, scale, shift, y, p, grid, st);
 }
 
+// Weight re-layout for the convolution kernels in ONE launch (the training path re-lays every layer's weight three times per
+// step -- forward, backward-data, and the framework needed reshape + permute + zeros + copy = four launches for each):
+//   out[a][t][b] = b < nb ? w[a * sa + b * sb + (flip ? T - 1 - t : t) * st] : 0       out is [A][T][bpad]
+__global__ void __launch_bounds__(256)
+weight_layout_kernel(const float* __restrict__ w, float* __restrict__ out, int A, int T, int nb, int bpad, long long sa, long long sb,
+                     long long st, int flip) {
+  const long long n = static_cast<long long>(A) * T * bpad;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(i % bpad);
+    const long long r = i / bpad;
+    const int t = static_cast<int>(r % T), a = static_cast<int>(r / T);
+    out[i] = b < nb ? w[a * sa + b * sb + (flip ? T - 1 - t : t) * st] : 0.f;
+  }
+}
+
 // extent checks shared by the entry points: buffer addressing is 32-bit per batch element
 bool ig_extent(IG& p, int KT) {
   const unsigned long long in_b = (static_cast<unsigned long long>(p.Cin - 1) * p.in_cstride + static_cast<unsigned long long>(p.D) * p.H * p.W) * 4ull;
@@ -985,4 +1001,16 @@ extern "C" size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, 
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const int ks = conv_hw_ksplit(B, Cin, Cout, D, Ho, Wo);
   return ks > 1 ? static_cast<size_t>(ks) * B * Cout * D * Ho * Wo * sizeof(float) : 0;
+}
+
+extern "C" int ts_conv_weight_layout(const float* w, float* out, int A, int T, int nb, int bpad, long long stride_a,
+                                     long long stride_b, long long stride_t, int flip, void* stream) {
+  TS_REQUIRE(A > 0 && T > 0 && nb > 0 && bpad >= nb, TS_ERR_SHAPE, "conv_weight_layout: bad size");
+  TS_REQUIRE_PTR(w); TS_REQUIRE_PTR(out);
+  const long long n = static_cast<long long>(A) * T * bpad;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(weight_layout_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ts::as_stream(stream), w, out, A, T, nb,
+                     bpad, stride_a, stride_b, stride_t, flip);
+  return ts::launched("weight_layout_kernel");
 }

@@ -260,8 +260,30 @@ def _pad_last(t, n):
     return out
 
 
+_CPAD = {}
+
+
 def _cpad(n):
-    return int(_lib.lib().ts_conv_cout_pad(n))
+    if n not in _CPAD:
+        _CPAD[n] = int(_lib.lib().ts_conv_cout_pad(n))
+    return _CPAD[n]
+
+
+def _layout(weight, a_dim, b_dim, flip=False):
+    """[A][taps][pad(B)] kernel layout of a conv weight [d0, d1, taps...] in one launch (ts_conv_weight_layout): A / B are
+    which of the first two dimensions goes outermost / innermost."""
+    weight = weight.detach()
+    if not weight.is_contiguous():
+        weight = weight.contiguous()
+    d0, d1 = weight.shape[0], weight.shape[1]
+    T = weight[0, 0].numel()
+    strides = (d1 * T, T)
+    A, nb = weight.shape[a_dim], weight.shape[b_dim]
+    bpad = _cpad(nb)
+    out = torch.empty((A, T, bpad), device=weight.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ts_conv_weight_layout(_lib.ptr(weight), _lib.ptr(out), A, T, nb, bpad, strides[a_dim], strides[b_dim], 1,
+                                                int(flip), _stream()), "ts_conv_weight_layout")
+    return out
 
 
 def _shift_vec(bias, n):
@@ -281,11 +303,11 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None):
     w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
     if transposed:                                   # weight [Cin, Cout, 1, 3, 3]
         Cout = weight.shape[1]
-        w_t = _pad_last(w9.permute(0, 2, 1), _cpad(Cout))                       # [ci][t][co]
+        w_t = _layout(weight, 0, 1)                                              # [ci][t][co]
         Ho, Wo = 2 * H, 2 * W
     else:                                            # weight [Cout, Cin, 1, 3, 3]
         Cout = weight.shape[0]
-        w_t = _pad_last(w9.permute(1, 2, 0), _cpad(Cout))
+        w_t = _layout(weight, 1, 0)
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((B, Cout, D, Ho, Wo), device=x.device, dtype=torch.float32)
     L = _lib.lib()
@@ -307,11 +329,11 @@ def _hw_backward(x, weight, dy, geom, need_x, need_w):
     w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
     if need_x:
         if transposed:
-            w_b = _pad_last(w9.permute(1, 2, 0), _cpad(Cin))                    # [co][t][ci] = W_T[ci][co][t]
+            w_b = _layout(weight, 1, 0)                                          # [co][t][ci] = W_T[ci][co][t]
         elif stride == 2:
-            w_b = _pad_last(w9.permute(0, 2, 1), _cpad(Cin))                    # [co][t][ci], taps as they are
+            w_b = _layout(weight, 0, 1)                                          # [co][t][ci], taps as they are
         else:
-            w_b = _pad_last(w9.flip(2).permute(0, 2, 1), _cpad(Cin))            # taps flipped
+            w_b = _layout(weight, 0, 1, flip=True)                               # taps flipped
         dx = torch.empty_like(x)
         rc = L.ts_conv3d_hw_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, D, H, W, stride, dilation,
                                      int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
@@ -356,11 +378,11 @@ def _d_forward(x, weight, stride, dilation, padding, transposed, bias=None):
     wk = weight.reshape(weight.shape[0], weight.shape[1], k)
     if transposed:
         Cout = weight.shape[1]
-        w_t = _pad_last(wk.permute(0, 2, 1), _cpad(Cout))
+        w_t = _layout(weight, 0, 1)
         Dout = 2 * Din
     else:
         Cout = weight.shape[0]
-        w_t = _pad_last(wk.permute(1, 2, 0), _cpad(Cout))
+        w_t = _layout(weight, 1, 0)
         Dout = (Din + 2 * padding - dilation * (k - 1) - 1) // stride + 1
     y = torch.empty((B, Cout, Dout, H, W), device=x.device, dtype=torch.float32)
     sh = _shift_vec(bias, _cpad(Cout))
@@ -379,11 +401,11 @@ def _d_backward(x, weight, dy, geom, need_x, need_w):
     wk = weight.reshape(weight.shape[0], weight.shape[1], k)
     if need_x:
         if transposed:
-            w_b = _pad_last(wk.permute(1, 2, 0), _cpad(Cin))
+            w_b = _layout(weight, 1, 0)
         elif stride == 2:
-            w_b = _pad_last(wk.permute(0, 2, 1), _cpad(Cin))
+            w_b = _layout(weight, 0, 1)
         else:
-            w_b = _pad_last(wk.flip(2).permute(0, 2, 1), _cpad(Cin))
+            w_b = _layout(weight, 0, 1, flip=True)
         dx = torch.empty_like(x)
         rc = L.ts_conv3d_d_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, Din, H, W, k, stride, dilation,
                                     padding, int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())

@@ -8,6 +8,29 @@ import sqlite3
 import sys
 
 
+def families(path, window=None):
+    """Busy time per kernel family (template arguments and argument lists stripped)."""
+    import re
+    db = sqlite3.connect(path)
+    where = ""
+    if window:
+        tend = db.execute("select max(end) from kernels").fetchone()[0]
+        where = " where start >= %d and start <= %d" % (tend - int(window[0] * 1e6), tend - int(window[1] * 1e6))
+    fam = {}
+    for name, dur in db.execute("select name, end-start from kernels" + where):
+        n = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        n = re.sub(r"<.*", "", n)
+        n = re.sub(r"\(.*", "", n).replace("void ", "")
+        f = fam.setdefault(n, [0, 0])
+        f[0] += 1
+        f[1] += dur
+    tot = sum(v[1] for v in fam.values()) or 1
+    print("%-60s %8s %12s %6s" % ("kernel family", "calls", "busy_ms", "pct"))
+    for n, (c, d) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:40]:
+        print("%-60s %8d %12.3f %6.1f" % (n[:60], c, d / 1e6, 100.0 * d / tot))
+    print("total busy %.3f ms" % (tot / 1e6))
+
+
 def main(path, top=25, window=None, by_grid=False):
     db = sqlite3.connect(path)
     where = ""
@@ -40,5 +63,9 @@ if __name__ == "__main__":
         window = (float(args[i + 1]), float(args[i + 2]))
         args = args[:i] + args[i + 3:]
     by_grid = "--by-grid" in args
-    args = [a for a in args if a != "--by-grid"]
-    main(args[0], int(args[1]) if len(args) > 1 else 25, window, by_grid)
+    fam = "--by-family" in args
+    args = [a for a in args if a not in ("--by-grid", "--by-family")]
+    if fam:
+        families(args[0], window)
+    else:
+        main(args[0], int(args[1]) if len(args) > 1 else 25, window, by_grid)

@@ -28,6 +28,8 @@ import time
 # the one framework pass this script makes (BatchNorm calibration) should not trigger MIOpen's
 # exhaustive solver search (seconds of naive-kernel benchmarking that would drown a profile)
 os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+# hipGraph replays of the training step (train-graph): see temporalstereo_amd/train.py; read when the HIP runtime starts
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import numpy as np
 import torch
@@ -224,7 +226,7 @@ def cpu_baseline(seed, budget_s=20.0, all_cores=False):
                        "(torch %s CPU kernels, %d threads; first pass %.2fs excluded)" % (n, torch.__version__, cores, first)), out, sd
 
 
-def training_leg(dev, rank, world, steps, warmup, batch, seed):
+def training_leg(dev, rank, world, steps, warmup, batch, seed, graph=False):
     """Data-parallel TRAINING steps of the same path (temporalstereo_amd.train.TrainStep: T=2 frame loop with the previous frame
     in eval()/no_grad, update_map, train-mode forward, fused smooth-L1 + Wasserstein losses, backward through the HIP kernels,
     bucketed gradient all-reduce over RCCL + SyncBatchNorm, clip 0.1, RMSprop), FlyingThings3D 544x960 D=192, `batch` pairs per GPU.
@@ -244,7 +246,7 @@ def training_leg(dev, rank, world, steps, warmup, batch, seed):
     T = torch.from_numpy(synth.small_motion(seed + rank, batch)).to(dev)
     eye = torch.eye(4, device=dev).expand(batch, 4, 4).contiguous()
     poses = [(eye, eye), (T, eye)]
-    step = TrainStep(net, max_disp=MAX_DISP, local_map_size=1)
+    step = TrainStep(net, max_disp=MAX_DISP, local_map_size=1, graph=graph)
     for _ in range(warmup):
         loss = step(frames, gt, K, poses)
     torch.cuda.synchronize()
@@ -267,7 +269,8 @@ def training_leg(dev, rank, world, steps, warmup, batch, seed):
         el = float(tt.item())
     nparam = sum(p.numel() for p in step.params)
     return dict(value=world * batch * steps / el, unit="pairs/s", ms_per_step=el / steps * 1e3, steps=steps, batch_per_gpu=batch,
-                frames=2, mode="eager autograd", sync_bn=step.sync_bn,
+                frames=2, mode="hipGraph replay of previous frame + update + forward + losses + backward" if graph else "eager autograd",
+                sync_bn=step.sync_bn,
                 gradient_exchange_ms=exch / steps, gradient_bytes=4 * nparam, final_loss=float(loss),
                 buckets_launched_in_backward=(step.buckets.launched_in_backward if step.buckets is not None else None),
                 note="training step of the aggregation path (features given, requires_grad): previous frame eval/no_grad + update_map + "
@@ -288,7 +291,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (config 2: 1)")
     ap.add_argument("--mode", default="native",
-                    choices=["native", "native-eager", "native-graph", "module", "module-graph", "module-hip", "train"],
+                    choices=["native", "native-eager", "native-graph", "module", "module-graph", "module-hip", "train", "train-graph"],
                     help="native: all-HIP inference path (aggregation.native) replayed from a recorded native "
                          "launch plan; native-eager: the same, issued op by op from Python; module: nn.Module "
                          "forward with the framework's own (MIOpen) convolutions; module-hip: nn.Module forward "
@@ -342,8 +345,8 @@ def main():
             dist.init_process_group(backend=backend)
 
     seed = synth.SEED0 + 2                      # config index 2
-    if a.mode == "train":
-        tr = training_leg(dev, rank, world, a.steps, a.warmup, a.batch, seed)
+    if a.mode in ("train", "train-graph"):
+        tr = training_leg(dev, rank, world, a.steps, a.warmup, a.batch, seed, graph=a.mode == "train-graph")
         if rank == 0:
             print(json.dumps(dict(metric="stereo pairs/sec, TRAINING step, FlyingThings3D 540x960 D=192 T=2 (aggregation hot path)",
                                   value=tr["value"], unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
@@ -495,8 +498,10 @@ def main():
         # the headline line at the mercy of a rank that fails inside them; `--mode train --gpus N` is the multi-GPU training run)
         try:
             training = training_leg(dev, rank, world, 8, 3, 1, seed)
+            g = training_leg(dev, rank, world, 16, 3, 1, seed, graph=True)
+            training["hipgraph"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "mode", "final_loss")}
         except Exception as e:      # the headline number must survive a failure of the extra leg
-            training = dict(error="%s: %s" % (type(e).__name__, e))
+            training = dict(error="%s: %s" % (type(e).__name__, e)) if training is None else dict(training, hipgraph_error="%s: %s" % (type(e).__name__, e))
 
     result = None
     if rank == 0:

@@ -272,21 +272,26 @@ int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* scale, const 
  *               [Cout][taps][ts_conv_cout_pad(Cin)]: taps flipped for a stride-1 forward, unflipped for a
  *               stride-2 forward (runs as the transposed form, cropped to the input size) and for a
  *               transposed forward (runs as a stride-2 convolution of dy).
- *   bwd_weight: x, dy -> dw [Cout][Cin][taps] in the framework's layout, OVERWRITTEN; fp32 atomics, so the
- *               summation order is not deterministic (as in the reference's cuDNN wgrad).  Cout <= 64.
- *               Transposed forward: call with x := dy, dy := x, stride 2 -> [Cin][Cout][taps]. */
+ *   bwd_weight: x, dy -> dw [Cout][Cin][taps] in the framework's layout, OVERWRITTEN.  Every workgroup
+ *               leaves its partial sums in `workspace` (ts_conv3d_bwd_weight_workspace_bytes(Cin, Cout,
+ *               taps) bytes, taps = 9 | k; contents undefined afterwards) and a second launch adds them in a
+ *               fixed order: the result is deterministic (no atomics).  Cout <= 64.
+ *               Transposed forward: call with x := dy, dy := x, stride 2 -> [Cin][Cout][taps]
+ *               (and size the workspace with the exchanged channel counts). */
+size_t ts_conv3d_bwd_weight_workspace_bytes(int Cin, int Cout, int taps);
 int ts_conv3d_hw_bwd_data(const float* dy, const float* w_b, float* dx, int B, int Cin, int Cout, int D, int H, int W,
                           int stride, int dilation, int transposed, long long dy_bstride, long long dy_cstride,
                           long long dx_bstride, long long dx_cstride, void* stream);
 int ts_conv3d_hw_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H, int W,
                             int stride, int dilation, long long x_bstride, long long x_cstride, long long dy_bstride,
-                            long long dy_cstride, void* stream);
+                            long long dy_cstride, void* workspace, size_t workspace_bytes, void* stream);
 int ts_conv3d_d_bwd_data(const float* dy, const float* w_b, float* dx, int B, int Cin, int Cout, int Din, int H, int W,
                          int k, int stride, int dilation, int padding, int transposed, long long dy_bstride,
                          long long dy_cstride, long long dx_bstride, long long dx_cstride, void* stream);
 int ts_conv3d_d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int Din, int H, int W,
                            int k, int stride, int dilation, int padding, long long x_bstride, long long x_cstride,
-                           long long dy_bstride, long long dy_cstride, void* stream);
+                           long long dy_bstride, long long dy_cstride, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* ResidualBlock3D up-steps: out = act(trilinear_align_corners(a -> (D,H,W)) + add)  module.py:285-295 */
 int ts_resize3d_add_act_fwd(const float* a, const float* add, float* out, int B, int C, int Da, int Ha, int Wa,
                             int D, int H, int W, int act, long long a_bstride, long long a_cstride,

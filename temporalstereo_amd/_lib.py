@@ -65,9 +65,10 @@ SIGNATURES = {
                          [c_f32p, ctypes.c_longlong, c_ptr, c_size, c_ptr]),
     "ts_conv3d_hw_workspace_bytes": (c_size, [c_int] * 8),
     "ts_conv3d_hw_bwd_data": (c_int, [c_f32p] * 3 + [c_int] * 9 + [ctypes.c_longlong] * 4 + [c_ptr]),
-    "ts_conv3d_hw_bwd_weight": (c_int, [c_f32p] * 3 + [c_int] * 8 + [ctypes.c_longlong] * 4 + [c_ptr]),
+    "ts_conv3d_bwd_weight_workspace_bytes": (ctypes.c_size_t, [c_int] * 3),
+    "ts_conv3d_hw_bwd_weight": (c_int, [c_f32p] * 3 + [c_int] * 8 + [ctypes.c_longlong] * 4 + [c_ptr, ctypes.c_size_t, c_ptr]),
     "ts_conv3d_d_bwd_data": (c_int, [c_f32p] * 3 + [c_int] * 11 + [ctypes.c_longlong] * 4 + [c_ptr]),
-    "ts_conv3d_d_bwd_weight": (c_int, [c_f32p] * 3 + [c_int] * 10 + [ctypes.c_longlong] * 4 + [c_ptr]),
+    "ts_conv3d_d_bwd_weight": (c_int, [c_f32p] * 3 + [c_int] * 10 + [ctypes.c_longlong] * 4 + [c_ptr, ctypes.c_size_t, c_ptr]),
     "ts_conv3d_d_fwd": (c_int, [c_f32p] * 5 + [c_int] * 12 + [c_float] + [ctypes.c_longlong] * 4 + [c_ptr]),
     "ts_resize3d_add_act_fwd": (c_int, [c_f32p] * 3 + [c_int] * 9 + [ctypes.c_longlong] * 6 + [c_ptr]),
     "ts_pool3d5_avgmax_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [ctypes.c_longlong] * 6 + [c_ptr]),

@@ -557,8 +557,10 @@ bool ig_extent(IG& p, int KT) {
 // B = X (4 pixels x 16 channels), D = a 16x16 block of dW.
 //   workgroup = (a run of pixel tiles) x (16 input channels) x (all <= 64 output channels, all taps);
 //   the (tap, 16-output-channel block) pairs are dealt round-robin to the four waves, each keeping its
-//   blocks of dW in registers across all of the workgroup's tiles and adding them to memory ONCE at the
-//   end (fp32 hardware atomics; summation order is not deterministic, as in the framework's own wgrad).
+//   blocks of dW in registers across all of the workgroup's tiles and writing them ONCE at the end as a
+//   partial [ci block][workgroup][item][r][lane] of the caller's workspace; wgrad_finish sums the
+//   workgroups' partials in a fixed order (deterministic; the first version added them to dW with fp32
+//   atomics -- 5-9 million device-scope atomics per layer, 270-365 us of the 2-D layers' 300-380 us).
 //   Per tile: dY [pixels][channels] and X [haloed pixels][16 channels] are staged in LDS pixel-major
 //   (odd pitches: the transposing writes and both fragment reads are conflict-free or 2-way at worst).
 // ------------------------------------------------------------------------------------------------
@@ -573,7 +575,7 @@ struct WG {
 
 template <int MODE, int KT, int ST, int DL>
 __global__ void __launch_bounds__(256)
-wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, const WG p) {
+wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, const WG p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CIP = 17;                                        // LDS pitch of an X pixel (16 channels + 1)
   constexpr int TRW = (MODE == MODE_HW) ? (ST == 2 ? 4 : 8) : 8; // tile rows (MODE_HW) -- 32 columns; MODE_D: 256 pixels
@@ -673,22 +675,50 @@ wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* _
       acc[it] = a;
     }
   }
-  // ---- one atomic add per element of this workgroup's dW blocks: lane holds co = 4 kq + r, ci = j
+  // ---- this workgroup's partial blocks: row (item, r) of 64 lanes; lane holds co = 16 cb + 4 kq + r, ci = ci0 + j
+  float* mine = part + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * nitems * 256;
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int item = wave + 4 * it;
     if (item >= nitems) break;
-    const int tap = item / cob, cb = item - tap * cob;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = cb * 16 + kq * 4 + r, ci = ci0 + j;
-      if (co < p.Cout && ci < p.Cin) atomicAdd(dw + (static_cast<size_t>(co) * p.Cin + ci) * KT + tap, acc[it][r]);
-    }
+    for (int r = 0; r < 4; ++r) mine[(item * 4 + r) * 64 + lane] = acc[it][r];
   }
 }
 
+// dW[co][ci][tap] = sum over the workgroups of one input-channel block, in launch order.
+//   grid (rows = items x 4, ci blocks), 256 threads: wave w adds workgroups w, w+4, ... of its row, the four
+//   wave sums are combined in wave order.
+__global__ void __launch_bounds__(256)
+wgrad_finish(const float* __restrict__ part, float* __restrict__ dw, int gx, int nitems, int cob, int Cin, int Cout, int KT) {
+  __shared__ float red[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x, cib = blockIdx.y;
+  const float* src = part + (static_cast<size_t>(cib) * gx * nitems * 4 + row) * 64 + lane;
+  const size_t pitch = static_cast<size_t>(nitems) * 256;
+  float s = 0.f;
+#pragma unroll 8
+  for (int g = wave; g < gx; g += 4) s += src[g * pitch];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) {
+    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const int item = row >> 2, r = row & 3;
+    const int tap = item / cob, cb = item - tap * cob;
+    const int co = cb * 16 + (lane >> 4) * 4 + r, ci = cib * 16 + (lane & 15);
+    if (co < Cout && ci < Cin) dw[(static_cast<size_t>(co) * Cin + ci) * KT + tap] = t;
+  }
+}
+
+// workgroups per input-channel block: the chip filled about twice over all blocks (every workgroup ends
+// with one partial of `items` KiB, so more of them only lengthens wgrad_finish)
+int wgrad_groups(int ciblocks) {
+  static const int per_cu = [] { const char* e = getenv("TS_WGRAD_GROUPS_PER_CU"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();
+  return (per_cu * ts::kNumCU + ciblocks - 1) / ciblocks;
+}
+
 template <int MODE, int KT, int ST, int DL>
-int launch_wgrad(const float* x, const float* dy, float* dw, WG p, hipStream_t st) {
+int launch_wgrad(const float* x, const float* dy, float* dw, WG p, void* workspace, size_t workspace_bytes, hipStream_t st) {
   constexpr int TRW = (MODE == MODE_HW) ? (ST == 2 ? 4 : 8) : 8;
   constexpr int NPX = (MODE == MODE_HW) ? TRW * 32 : 256;
   constexpr int NIN = (MODE == MODE_HW) ? ((TRW - 1) * ST + 2 * DL + 1) * (31 * ST + 2 * DL + 1) : KT * 256;
@@ -706,16 +736,19 @@ int launch_wgrad(const float* x, const float* dy, float* dw, WG p, hipStream_t s
   }
   p.ntiles = p.B * p.Do * p.tiles_per_plane;
   const int ciblocks = (p.Cin + 15) / 16;
-  // enough workgroups to fill the chip a few times, few enough that the final atomics stay cheap
-  int gx = (4 * ts::kNumCU + ciblocks - 1) / ciblocks;
+  const int cob = (p.Cout + 15) / 16, nitems = KT * cob;
+  int gx = wgrad_groups(ciblocks);
   if (gx > p.ntiles) gx = p.ntiles;
   if (gx < 1) gx = 1;
+  const size_t need = static_cast<size_t>(gx) * ciblocks * nitems * 256 * sizeof(float);
+  TS_REQUIRE(workspace != nullptr && workspace_bytes >= need, TS_ERR_SHAPE,
+             "conv bwd_weight: workspace of %zu bytes, %zu needed (ts_conv3d_bwd_weight_workspace_bytes)", workspace_bytes, need);
+  float* part = static_cast<float*>(workspace);
   auto kern = &wgrad_kernel<MODE, KT, ST, DL>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  hipError_t e = hipMemsetAsync(dw, 0, static_cast<size_t>(p.Cout) * p.Cin * KT * sizeof(float), st);
-  if (e != hipSuccess) return ts::fail(static_cast<int>(e), "conv bwd_weight: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(gx, ciblocks), dim3(256), lds, st, x, dy, dw, p);
+  hipLaunchKernelGGL(kern, dim3(gx, ciblocks), dim3(256), lds, st, x, dy, part, p);
+  hipLaunchKernelGGL(wgrad_finish, dim3(nitems * 4, ciblocks), dim3(256), 0, st, part, dw, gx, nitems, cob, p.Cin, p.Cout, KT);
   return ts::launched("wgrad_kernel");
 }
 
@@ -850,9 +883,17 @@ extern "C" int ts_conv3d_hw_bwd_data(const float* dy, const float* w_b, float* d
 // -> dw [Cout][Cin][9] (torch layout, OVERWRITTEN).  Cout <= 64.  The transposed form's weight gradient is
 // the same call with the roles of x and dy exchanged (x := dy of the 2H x 2W output, dy := x, stride 2),
 // which yields [Cin][Cout][9] -- ConvTranspose3d's own layout.
+// Upper bound of the partial-sum workspace of both bwd_weight entry points (taps = 9 | k).
+extern "C" size_t ts_conv3d_bwd_weight_workspace_bytes(int Cin, int Cout, int taps) {
+  if (Cin <= 0 || Cout <= 0 || taps <= 0) return 0;
+  const int ciblocks = (Cin + 15) / 16, cob = (Cout + 15) / 16;
+  return static_cast<size_t>(wgrad_groups(ciblocks)) * ciblocks * taps * cob * 256 * sizeof(float);
+}
+
 extern "C" int ts_conv3d_hw_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H,
                                        int W, int stride, int dilation, long long x_bstride, long long x_cstride,
-                                       long long dy_bstride, long long dy_cstride, void* stream) {
+                                       long long dy_bstride, long long dy_cstride, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw_bwd_weight: non-positive size");
   TS_REQUIRE(Cout <= 64, TS_ERR_UNSUPPORTED, "conv3d_hw_bwd_weight: Cout=%d > 64", Cout);
   TS_REQUIRE((stride == 1 && (dilation == 1 || dilation == 2)) || (stride == 2 && dilation == 1), TS_ERR_UNSUPPORTED,
@@ -865,9 +906,9 @@ extern "C" int ts_conv3d_hw_bwd_weight(const float* x, const float* dy, float* d
   p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.dy_bstride = dy_bstride; p.dy_cstride = dy_cstride;
   TS_REQUIRE(wg_extent(p), TS_ERR_UNSUPPORTED, "conv3d_hw_bwd_weight: a batch element spans 2 GiB or more");
   hipStream_t st = ts::as_stream(stream);
-  if (stride == 2) return launch_wgrad<MODE_HW, 9, 2, 1>(x, dy, dw, p, st);
-  if (dilation == 2) return launch_wgrad<MODE_HW, 9, 1, 2>(x, dy, dw, p, st);
-  return launch_wgrad<MODE_HW, 9, 1, 1>(x, dy, dw, p, st);
+  if (stride == 2) return launch_wgrad<MODE_HW, 9, 2, 1>(x, dy, dw, p, workspace, workspace_bytes, st);
+  if (dilation == 2) return launch_wgrad<MODE_HW, 9, 1, 2>(x, dy, dw, p, workspace, workspace_bytes, st);
+  return launch_wgrad<MODE_HW, 9, 1, 1>(x, dy, dw, p, workspace, workspace_bytes, st);
 }
 
 // x [B,Cin,Din,H,W] -> y [B,Cout,Dout,H,W]; w_t is [Cin][k][CoutPad].  k in {1,3,5}.  transposed != 0:
@@ -944,7 +985,8 @@ extern "C" int ts_conv3d_d_bwd_data(const float* dy, const float* w_b, float* dx
 // transposed form: exchange x and dy as for ts_conv3d_hw_bwd_weight.
 extern "C" int ts_conv3d_d_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int Din, int H,
                                       int W, int k, int stride, int dilation, int padding, long long x_bstride,
-                                      long long x_cstride, long long dy_bstride, long long dy_cstride, void* stream) {
+                                      long long x_cstride, long long dy_bstride, long long dy_cstride, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Din > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_d_bwd_weight: non-positive size");
   TS_REQUIRE(Cout <= 64, TS_ERR_UNSUPPORTED, "conv3d_d_bwd_weight: Cout=%d > 64", Cout);
   TS_REQUIRE(k == 1 || k == 3 || k == 5, TS_ERR_UNSUPPORTED, "conv3d_d_bwd_weight: k must be 1, 3 or 5");
@@ -958,9 +1000,9 @@ extern "C" int ts_conv3d_d_bwd_weight(const float* x, const float* dy, float* dw
   p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.dy_bstride = dy_bstride; p.dy_cstride = dy_cstride;
   TS_REQUIRE(wg_extent(p), TS_ERR_UNSUPPORTED, "conv3d_d_bwd_weight: a batch element spans 2 GiB or more");
   hipStream_t st = ts::as_stream(stream);
-  if (k == 1) return launch_wgrad<MODE_D, 1, 1, 1>(x, dy, dw, p, st);
-  if (k == 3) return launch_wgrad<MODE_D, 3, 1, 1>(x, dy, dw, p, st);
-  return launch_wgrad<MODE_D, 5, 1, 1>(x, dy, dw, p, st);
+  if (k == 1) return launch_wgrad<MODE_D, 1, 1, 1>(x, dy, dw, p, workspace, workspace_bytes, st);
+  if (k == 3) return launch_wgrad<MODE_D, 3, 1, 1>(x, dy, dw, p, workspace, workspace_bytes, st);
+  return launch_wgrad<MODE_D, 5, 1, 1>(x, dy, dw, p, workspace, workspace_bytes, st);
 }
 
 // ConvTranspose2d(kernel 4, stride 2, padding 1) of UNet (module.py:453-457): x [B,Cin,H,W] -> y [B,Cout,2H,2W]

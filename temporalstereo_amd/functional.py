@@ -321,6 +321,14 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None):
     return x, y, (B, Cin, Cout, D, H, W, stride, dilation, transposed)
 
 
+def _wgrad_workspace(cin, cout, taps, device):
+    """Partial-sum buffer of ``ts_conv3d_*_bwd_weight`` (symmetric in the channel counts' roles: the larger of
+    the two orders covers the transposed form, which exchanges them)."""
+    L = _lib.lib()
+    n = max(int(L.ts_conv3d_bwd_weight_workspace_bytes(cin, cout, taps)), int(L.ts_conv3d_bwd_weight_workspace_bytes(cout, cin, taps)))
+    return torch.empty(n // 4, dtype=torch.float32, device=device), n
+
+
 def _hw_backward(x, weight, dy, geom, need_x, need_w):
     B, Cin, Cout, D, H, W, stride, dilation, transposed = geom
     dy = dy.contiguous()
@@ -340,12 +348,13 @@ def _hw_backward(x, weight, dy, geom, need_x, need_w):
         _lib.check(rc, "ts_conv3d_hw_bwd_data")
     if need_w:
         dw = torch.empty_like(weight)
+        ws, nws = _wgrad_workspace(Cin, Cout, 9, x.device)
         if transposed:     # roles exchanged: a stride-2 convolution maps dy (2H x 2W) to x
             rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, D, 2 * H, 2 * W, 2, 1,
-                                           dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _stream())
+                                           dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _lib.ptr(ws), nws, _stream())
         else:
             rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, D, H, W, stride, dilation,
-                                           x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _stream())
+                                           x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _lib.ptr(ws), nws, _stream())
         _lib.check(rc, "ts_conv3d_hw_bwd_weight")
     return dx, dw
 
@@ -412,12 +421,13 @@ def _d_backward(x, weight, dy, geom, need_x, need_w):
         _lib.check(rc, "ts_conv3d_d_bwd_data")
     if need_w:
         dw = torch.empty_like(weight)
+        ws, nws = _wgrad_workspace(Cin, Cout, k, x.device)
         if transposed:
             rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, 2 * Din, H, W, 3, 2, 1, 1,
-                                          dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _stream())
+                                          dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _lib.ptr(ws), nws, _stream())
         else:
             rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, Din, H, W, k, stride, dilation,
-                                          padding, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _stream())
+                                          padding, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _lib.ptr(ws), nws, _stream())
         _lib.check(rc, "ts_conv3d_d_bwd_weight")
     return dx, dw
 

@@ -12,13 +12,16 @@ The aggregation's inputs are the backbone's feature pyramids (out of scope: feat
 cost volume's backward towards them runs as it would under the backbone).  Everything on the data path is a HIP kernel behind
 an autograd Function except train-mode BatchNorm / activations (framework ops; SyncBatchNorm of dist.py across ranks).
 
-The step is host-bound through the framework's autograd (~300 Python-level ops per frame: 31.7 ms at 544x960, batch 1, T=2 on
-MI355X).  Capturing previous frame + update + forward + loss + backward into one hipGraph was tried: 18.8 ms per replay -- ROCm
-7.2 replays a captured chain of ~1500 small kernels no faster than it issues them -- and not bit-safe (NaN loss after the first
-optimizer step), so it is not offered.  What gets this step to the kernels' own time is a recorded native plan of forward AND
-backward as for inference (aggregation/engine.py), which needs HIP kernels for train-mode BatchNorm + activation and the backward
-of the 2-D upsamplers first.
+Issued op by op the step is host-bound (~1900 launches through the framework's autograd per T=2 step; the kernels themselves
+take about 60 % of the wall time).  `graph=True` captures previous frames + state update + forward + losses + backward ONCE into a
+hipGraph and replays it per step on static copies of the inputs (the step copies each call's tensors into them); gradient
+exchange, clipping and the optimizer stay outside.  With more than one rank the captured BatchNorm is the per-rank one
+(collectives are not captured), which the step reports as `sync_bn: False`.  ROCm 7.2's replay of pre-built AQL packets
+("graph packet capture") computes garbage gradients from the second or third replay of a graph of this size on (loss finite,
+gradients 1e35 / NaN; bit-stable with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, tools/exp/graph_env.sh), so graph mode insists on that
+setting in the environment -- `temporalstereo_amd` sets it on import when nothing else has.
 """
+import os
 import time
 
 import torch
@@ -29,9 +32,14 @@ from .losses import DispSmoothL1Loss, WarssersteinDistanceLoss
 
 
 class TrainStep:
-    def __init__(self, net, max_disp=192, local_map_size=1, lr=1e-4, clip=0.1, sync_bn=True, bucket_bytes=32 << 20, baseline=1.0):
+    def __init__(self, net, max_disp=192, local_map_size=1, lr=1e-4, clip=0.1, sync_bn=True, bucket_bytes=32 << 20, baseline=1.0,
+                 graph=False):
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        self.sync_bn = bool(sync_bn) and self.world > 1
+        self.graph = bool(graph)
+        if self.graph and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            raise RuntimeError("TrainStep(graph=True) needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP "
+                               "runtime starts (ROCm 7.2 replays pre-built graph packets incorrectly; see train.py)")
+        self.sync_bn = bool(sync_bn) and self.world > 1 and not self.graph
         if self.sync_bn:
             net = tsd.sync_batchnorm(net)
         self.net = net
@@ -41,7 +49,8 @@ class TrainStep:
         self.local_map_size, self.clip, self.baseline = local_map_size, clip, baseline
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.opt = torch.optim.RMSprop(self.params, lr=lr)
-        self.buckets = tsd.GradientBuckets(self.params, bucket_bytes=bucket_bytes) if self.world > 1 else None
+        self.buckets = tsd.GradientBuckets(self.params, bucket_bytes=bucket_bytes) if self.world > 1 and not self.graph else None
+        self._g = self._static = self._loss = None
         self.timings = {}
         self._modules = list(net.modules())
 
@@ -74,14 +83,73 @@ class TrainStep:
         return total.detach()
 
     # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _tensors(tree):
+        if torch.is_tensor(tree):
+            yield tree
+        elif isinstance(tree, (list, tuple)):
+            for t in tree:
+                yield from TrainStep._tensors(t)
+
+    @staticmethod
+    def _clone(tree):
+        if torch.is_tensor(tree):
+            return tree.detach().clone().requires_grad_(tree.requires_grad)
+        if isinstance(tree, (list, tuple)):
+            return type(tree)(TrainStep._clone(t) for t in tree)
+        return tree
+
+    def _capture(self, args):
+        self._static = self._clone(args)
+        # the warm-up passes must leave no trace: BatchNorm's running statistics are put back afterwards
+        buffers = [(b, b.detach().clone()) for b in self.net.buffers()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                                      # warm-up: allocator, solver choices, lazy initialisations
+                self.opt.zero_grad(set_to_none=True)
+                self._forward_backward(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        for b, saved in buffers:
+            b.copy_(saved)
+        torch.cuda.synchronize()
+        self.opt.zero_grad(set_to_none=True)
+        for t in self._tensors(self._static):
+            t.grad = None
+        self._g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g):
+            self._loss = self._forward_backward(*self._static)
+
+    def _all_reduce_flat(self):
+        grads = [p.grad for p in self.params if p.grad is not None]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        torch.distributed.all_reduce(flat)
+        flat.div_(self.world)
+        for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(r)
+
+    # ------------------------------------------------------------------------------------------------------------
     def __call__(self, frames, gt, K, poses):
         """One optimisation step.  Returns the (local) loss as a 0-d device tensor."""
         t0 = time.perf_counter()
-        self.opt.zero_grad(set_to_none=True)
-        loss = self._forward_backward(frames, gt, K, poses)
-        t1 = time.perf_counter()
-        if self.buckets is not None:
-            self.buckets.finish()
+        if self.graph:
+            args = (frames, gt, K, poses)
+            if self._g is None:
+                self._capture(args)
+            else:
+                for dst, src in zip(self._tensors(self._static), self._tensors(args)):
+                    dst.detach().copy_(src, non_blocking=True)
+            self._g.replay()
+            loss = self._loss
+            t1 = time.perf_counter()
+            if self.world > 1:
+                self._all_reduce_flat()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+            loss = self._forward_backward(frames, gt, K, poses)
+            t1 = time.perf_counter()
+            if self.buckets is not None:
+                self.buckets.finish()
         t2 = time.perf_counter()
         if self.clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.clip)

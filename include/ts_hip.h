@@ -101,7 +101,8 @@ int ts_block_cost_sampled_bwd(const float* left, const float* right, const float
  * BatchNorm (+ activation) of the convolution wrappers in TRAIN mode (layers/basic_layers.py:194-235: conv -> norm ->
  * activation).  x / out / dy / dx are [B,C,N] with N = D*H*W contiguous and explicit batch / channel strides (elements).
  *   ts_bn_stats_fwd       mean[C], var[C] (biased) of x over (B,N); deterministic.  running_mean / running_var (may be NULL) are
- *                         updated with `momentum` (running_var with the unbiased estimate, as nn.BatchNorm)
+ *                         updated with `momentum` (running_var with the unbiased estimate, as nn.BatchNorm);
+ *                         *num_batches_tracked (device int64, may be NULL) is incremented in the same launch
  *   ts_bn_apply_act_fwd   out = act((x - mean) * rsqrt(var + eps) * gamma + beta);  act 0 none | 1 SiLU | 2 ReLU
  *   ts_bn_act_bwd_reduce  sum_dz[C] = sum dz, sum_dz_xhat[C] = sum dz * xhat with dz = dy * act'(z)  (= grad beta, grad gamma)
  *   ts_bn_act_bwd_apply   train: dx = (dz - sum_dz/count - xhat * sum_dz_xhat/count) * invstd * gamma; eval: dx = dz * invstd * gamma
@@ -109,7 +110,8 @@ int ts_block_cost_sampled_bwd(const float* left, const float* right, const float
  * ---------------------------------------------------------------------------------------- */
 size_t ts_bn_workspace_bytes(int B, int C, long long N);
 int ts_bn_stats_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
-                    void* workspace, int B, int C, long long N, long long bstride, long long cstride, void* stream);
+                    long long* num_batches_tracked, void* workspace, int B, int C, long long N, long long bstride,
+                    long long cstride, void* stream);
 int ts_bn_apply_act_fwd(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float* out,
                         int B, int C, long long N, long long x_bstride, long long x_cstride, long long out_bstride,
                         long long out_cstride, float eps, int act, void* stream);
@@ -244,6 +246,15 @@ int ts_conv_cout_pad(int cout);
  * layouts of ts_conv3d_*_fwd / *_bwd_data from a framework weight ([Cout][Cin][taps] or [Cin][Cout][taps]) in one launch. */
 int ts_conv_weight_layout(const float* w, float* out, int A, int T, int nb, int bpad, long long stride_a, long long stride_b,
                           long long stride_t, int flip, void* stream);
+/* The same for n weights in one launch (training: every convolution weight is re-laid once per optimizer update).
+ * table: n entries in DEVICE memory; blocks_x: 256-thread workgroups per entry (grid-stride over larger entries). */
+typedef struct {
+  const float* w; float* out;
+  int A, T, nb, bpad;
+  long long stride_a, stride_b, stride_t;
+  int flip, reserved;
+} ts_weight_layout_desc;               /* 64 bytes */
+int ts_conv_weight_layout_many(const void* table, int n, int blocks_x, void* stream);
 /* Upper bound (8 | 16 | 32, default 32) on the input-channel chunk -- hence the LDS footprint -- of the
  * convolution launches that follow on this host thread: short chunks when kernels of several streams
  * should share the CUs, long chunks for a lone dependent chain.  Recordable in a plan. */

@@ -42,7 +42,7 @@ SIGNATURES = {
     "ts_softargmin_bwd": (c_int, [c_f32p] * 6 + [c_float, c_int] + [c_int] * 4 + [c_ptr]),
     "ts_argmax_select_fwd": (c_int, [c_f32p] * 4 + [c_int] * 4 + [c_ptr]),
     "ts_bn_workspace_bytes": (c_size, [c_int, c_int, ctypes.c_longlong]),
-    "ts_bn_stats_fwd": (c_int, [c_f32p] * 5 + [c_float, c_ptr, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_ptr]),
+    "ts_bn_stats_fwd": (c_int, [c_f32p] * 5 + [c_float, c_ptr, c_ptr, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_ptr]),
     "ts_bn_apply_act_fwd": (c_int, [c_f32p] * 6 + [c_int, c_int] + [ctypes.c_longlong] * 5 + [c_float, c_int, c_ptr]),
     "ts_bn_act_bwd_reduce": (c_int, [c_f32p] * 8 + [c_ptr, c_int, c_int] + [ctypes.c_longlong] * 5 + [c_float, c_int, c_ptr]),
     "ts_bn_act_bwd_apply": (c_int, [c_f32p] * 9 + [c_int, c_int] + [ctypes.c_longlong] * 5 + [c_float, c_int, c_int, c_float, c_ptr]),
@@ -60,6 +60,7 @@ SIGNATURES = {
     "ts_softsplat_softmax_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 4 + [c_ptr]),
     "ts_conv_cout_pad": (c_int, [c_int]),
     "ts_conv_weight_layout": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_longlong] * 3 + [c_int, c_ptr]),
+    "ts_conv_weight_layout_many": (c_int, [c_ptr, c_int, c_int, c_ptr]),
     "ts_conv_set_chunk_cap": (c_int, [c_int]),
     "ts_conv3d_hw_fwd": (c_int, [c_f32p] * 5 + [c_int] * 10 + [c_float] + [ctypes.c_longlong] * 4 +
                          [c_f32p, ctypes.c_longlong, c_ptr, c_size, c_ptr]),

@@ -83,8 +83,10 @@ bn_stats_partial(const float* __restrict__ x, float2* __restrict__ partial, cons
 // (running_var takes the unbiased estimate, as nn.BatchNorm does)
 __global__ void __launch_bounds__(64)
 bn_stats_finish(const float* __restrict__ x, const float2* __restrict__ partial, float* __restrict__ mean, float* __restrict__ var,
-                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, const BN p) {
+                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                long long* __restrict__ num_batches_tracked, const BN p) {
   const int c = blockIdx.x;
+  if (num_batches_tracked && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   const int n = p.B * p.nchunk;
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < n; i += 64) {
@@ -216,7 +218,8 @@ extern "C" size_t ts_bn_workspace_bytes(int B, int C, long long N) {
 }
 
 extern "C" int ts_bn_stats_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
-                               void* workspace, int B, int C, long long N, long long bstride, long long cstride, void* stream) {
+                               long long* num_batches_tracked, void* workspace, int B, int C, long long N, long long bstride,
+                               long long cstride, void* stream) {
   TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535, TS_ERR_SHAPE, "bn_stats: bad size");
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(workspace);
   BN p{B, C, N, bstride, cstride, 0, 0};
@@ -225,7 +228,7 @@ extern "C" int ts_bn_stats_fwd(const float* x, float* mean, float* var, float* r
   hipLaunchKernelGGL(bn_stats_partial, dim3(p.nchunk, C, B), dim3(256), 0, ts::as_stream(stream), x, partial, p);
   if (int rc = ts::launched("bn_stats_partial")) return rc;
   hipLaunchKernelGGL(bn_stats_finish, dim3(C), dim3(64), 0, ts::as_stream(stream), x, partial, mean, var, running_mean, running_var,
-                     momentum, p);
+                     momentum, num_batches_tracked, p);
   return ts::launched("bn_stats_finish");
 }
 

@@ -540,6 +540,29 @@ weight_layout_kernel(const float* __restrict__ w, float* __restrict__ out, int A
   }
 }
 
+// The same for a whole table of weights in ONE launch (a training step re-lays every convolution weight once per
+// optimizer update: ~280 launches of the kernel above otherwise).  blockIdx.y = table entry.
+struct WeightLayoutDesc {            // == ts_weight_layout_desc of include/ts_hip.h (64 bytes)
+  const float* w; float* out;
+  int A, T, nb, bpad;
+  long long sa, sb, st;
+  int flip, reserved;
+};
+static_assert(sizeof(WeightLayoutDesc) == 64, "table entry layout");
+
+__global__ void __launch_bounds__(256)
+weight_layout_many_kernel(const WeightLayoutDesc* __restrict__ table) {
+  const WeightLayoutDesc d = table[blockIdx.y];
+  const long long n = static_cast<long long>(d.A) * d.T * d.bpad;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(i % d.bpad);
+    const long long r = i / d.bpad;
+    const int t = static_cast<int>(r % d.T), a = static_cast<int>(r / d.T);
+    d.out[i] = b < d.nb ? d.w[a * d.sa + b * d.sb + (d.flip ? d.T - 1 - t : t) * d.st] : 0.f;
+  }
+}
+
 // extent checks shared by the entry points: buffer addressing is 32-bit per batch element
 bool ig_extent(IG& p, int KT) {
   const unsigned long long in_b = (static_cast<unsigned long long>(p.Cin - 1) * p.in_cstride + static_cast<unsigned long long>(p.D) * p.H * p.W) * 4ull;
@@ -1055,4 +1078,14 @@ extern "C" int ts_conv_weight_layout(const float* w, float* out, int A, int T, i
   hipLaunchKernelGGL(weight_layout_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ts::as_stream(stream), w, out, A, T, nb,
                      bpad, stride_a, stride_b, stride_t, flip);
   return ts::launched("weight_layout_kernel");
+}
+
+// table: n entries of ts_weight_layout_desc in DEVICE memory; blocks_x: workgroups per entry (entries larger than
+// blocks_x * 256 elements are covered by a grid-stride loop, smaller ones leave the surplus workgroups idle).
+extern "C" int ts_conv_weight_layout_many(const void* table, int n, int blocks_x, void* stream) {
+  TS_REQUIRE(n > 0 && n <= 65535 && blocks_x > 0 && blocks_x <= 4096, TS_ERR_SHAPE, "conv_weight_layout_many: bad table size");
+  TS_REQUIRE_PTR(table);
+  hipLaunchKernelGGL(weight_layout_many_kernel, dim3(static_cast<unsigned>(blocks_x), static_cast<unsigned>(n)), dim3(256), 0,
+                     ts::as_stream(stream), static_cast<const WeightLayoutDesc*>(table));
+  return ts::launched("weight_layout_many_kernel");
 }

@@ -82,7 +82,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_bn_stats_fwd),             TS_PLAN_OP(ts_bn_apply_act_fwd),
     TS_PLAN_OP(ts_bn_act_bwd_reduce),        TS_PLAN_OP(ts_bn_act_bwd_apply),
     TS_PLAN_OP(ts_convex_upsample_bwd),      TS_PLAN_OP(ts_unet_upsample_bwd),
-    TS_PLAN_OP(ts_conv_weight_layout),
+    TS_PLAN_OP(ts_conv_weight_layout),      TS_PLAN_OP(ts_conv_weight_layout_many),
 };
 
 struct Call {

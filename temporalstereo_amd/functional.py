@@ -269,21 +269,92 @@ def _cpad(n):
     return _CPAD[n]
 
 
-def _layout(weight, a_dim, b_dim, flip=False):
-    """[A][taps][pad(B)] kernel layout of a conv weight [d0, d1, taps...] in one launch (ts_conv_weight_layout): A / B are
-    which of the first two dimensions goes outermost / innermost."""
+class WeightLayouts:
+    """Kernel layouts of the convolution weights of one training step, refreshed in ONE launch.
+
+    Every convolution call needs its weight as [A][taps][pad(B)] (forward and backward-data each their own): issued one by one that
+    is ~280 launches of `ts_conv_weight_layout` per T=2 step.  Inside `with layouts:` the first request for a (weight, order) pair
+    runs that launch and registers the pair; `refresh()` -- called by the step after the optimizer has changed the weights -- then
+    re-lays every registered pair with one `ts_conv_weight_layout_many` launch and later requests are dictionary look-ups.
+    Keys are (data_ptr, shape, order): in-place updates (the optimizers') keep them valid; a weight that is REPLACED gets a new
+    entry (the stale one is re-laid for nothing until `clear()`)."""
+
+    def __init__(self):
+        self.entries = {}           # key -> (weight, out, descriptor tuple)
+        self._table = None
+        self._dirty = False
+        self._blocks = 1
+
+    def __enter__(self):
+        global _LAYOUTS
+        self._outer, _LAYOUTS = _LAYOUTS, self
+        return self
+
+    def __exit__(self, *exc):
+        global _LAYOUTS
+        _LAYOUTS = self._outer
+        return False
+
+    def clear(self):
+        self.entries, self._table, self._dirty = {}, None, False
+
+    def get(self, weight, a_dim, b_dim, flip):
+        key = (weight.data_ptr(), tuple(weight.shape), a_dim, b_dim, bool(flip))
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= 4096:       # someone feeds temporaries (each kept alive below): start over rather than grow
+                self.clear()
+            out, desc = _layout_now(weight, a_dim, b_dim, flip)
+            self.entries[key] = e = (weight, out, desc)
+            self._dirty = True
+        return e[1]
+
+    def refresh(self):
+        """Re-lay every registered weight from its current values (one launch on the current stream)."""
+        if not self.entries:
+            return
+        if self._dirty:
+            import numpy as np
+            rec = np.zeros(len(self.entries), dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("A", "<i4"), ("T", "<i4"), ("nb", "<i4"),
+                                                               ("bpad", "<i4"), ("sa", "<i8"), ("sb", "<i8"), ("st", "<i8"),
+                                                               ("flip", "<i4"), ("reserved", "<i4")]))
+            most = 1
+            for i, (weight, out, d) in enumerate(self.entries.values()):
+                rec[i] = (weight.data_ptr(), out.data_ptr()) + d + (0,)
+                most = max(most, out.numel())
+            dev = next(iter(self.entries.values()))[1].device
+            self._table = torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev)
+            self._blocks = min(64, (most + 255) // 256)
+            self._dirty = False
+        _lib.check(_lib.lib().ts_conv_weight_layout_many(_lib.ptr(self._table), len(self.entries), self._blocks, _stream()),
+                   "ts_conv_weight_layout_many")
+
+
+_LAYOUTS = None
+
+
+def _layout_now(weight, a_dim, b_dim, flip):
     weight = weight.detach()
     if not weight.is_contiguous():
         weight = weight.contiguous()
-    d0, d1 = weight.shape[0], weight.shape[1]
+    d1 = weight.shape[1]
     T = weight[0, 0].numel()
     strides = (d1 * T, T)
     A, nb = weight.shape[a_dim], weight.shape[b_dim]
     bpad = _cpad(nb)
     out = torch.empty((A, T, bpad), device=weight.device, dtype=torch.float32)
+    desc = (A, T, nb, bpad, strides[a_dim], strides[b_dim], 1, int(flip))
     _lib.check(_lib.lib().ts_conv_weight_layout(_lib.ptr(weight), _lib.ptr(out), A, T, nb, bpad, strides[a_dim], strides[b_dim], 1,
                                                 int(flip), _stream()), "ts_conv_weight_layout")
-    return out
+    return out, desc
+
+
+def _layout(weight, a_dim, b_dim, flip=False):
+    """[A][taps][pad(B)] kernel layout of a conv weight [d0, d1, taps...] (ts_conv_weight_layout): A / B are which of the first two
+    dimensions goes outermost / innermost.  Inside a `WeightLayouts` context the layouts are kept and refreshed together."""
+    if _LAYOUTS is not None and weight.is_contiguous():
+        return _LAYOUTS.get(weight, a_dim, b_dim, flip)
+    return _layout_now(weight, a_dim, b_dim, flip)[0]
 
 
 def _shift_vec(bias, n):
@@ -460,7 +531,8 @@ class _ConvBNAct(torch.autograd.Function):
     backward sums are exchanged across its ranks (SyncBatchNorm of dist.py, one all_gather forward, one all_reduce backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, family, geom, eps, momentum, act, training, group):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, family, geom, eps, momentum, act, training, group,
+                counter=None):
         if family == "hw":
             x, y, cg = _hw_forward(x, weight, geom[0], geom[1], geom[2], bias)
         else:
@@ -475,8 +547,8 @@ class _ConvBNAct(torch.autograd.Function):
             ws = torch.empty(int(L.ts_bn_workspace_bytes(B, C, N)), device=y.device, dtype=torch.uint8)
             local_update = group is None and running_mean is not None
             _lib.check(L.ts_bn_stats_fwd(_lib.ptr(y), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(running_mean if local_update else None),
-                                         _lib.ptr(running_var if local_update else None), float(momentum), _lib.ptr(ws), B, C, N,
-                                         y.stride(0), y.stride(1), _stream()), "ts_bn_stats_fwd")
+                                         _lib.ptr(running_var if local_update else None), float(momentum), _lib.ptr(counter),
+                                         _lib.ptr(ws), B, C, N, y.stride(0), y.stride(1), _stream()), "ts_bn_stats_fwd")
             if group is not None:
                 import torch.distributed as dist
                 world = dist.get_world_size(group)
@@ -535,7 +607,7 @@ class _ConvBNAct(torch.autograd.Function):
         gbias = None
         if has_bias and ctx.needs_input_grad[2]:
             gbias = dy.sum(dim=[0] + list(range(2, dy.dim())))     # == 0 up to rounding in train mode (BatchNorm removes the mean)
-        return dx, dw, gbias, ggamma, gbeta, None, None, None, None, None, None, None, None, None
+        return dx, dw, gbias, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False):
@@ -548,10 +620,9 @@ def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
             group = bn.process_group if bn.process_group is not None else dist.group.WORLD
     momentum = bn.momentum if bn.momentum is not None else 0.1
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    counter = bn.num_batches_tracked if (training and bn.track_running_stats) else None     # incremented by the statistics launch
     return _ConvBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, family, geom, bn.eps, momentum,
-                            BN_ACT[activation], training, group)
+                            BN_ACT[activation], training, group, counter)
 
 
 def conv3d_supported(weight_shape, stride, padding, dilation, groups, transposed=False, output_padding=(0, 0, 0)):

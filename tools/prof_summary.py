@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 results .db (kernel trace) as a per-kernel table.
 
-usage: prof_summary.py results.db [top] [--window-ms A B]   (window relative to the LAST kernel end,
+usage: prof_summary.py results.db [top] [--by-grid | --by-family] [--match SUBSTRING] [--window-ms A B]   (window relative to the LAST kernel end,
        e.g. --window-ms 60 20 keeps kernels that started between 60 and 20 ms before the end)
 """
 import sqlite3
@@ -31,7 +31,7 @@ def families(path, window=None):
     print("total busy %.3f ms" % (tot / 1e6))
 
 
-def main(path, top=25, window=None, by_grid=False):
+def main(path, top=25, window=None, by_grid=False, match=None):
     db = sqlite3.connect(path)
     where = ""
     if window:
@@ -43,6 +43,10 @@ def main(path, top=25, window=None, by_grid=False):
         (" group by name, grid_x, grid_y, grid_z " if by_grid else " group by name ") +
         "order by sum(end-start) desc"))
     tot = sum(r[5] for r in rows) or 1
+    if match:           # full names of the kernels containing `match`
+        for r in [r for r in rows if match in r[0]][:top]:
+            print("%6d calls  %8.1f us avg  %5.1f %%  g=%dx%dx%d  %s" % (r[1], r[2] / 1e3, 100.0 * r[5] / tot, r[9] // max(r[8], 1), r[10], r[11], r[0][:400]))
+        return
     span = db.execute("select min(start), max(end), count(*) from kernels" + where).fetchone()
     print("kernels: %d dispatches, %d distinct, busy %.3f ms over a %.3f ms span" % (span[2], len(rows), tot / 1e6, (span[1] - span[0]) / 1e6))
     print("%-72s %6s %9s %9s %9s %6s %5s %7s %5s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct", "vgpr", "lds", "wg"))
@@ -62,10 +66,15 @@ if __name__ == "__main__":
         i = args.index("--window-ms")
         window = (float(args[i + 1]), float(args[i + 2]))
         args = args[:i] + args[i + 3:]
+    match = None
+    if "--match" in args:
+        i = args.index("--match")
+        match = args[i + 1]
+        args = args[:i] + args[i + 2:]
     by_grid = "--by-grid" in args
     fam = "--by-family" in args
     args = [a for a in args if a not in ("--by-grid", "--by-family")]
     if fam:
         families(args[0], window)
     else:
-        main(args[0], int(args[1]) if len(args) > 1 else 25, window, by_grid)
+        main(args[0], int(args[1]) if len(args) > 1 else 25, window, by_grid, match)

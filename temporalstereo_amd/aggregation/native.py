@@ -16,6 +16,7 @@ aggregation/levels.py with NO framework op on the data path:
 
 Semantics are those of the reference modules in eval mode (citations in levels.py / blocks.py).
 """
+import os
 import time
 
 import torch
@@ -237,6 +238,22 @@ def _strides5(t):
     return t.stride(0), t.stride(1)
 
 
+# TS_CONV_X6=0: every (1,3,3) convolution on the f32-input MFMA kernel (A/B measurements, bit-exact fp32 products)
+X6 = os.environ.get("TS_CONV_X6", "1") != "0"
+
+
+def x6_weights(f):
+    """The bf16-split copy of a Folded layer's weights (ts_conv3d_hw_x6_weight_split), made on first use -- outside any plan
+    recording: the split runs once, replays only read it."""
+    w6 = getattr(f, "w6", None)
+    if w6 is None:
+        L = _lib._real_lib()
+        w6 = torch.empty(int(L.ts_conv3d_hw_x6_weight_bytes(f.cin, f.cout)), device=f.w.device, dtype=torch.uint8)
+        _lib.check(L.ts_conv3d_hw_x6_weight_split(f.w.data_ptr(), w6.data_ptr(), f.cin, f.cout, _stream()), "ts_conv3d_hw_x6_weight_split")
+        f.w6 = w6
+    return w6
+
+
 def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0, addend=None, second=None,
             out_second=None):
     """x [B,Cin,D,H,W] -> [B,Cout,D,Ho,Wo].  addend [B,Cout,1,Ho,Wo]: added to every depth plane's raw sum.
@@ -270,6 +287,14 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
         _lib.ptr(out_second)
     L = _lib.lib()
     wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, f.cout, D, H, W, stride, int(transposed)))
+    if X6 and not wsb and L.ts_conv3d_hw_x6_supported(Cin, f.cout, W, stride, dilation, int(transposed)):
+        # fp32 products from bf16 pieces on the bf16 matrix pipe (fp32-exact to the last bit or two, 3/8 of the matrix time);
+        # layers whose reduction is split over workgroups (small grids) stay on the f32 MFMA kernel
+        rc = L.ts_conv3d_hw_x6_fwd(_lib.ptr(x), _lib.ptr(x6_weights(f)), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
+                                   B, Cin, f.cout, D, H, W, dilation, f.act if act is None else act, float(act_param),
+                                   ib, ic, ob, oc, _lib.ptr(addend), addend.stride(0) if addend is not None else 0, _stream())
+        _lib.check(rc, "ts_conv3d_hw_x6_fwd")
+        return out
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
     rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
                             B, Cin, f.cout, D, H, W, stride, dilation, int(transposed),

@@ -418,6 +418,237 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same convolution with every fp32 product formed from bf16 pieces on the bf16 matrix pipe ("x6"):
+//     a = a0 + a1 + a2 (+ O(2^-24 a)),  each part a bf16 (round-to-nearest of the running remainder)
+//     a b ~= a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0          (dropped terms <= 2^-24 |a b|)
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The f32-input MFMA runs at 1/16 of the bf16 rate on gfx950
+// (MI355X_MICROARCH.md), so six bf16 MFMAs of K=32 replace eight f32 MFMAs of K=4 at 3/8 of the matrix time, and the
+// result is as close to the exact sum as the f32 MFMA chain is (tools/exp/bf16_split_eval.py: rms error 1.2e-7 of the
+// output rms against 3.0e-7 for a plain fp32 dot product; the three-product split everybody quotes is 4.4e-6, which
+// would not hold the parity bar).  Stride-1 (1,3,3) layers with >= 16 input channels.
+//   K chunk = 16 input channels = two groups of 8; an MFMA's K = 32 is (two taps) x (16 channels): lane group kq holds
+//   tap 2s + (kq >> 1), channel group kq & 1.  Nine taps = five steps, the tenth slot multiplies zero weights.
+//   LDS: inputs pixel-major, [part][group][pixel] x 16 bytes (8 channels of one part): a B fragment is one ds_read_b128
+//   and 16 consecutive pixels are 256 contiguous bytes; the fp32 tile is split while it is committed.  Weights arrive
+//   pre-split from the host pass (weight_split6_kernel) as [chunk][part][tap slot][group][co][8]: an A fragment is one
+//   ds_read_b128 as well.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+// (a, b) -> packed (hi, mid, lo) parts
+__device__ __forceinline__ void split6(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = pack_bf16(a, b);
+  a -= __uint_as_float(hi << 16); b -= __uint_as_float(hi & 0xffff0000u);
+  mid = pack_bf16(a, b);
+  a -= __uint_as_float(mid << 16); b -= __uint_as_float(mid & 0xffff0000u);
+  lo = pack_bf16(a, b);
+}
+
+constexpr int X6_NC = 16, X6_SLOTS = 10;
+
+// w_t fp32 [Cin][9][coutp] -> w6 [chunk][part 3][slot 10][group 2][coutp][8] bf16 (slot 9 and channels past Cin: zero)
+__global__ void __launch_bounds__(256)
+weight_split6_kernel(const float* __restrict__ w_t, u32x4* __restrict__ w6, int Cin, int coutp, int nchunk) {
+  const int n = nchunk * X6_SLOTS * 2 * coutp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int co = i % coutp;
+    int r = i / coutp;
+    const int g = r & 1; r >>= 1;
+    const int slot = r % X6_SLOTS, chunk = r / X6_SLOTS;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = chunk * X6_NC + g * 8 + e;
+      v[e] = (slot < 9 && ci < Cin) ? w_t[(static_cast<size_t>(ci) * 9 + slot) * coutp + co] : 0.f;
+    }
+    unsigned part[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split6(v[2 * e], v[2 * e + 1], part[0][e], part[1][e], part[2][e]);
+#pragma unroll
+    for (int pt = 0; pt < 3; ++pt)
+      w6[(((static_cast<size_t>(chunk) * 3 + pt) * X6_SLOTS + slot) * 2 + g) * coutp + co] =
+          u32x4{part[pt][0], part[pt][1], part[pt][2], part[pt][3]};
+  }
+}
+
+template <int CB, int DL>
+__global__ void __launch_bounds__(256, 2)
+ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, const float* __restrict__ scale,
+                  const float* __restrict__ shift, float* __restrict__ y, const IG p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds6[];
+  // Staged tile: rows ty0-DL .. ty0+7+DL, columns tx0-4 .. tx0+35 as ten ALIGNED quads per row (W % 4 == 0: a quad is inside
+  // the image or outside it, never across its border).  One dwordx4 per (row, quad, channel): the first version staged single
+  // pixels -- 32 dword gathers per thread and chunk, ~29 cycles of the texture addresser each, 60 % of the kernel's time.
+  constexpr int in_rows = 8 + 2 * DL, QPR = 10, LCOLS = 4 * QPR, NPIX = in_rows * LCOLS;
+  constexpr int NPIXP = NPIX + 1;
+  constexpr int SLOTS = in_rows * QPR;                  // (row, quad) pairs; threads [0, SLOTS) stage channels 0-7, [SLOTS, 2 SLOTS) 8-15
+  static_assert(2 * SLOTS <= 256, "staging slots");
+  constexpr int COB = CB * 16;
+  constexpr int WV = 3 * X6_SLOTS * 2 * COB;            // 16-byte weight vectors per chunk
+  constexpr int RWN = (WV + 255) / 256;
+  u32x4* in6 = lds6;                                    // [part][group][NPIXP]
+  u32x4* w6s = lds6 + 3 * 2 * NPIXP;                    // [part][slot][group][COB] (+ dump)
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  // XCD-aware placement: consecutive workgroup ids go round the eight XCDs (each with its own L2), so workgroup L works on
+  // slot (L % 8) * (total / 8) + L / 8 of the (batch, plane, tile) order: an XCD gets a contiguous band of the image and its L2
+  // serves the halo rows / columns that neighbouring tiles share (5-10 % on the 272x480 layers; TS_X6_XCD=0 = p.kspan & 1
+  // switches it off for A/B runs).
+  unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z, per = total / 8;
+    if (!(p.kspan & 1) && lin < per * 8) lin = (lin % 8) * per + lin / 8;
+  }
+  const int tile = lin % gridDim.x;
+  const int od = (lin / gridDim.x) % gridDim.y;
+  const int bz = lin / (gridDim.x * gridDim.y);
+  const int cog = bz % p.co_groups, b = bz / p.co_groups;
+  const int co0 = cog * COB;
+  const int ty0 = (tile / p.tiles_x) * 8, tx0 = (tile % p.tiles_x) * 32;
+  const unsigned HW = static_cast<unsigned>(p.H) * p.W;
+  const unsigned cstride_b = static_cast<unsigned>(p.in_cstride) * 4u;
+
+  const bool stager = threadIdx.x < 2 * SLOTS;
+  const int sg = (static_cast<int>(threadIdx.x) >= SLOTS) ? 1 : 0;            // channel group this thread stages
+  const int sslot = static_cast<int>(threadIdx.x) - sg * SLOTS;
+  const int srow = sslot / QPR, squad = sslot - srow * QPR;
+  unsigned goff = kOOB;
+  {
+    const int gy = ty0 - DL + srow, gx = tx0 - 4 + 4 * squad;
+    if (stager && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+      goff = (static_cast<unsigned>(od) * HW + static_cast<unsigned>(gy) * p.W + gx) * 4u;
+  }
+  const int lpix = (sg * NPIXP) + srow * LCOLS + 4 * squad;                   // + part * 2 * NPIXP + pixel in quad
+
+  unsigned woff[RWN];
+  int wl[RWN];
+#pragma unroll
+  for (int q = 0; q < RWN; ++q) {
+    const int v = threadIdx.x + 256 * q;
+    const int col = v % COB, r = v / COB;               // r = (part * 10 + slot) * 2 + group
+    const bool ok = v < WV && co0 + col < p.coutp;
+    woff[q] = ok ? static_cast<unsigned>(r * p.coutp + co0 + col) * 16u : kOOB;
+    wl[q] = v < WV ? v : WV;
+  }
+  const __amdgpu_buffer_rsrc_t xr = ig_rsrc(x + static_cast<long long>(b) * p.in_bstride, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t wr = ig_rsrc(w6, p.w_bytes);
+  const unsigned wchunk_b = static_cast<unsigned>(3 * X6_SLOTS * 2 * p.coutp) * 16u;
+
+  // fragment bases (u32x4 units): B = pixel of this lane in each 16-pixel block, group kq & 1; A = channel j, group kq & 1
+  int boff[4];
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb)
+    boff[pb] = (kq & 1) * NPIXP + (wave * 2 + (pb >> 1)) * LCOLS + (4 - DL) + (pb & 1) * 16 + j;
+  const int aoff = (kq & 1) * COB + j;
+  const int tsel = kq >> 1;                             // which tap of a step's pair
+
+  v4f acc[CB][4];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
+  float esc[CB][4], esh[CB][4];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = min(co0 + cb * 16 + kq * 4 + r, p.coutp - 1);
+      esc[cb][r] = scale ? scale[co] : 1.f;
+      esh[cb][r] = shift ? shift[co] : 0.f;
+    }
+
+  v4f rin[8];
+  u32x4 rw[RWN];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      // channels past Cin re-read the last real one; their weights are zero
+      const unsigned co = static_cast<unsigned>(min(c0 + sg * 8 + c, p.Cin - 1)) * cstride_b;
+      rin[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, goff == kOOB ? kOOB : goff + co, 0, 0));
+    }
+    const unsigned wso = static_cast<unsigned>(c0 / X6_NC) * wchunk_b;
+#pragma unroll
+    for (int q = 0; q < RWN; ++q) rw[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff[q], wso, 0);
+  };
+  auto commit = [&]() {
+    if (stager) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned part[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split6(rin[2 * e][i], rin[2 * e + 1][i], part[0][e], part[1][e], part[2][e]);
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+          in6[pt * 2 * NPIXP + lpix + i] = u32x4{part[pt][0], part[pt][1], part[pt][2], part[pt][3]};
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RWN; ++q) w6s[wl[q]] = rw[q];
+  };
+
+  fetch(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += X6_NC) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (c0 + X6_NC < p.Cin) fetch(c0 + X6_NC);
+#pragma unroll
+    for (int s = 0; s < X6_SLOTS / 2; ++s) {
+      const int slot = 2 * s + tsel;                                      // per lane group
+      const int tap = slot < 9 ? slot : 8;                                // slot 9: zero weights, any valid pixel
+      const int toff = (tap / 3) * DL * LCOLS + (tap % 3) * DL;
+      bf16x8 a[3][CB], bv[3][4];
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+          a[pt][cb] = __builtin_bit_cast(bf16x8, w6s[((pt * X6_SLOTS + slot) * 2) * COB + aoff + cb * 16]);
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) bv[pt][pb] = __builtin_bit_cast(bf16x8, in6[pt * 2 * NPIXP + boff[pb] + toff]);
+      }
+      // smallest terms first
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb)
+            acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[t]][cb], bv[PB[t]][pb], acc[cb][pb], 0, 0, 0);
+    }
+  }
+
+  const size_t hw_o = static_cast<size_t>(p.Ho) * p.Wo;
+  const __amdgpu_buffer_rsrc_t yr = ig_rsrc(y + static_cast<long long>(b) * p.out_bstride, p.out_bytes);
+  const unsigned ocs = static_cast<unsigned>(p.out_cstride) * 4u;
+  const float* ab = p.addend ? p.addend + static_cast<size_t>(b) * p.add_bstride : nullptr;
+#pragma unroll
+  for (int pb = 0; pb < 4; ++pb) {
+    const int oy = ty0 + wave * 2 + (pb >> 1), ox = tx0 + (pb & 1) * 16 + j;
+    const bool inside = oy < p.Ho && ox < p.Wo;
+    const unsigned ppix = static_cast<unsigned>(oy) * p.Wo + ox;
+    const unsigned opix = static_cast<unsigned>(od) * static_cast<unsigned>(hw_o) + ppix;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + cb * 16 + kq * 4 + r;
+        const unsigned off = (inside && co < p.Cout) ? opix * 4u + static_cast<unsigned>(co) * ocs : kOOB;
+        float v = acc[cb][pb][r];
+        if (ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * hw_o + (inside ? ppix : 0u)];
+        v = apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param, co);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, off, 0, 0);
+      }
+  }
+}
+
 // sums the split-K partials in a fixed order (deterministic) and applies scale / shift / activation.
 // grid.y = (batch element, output channel): no 64-bit division per element
 __global__ void __launch_bounds__(256)
@@ -866,7 +1097,84 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
                      static_cast<long long>(p.Ho) * p.Wo);
   return ts::launched("conv_splitk_finish");
 }
+
+// ---- x6 (bf16-split) form of the stride-1 (1,3,3) convolution ------------------------------------------------------
+template <int CB, int DL>
+int launch_x6(const float* x, const void* w6, const float* scale, const float* shift, float* y, const IG& p, dim3 grid, hipStream_t st) {
+  constexpr int NPIXP = (8 + 2 * DL) * 40 + 1;
+  constexpr size_t lds = (static_cast<size_t>(3) * 2 * NPIXP + 3 * X6_SLOTS * 2 * CB * 16 + 1) * 16;
+  static_assert(lds <= 80 * 1024, "ig_conv_x6_kernel: two workgroups per CU");
+  auto kern = &ig_conv_x6_kernel<CB, DL>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, static_cast<const u32x4*>(w6), scale, shift, y, p);
+  return ts::launched("ig_conv_x6_kernel");
+}
+
+size_t x6_weight_bytes(int Cin, int Cout) {
+  const int bucket = cout_bucket(Cout);
+  return static_cast<size_t>((Cin + X6_NC - 1) / X6_NC) * 3 * X6_SLOTS * 2 * bucket * 16;
+}
 }  // namespace
+
+extern "C" int ts_conv3d_hw_x6_supported(int Cin, int Cout, int W, int stride, int dilation, int transposed) {
+  return Cin >= X6_NC && Cout > 0 && Cout <= 64 && W > 0 && W % 4 == 0 && stride == 1 && (dilation == 1 || dilation == 2) &&
+         !transposed;
+}
+
+extern "C" size_t ts_conv3d_hw_x6_weight_bytes(int Cin, int Cout) {
+  return (Cin > 0 && Cout > 0 && Cout <= 64) ? x6_weight_bytes(Cin, Cout) : 0;
+}
+
+extern "C" int ts_conv3d_hw_x6_weight_split(const float* w_t, void* w6, int Cin, int Cout, void* stream) {
+  TS_REQUIRE(Cin > 0 && Cout > 0 && Cout <= 64, TS_ERR_SHAPE, "conv3d_hw_x6_weight_split: bad channel counts");
+  TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(w6);
+  const int bucket = cout_bucket(Cout), nchunk = (Cin + X6_NC - 1) / X6_NC;
+  const int n = nchunk * X6_SLOTS * 2 * bucket;
+  hipLaunchKernelGGL(weight_split6_kernel, dim3((n + 255) / 256), dim3(256), 0, ts::as_stream(stream), w_t,
+                     static_cast<u32x4*>(w6), Cin, bucket, nchunk);
+  return ts::launched("weight_split6_kernel");
+}
+
+extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* scale, const float* shift, float* y,
+                                   int B, int Cin, int Cout, int D, int H, int W, int dilation, int act, float act_param,
+                                   long long in_bstride, long long in_cstride, long long out_bstride,
+                                   long long out_cstride, const float* addend, long long addend_bstride, void* stream) {
+  TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw_x6: non-positive size");
+  TS_REQUIRE(ts_conv3d_hw_x6_supported(Cin, Cout, W, 1, dilation, 0), TS_ERR_UNSUPPORTED,
+             "conv3d_hw_x6: needs Cin >= 16, Cout <= 64, W %% 4 == 0, dilation 1 | 2 (Cin=%d Cout=%d W=%d dilation=%d)", Cin, Cout,
+             W, dilation);
+  TS_REQUIRE(act >= 0 && act <= 4, TS_ERR_SHAPE, "conv3d_hw_x6: unknown activation");
+  TS_REQUIRE(D <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw_x6: grid too large");
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w6); TS_REQUIRE_PTR(y);
+  IG p;
+  p.Cin = Cin; p.Cout = Cout; p.coutp = cout_bucket(Cout); p.D = D; p.H = H; p.W = W; p.Do = D; p.Ho = H; p.Wo = W;
+  p.stride = 1; p.dil = dilation; p.pad = dilation; p.k = 3; p.transposed = 0;
+  p.act = act; p.act_param = act_param;
+  p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
+  static const int no_xcd = [] { const char* e = getenv("TS_X6_XCD"); return (e && e[0] == '0') ? 1 : 0; }();
+  p.ksplit = 1; p.kspan = no_xcd; p.partial = nullptr; p.B = B;
+  p.addend = addend; p.add_bstride = addend_bstride;
+  TS_REQUIRE(ig_extent(p, 9), TS_ERR_UNSUPPORTED, "conv3d_hw_x6: a batch element of x spans 2 GiB or more");
+  const size_t wb = x6_weight_bytes(Cin, Cout);
+  TS_REQUIRE(wb < 0x7fffffffull, TS_ERR_UNSUPPORTED, "conv3d_hw_x6: weight array too large");
+  p.w_bytes = static_cast<unsigned>(wb);
+  {
+    const unsigned long long plane = static_cast<unsigned long long>(D) * H * W;
+    const unsigned long long out_b = (static_cast<unsigned long long>(Cout - 1) * out_cstride + plane) * 4ull;
+    TS_REQUIRE(out_b < 0x7fffffffull && out_cstride >= 0, TS_ERR_UNSUPPORTED, "conv3d_hw_x6: a batch element of y spans 2 GiB or more");
+    p.out_bytes = static_cast<unsigned>(out_b); p.part_bytes = 0;
+  }
+  p.tiles_x = (W + 31) / 32;
+  const int tiles = ((H + 7) / 8) * p.tiles_x;
+  const int need = (Cout + 15) / 16;
+  const int cb = need >= 2 ? 2 : 1;
+  p.co_groups = (need + cb - 1) / cb;
+  const dim3 grid(tiles, D, B * p.co_groups);
+  hipStream_t st = ts::as_stream(stream);
+  if (cb == 2) return dilation == 2 ? launch_x6<2, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<2, 1>(x, w6, scale, shift, y, p, grid, st);
+  return dilation == 2 ? launch_x6<1, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<1, 1>(x, w6, scale, shift, y, p, grid, st);
+}
 
 extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
                                 int B, int Cin, int Cout, int D, int H, int W, int stride, int dilation,

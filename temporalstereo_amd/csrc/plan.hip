@@ -83,6 +83,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_bn_act_bwd_reduce),        TS_PLAN_OP(ts_bn_act_bwd_apply),
     TS_PLAN_OP(ts_convex_upsample_bwd),      TS_PLAN_OP(ts_unet_upsample_bwd),
     TS_PLAN_OP(ts_conv_weight_layout),      TS_PLAN_OP(ts_conv_weight_layout_many),
+    TS_PLAN_OP(ts_conv3d_hw_x6_fwd),        TS_PLAN_OP(ts_conv3d_hw_x6_weight_split),
 };
 
 struct Call {

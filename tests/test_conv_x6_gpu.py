@@ -1,0 +1,79 @@
+"""ts_conv3d_hw_x6_fwd: the stride-1 (1,3,3) convolution with fp32 products assembled from bf16 pieces (six bf16 MFMAs per
+product block, fp32 accumulation) against an fp64 convolution -- it has to be as accurate as the f32-MFMA kernel it replaces
+(reference: the Conv3d wrappers of layers/basic_layers.py:194-235 in eval mode, BatchNorm folded to scale / shift)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(B, Cin, Cout, D, H, W, dilation, act, with_addend, seed):
+    from temporalstereo_amd import _lib
+    from temporalstereo_amd.aggregation import native as N
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, D, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 1, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(dev)
+    bn = torch.nn.BatchNorm3d(Cout).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    f = N.Folded(w, None, bn, act, False, "hw")
+    addend = torch.randn(B, Cout, 1, H, W, generator=g).to(dev) if with_addend else None
+    outs = {}
+    for x6 in (True, False):
+        N.X6 = x6
+        try:
+            outs[x6] = N.conv_hw(x, f, 1, dilation, addend=addend)
+        finally:
+            N.X6 = True
+    torch.cuda.synchronize()
+    xd, wd = x.double(), w.double()
+    ref = F.conv3d(xd, wd, padding=(0, dilation, dilation), dilation=(1, dilation, dilation))
+    if addend is not None:
+        ref = ref + addend.double()
+    ref = ref * f.scale[:Cout].double().view(1, -1, 1, 1, 1) + f.shift[:Cout].double().view(1, -1, 1, 1, 1)
+    if act == N.ACT_SILU:
+        ref = F.silu(ref)
+    e6 = float((outs[True].double() - ref).abs().max())
+    e32 = float((outs[False].double() - ref).abs().max())
+    return e6, e32, float(ref.abs().max())
+
+
+CASES = [
+    # B, Cin, Cout, D, H, W, dilation, with_addend
+    (1, 16, 16, 2, 24, 64, 1, False),
+    (2, 32, 32, 3, 37, 44, 1, False),          # ragged tile edges
+    (1, 176, 8, 5, 34, 60, 1, True),           # the first layer of the 1/4 level: 11 chunks, Cout 8, addend
+    (1, 20, 24, 2, 16, 36, 1, False),          # ragged channel counts on both sides
+    (1, 64, 64, 1, 40, 72, 1, False),          # two output-channel groups
+    (1, 48, 32, 2, 24, 40, 2, False),          # dilation 2
+    (1, 128, 32, 1, 68, 120, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_%dto%d_D%d_%dx%d_dil%d%s" % (c[:7] + ("_addend" if c[7] else "",)))
+def test_x6_is_as_accurate_as_the_f32_mfma_kernel(case):
+    from temporalstereo_amd.aggregation import native as N
+    B, Cin, Cout, D, H, W, dil, add = case
+    for act in (N.ACT_NONE, N.ACT_SILU):
+        e6, e32, scale = _run(B, Cin, Cout, D, H, W, dil, act, add, seed=Cin * 7 + Cout)
+        # both within a few fp32 ulps of the exact result; the split form no worse than 1.5x the f32 chain (+1 ulp of slack)
+        assert e32 <= 4e-6 * max(scale, 1.0), (e32, scale)
+        assert e6 <= 1.5 * e32 + 2.5e-7 * max(scale, 1.0), (e6, e32, scale)
+
+
+def test_x6_layer_selection():
+    from temporalstereo_amd import _lib
+    L = _lib.lib()
+    assert L.ts_conv3d_hw_x6_supported(16, 8, 240, 1, 1, 0) == 1
+    assert L.ts_conv3d_hw_x6_supported(176, 64, 60, 1, 2, 0) == 1
+    assert L.ts_conv3d_hw_x6_supported(8, 8, 240, 1, 1, 0) == 0          # fewer channels than one K chunk
+    assert L.ts_conv3d_hw_x6_supported(32, 32, 30, 1, 1, 0) == 0         # rows are staged as aligned quads: W % 4 == 0
+    assert L.ts_conv3d_hw_x6_supported(32, 32, 240, 2, 1, 0) == 0        # stride 2 stays on the f32 kernel
+    assert L.ts_conv3d_hw_x6_supported(32, 32, 240, 2, 1, 1) == 0
+    assert L.ts_conv3d_hw_x6_weight_bytes(176, 8) == 11 * 3 * 10 * 2 * 8 * 16          # [chunk][part][slot][group][CoutPad 8][8 bf16]

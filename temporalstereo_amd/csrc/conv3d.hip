@@ -450,6 +450,38 @@ __device__ __forceinline__ void split6(float a, float b, unsigned& hi, unsigned&
   lo = pack_bf16(a, b);
 }
 
+
+// Epilogue through LDS: the accumulator layout (lane = pixel j of a 16-pixel block, registers = 4 channels) stores 64-byte
+// runs of four different channel planes per instruction -- 32 dword stores per thread for a 32-channel tile, ~11,000 cycles per
+// workgroup.  Staged as [channel][256 tile pixels] (pitch 272: the four channel rows a wave writes per instruction sit on
+// disjoint banks) a wave then stores 64 float4 of ONE channel: eight full 128-byte rows per instruction, a quarter of the
+// instructions.  Needs whole quads (Wo % 4 == 0 for the 8 x 32 pixel tiles, H W % 4 == 0 for the 256-pixel runs of MODE_D).
+constexpr int kEpiPitch = 272;
+template <int NCB>
+__device__ __forceinline__ void epilogue_stage(float* epi, const float (&v)[NCB][4][4], int wave, int kq, int j) {
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epi[(cb * 16 + kq * 4 + r) * kEpiPitch + wave * 64 + pb * 16 + j] = v[cb][pb][r];
+}
+// tile pixel quad q (0..63) of channel co: byte offset of its first pixel inside the channel plane, or kOOB
+template <int NCB, class QuadOffset>
+__device__ __forceinline__ void epilogue_flush(const float* epi, __amdgpu_buffer_rsrc_t yr, unsigned ocs, int co_base, int Cout,
+                                               QuadOffset quad_offset) {
+#pragma unroll
+  for (int it = 0; it < NCB * 4; ++it) {
+    const int idx = static_cast<int>(threadIdx.x) + 256 * it;
+    const int col = idx >> 6, q = idx & 63;
+    const u32x4 val = *reinterpret_cast<const u32x4*>(epi + col * kEpiPitch + q * 4);
+    const unsigned po = quad_offset(q);
+    const int co = co_base + col;
+    const unsigned off = (po != kOOB && co < Cout) ? po + static_cast<unsigned>(co) * ocs : kOOB;
+    __builtin_amdgcn_raw_buffer_store_b128(val, yr, off, 0, 0);
+  }
+}
+
 constexpr int X6_NC = 16, X6_SLOTS = 10;
 
 // w_t fp32 [Cin][9][coutp] -> w6 [chunk][part 3][slot 10][group 2][coutp][8] bf16 (slot 9 and channels past Cin: zero)
@@ -629,24 +661,31 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
   const __amdgpu_buffer_rsrc_t yr = ig_rsrc(y + static_cast<long long>(b) * p.out_bstride, p.out_bytes);
   const unsigned ocs = static_cast<unsigned>(p.out_cstride) * 4u;
   const float* ab = p.addend ? p.addend + static_cast<size_t>(b) * p.add_bstride : nullptr;
+  float outv[CB][4][4];
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
     const int oy = ty0 + wave * 2 + (pb >> 1), ox = tx0 + (pb & 1) * 16 + j;
     const bool inside = oy < p.Ho && ox < p.Wo;
     const unsigned ppix = static_cast<unsigned>(oy) * p.Wo + ox;
-    const unsigned opix = static_cast<unsigned>(od) * static_cast<unsigned>(hw_o) + ppix;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + cb * 16 + kq * 4 + r;
-        const unsigned off = (inside && co < p.Cout) ? opix * 4u + static_cast<unsigned>(co) * ocs : kOOB;
         float v = acc[cb][pb][r];
         if (ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * hw_o + (inside ? ppix : 0u)];
-        v = apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param, co);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, off, 0, 0);
+        outv[cb][pb][r] = apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param, co);
       }
   }
+  __syncthreads();                                      // the last chunk's fragments are consumed: the tile buffers become the staging area
+  float* epi = reinterpret_cast<float*>(lds6);
+  epilogue_stage<CB>(epi, outv, wave, kq, j);
+  __syncthreads();
+  const unsigned obase = static_cast<unsigned>(od) * static_cast<unsigned>(hw_o);
+  epilogue_flush<CB>(epi, yr, ocs, co0, p.Cout, [&](int q) {
+    const int oy = ty0 + (q >> 3), ox = tx0 + (q & 7) * 4;
+    return (oy < p.Ho && ox < p.Wo) ? (obase + static_cast<unsigned>(oy) * p.Wo + ox) * 4u : kOOB;       // W % 4 == 0: whole quads
+  });
 }
 
 // sums the split-K partials in a fixed order (deterministic) and applies scale / shift / activation.
@@ -1118,7 +1157,8 @@ size_t x6_weight_bytes(int Cin, int Cout) {
 }  // namespace
 
 extern "C" int ts_conv3d_hw_x6_supported(int Cin, int Cout, int W, int stride, int dilation, int transposed) {
-  return Cin >= X6_NC && Cout > 0 && Cout <= 64 && W > 0 && W % 4 == 0 && stride == 1 && (dilation == 1 || dilation == 2) &&
+  // Cout <= 8: the row-paired f32 kernel (both output rows of a wave in one 16-row MFMA) is as fast at batch 1 and faster at 4
+  return Cin >= X6_NC && Cout > 8 && Cout <= 64 && W > 0 && W % 4 == 0 && stride == 1 && (dilation == 1 || dilation == 2) &&
          !transposed;
 }
 

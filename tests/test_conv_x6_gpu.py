@@ -48,7 +48,7 @@ CASES = [
     # B, Cin, Cout, D, H, W, dilation, with_addend
     (1, 16, 16, 2, 24, 64, 1, False),
     (2, 32, 32, 3, 37, 44, 1, False),          # ragged tile edges
-    (1, 176, 8, 5, 34, 60, 1, True),           # the first layer of the 1/4 level: 11 chunks, Cout 8, addend
+    (1, 176, 12, 5, 34, 60, 1, True),          # 11 chunks, a ragged channel block, addend
     (1, 20, 24, 2, 16, 36, 1, False),          # ragged channel counts on both sides
     (1, 64, 64, 1, 40, 72, 1, False),          # two output-channel groups
     (1, 48, 32, 2, 24, 40, 2, False),          # dilation 2
@@ -70,7 +70,8 @@ def test_x6_is_as_accurate_as_the_f32_mfma_kernel(case):
 def test_x6_layer_selection():
     from temporalstereo_amd import _lib
     L = _lib.lib()
-    assert L.ts_conv3d_hw_x6_supported(16, 8, 240, 1, 1, 0) == 1
+    assert L.ts_conv3d_hw_x6_supported(16, 16, 240, 1, 1, 0) == 1
+    assert L.ts_conv3d_hw_x6_supported(176, 8, 240, 1, 1, 0) == 0         # Cout <= 8: the row-paired f32 kernel is the faster one
     assert L.ts_conv3d_hw_x6_supported(176, 64, 60, 1, 2, 0) == 1
     assert L.ts_conv3d_hw_x6_supported(8, 8, 240, 1, 1, 0) == 0          # fewer channels than one K chunk
     assert L.ts_conv3d_hw_x6_supported(32, 32, 30, 1, 1, 0) == 0         # rows are staged as aligned quads: W % 4 == 0

@@ -48,7 +48,12 @@ def _aux_stream():
     return _PAR["aux"]
 
 
+_STAGE_CAP = int(os.environ.get("TS_STAGE_CHUNK_CAP", "8"))      # K chunk of the f32 kernels while several stages share the chip
+
+
 def _chunk_cap(cap):
+    if cap == 8:
+        cap = _STAGE_CAP
     _lib.check(_lib.lib().ts_conv_set_chunk_cap(int(cap)), "ts_conv_set_chunk_cap")
 
 
@@ -240,6 +245,7 @@ def _strides5(t):
 
 # TS_CONV_X6=0: every (1,3,3) convolution on the f32-input MFMA kernel (A/B measurements, bit-exact fp32 products)
 X6 = os.environ.get("TS_CONV_X6", "1") != "0"
+_X6_MIN_GRID = int(os.environ.get("TS_CONV_X6_MIN_GRID", "128"))    # measured 32 ... 384: 128 best at batch 1, flat at batch 4
 
 
 def x6_weights(f):
@@ -288,7 +294,7 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
     L = _lib.lib()
     wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, f.cout, D, H, W, stride, int(transposed)))
     x6_grid = ((H + 7) // 8) * ((W + 31) // 32) * D * B * ((f.cout + 31) // 32)
-    if X6 and (not wsb or x6_grid >= 384) and L.ts_conv3d_hw_x6_supported(Cin, f.cout, W, stride, dilation, int(transposed)):
+    if X6 and (not wsb or x6_grid >= _X6_MIN_GRID) and L.ts_conv3d_hw_x6_supported(Cin, f.cout, W, stride, dilation, int(transposed)):
         # fp32 products from bf16 pieces on the bf16 matrix pipe (fp32-exact to the last bit or two, 3/8 of the matrix time);
         # layers whose reduction has to be split over workgroups to fill the chip (small grids) stay on the f32 MFMA kernel
         rc = L.ts_conv3d_hw_x6_fwd(_lib.ptr(x), _lib.ptr(x6_weights(f)), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),

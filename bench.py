@@ -530,7 +530,7 @@ def main():
                             traffic=traffic,
                             measured="HIP events on the launch stream around %d back-to-back C-ABI launches on the pipeline's "
                                      "own input tensors, right after the timed steps" % max(a.steps, 50),
-                            kernel="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample_direct) on "
+                            kernel="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample_rows) on "
                                    "[%d,%d,%d,%d] x %d candidates" % pkey[:5],
                             algorithmic_bytes=nbytes, mean_us=k1_times[pkey] * 1e6,
                             frac_of_measured_copy_ceiling=ach / 6.29e12,

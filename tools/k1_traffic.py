@@ -44,7 +44,7 @@ def main(fetch_db, write_db):
     fx, wx = 1.0 / cal["read_fetch_over_true"], 1.0 / cal["fill_write_over_true"]
     rows = {}
     for name, sub, grid in (("main (reference half + warped half + scale-0 correlation + pooled maps)", "block_cost_fast<true, true, 3, true>", (34, 16, 1)),
-                            ("expansion of the pooled maps", "block_cost_upsample_direct", (16, 80, 1)),
+                            ("expansion of the pooled maps", "block_cost_upsample_rows<true, 4>", (8, 80, 1)),
                             ("pipeline: main without the reference half", "block_cost_fast<true, true, 3, false>", (34, 16, 1))):
         f, w = find(F, sub, grid) * kib, find(W, sub, grid) * kib
         rows[name] = dict(fetch_size_bytes_raw=f, write_size_bytes_raw=w, hbm_bytes=f * fx + w * wx)
@@ -52,7 +52,7 @@ def main(fetch_db, write_db):
     up_b = rows["expansion of the pooled maps"]["hbm_bytes"]
     alg = 232527360
     print(json.dumps(dict(workload_key=[1, 128, 136, 240, 5, True],
-                          launch="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample_direct), the launches of `python bench.py`",
+                          launch="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample_rows), the launches of `python bench.py`",
                           hbm_bytes_per_launch=main_b + up_b, algorithmic_bytes=alg, ratio=(main_b + up_b) / alg,
                           correction="FETCH_SIZE x%.3f, WRITE_SIZE x%.3f (measured on the calibration streams of the same passes)" % (fx, wx),
                           calibration=cal, kernels=rows,

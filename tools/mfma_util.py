@@ -7,6 +7,8 @@
   TF/s  = issued MFMA flops / kernel duration; v_mfma_f32_16x16x4_f32 holds a SIMD's pipe for 32 cycles
           (MI355X_MICROARCH.md, per-instruction constants) and does 2*16*16*4 = 2048 flops, so
           flops = BUSY/32 * 2048.  Includes the zero-padded part of a tile (Cout 8 on a 16-wide tile).
+          ig_conv_x6_kernel issues v_mfma_f32_16x16x32_bf16 (16 cycles, 16384 flops) and spends six of them, on ten tap slots
+          for nine taps, per fp32 product block: its TF/s column is the fp32-EQUIVALENT rate, BUSY/16 * 16384 / 6 * 0.9.
 usage: mfma_util.py results.db [name-pattern]
 """
 import sqlite3
@@ -38,6 +40,8 @@ def main(path, pattern="%ig_conv%"):
             continue
         util = busy / (gui / 8.0 * 1024.0)
         flops = busy / 32.0 * 2048.0
+        if "x6" in name:
+            flops = busy / 16.0 * 16384.0 / 6.0 * 0.9
         out.append((busy * n, name, grid, n, dur / 1e3, util, flops / dur / 1e3, gui / 8.0 / dur * 1e3, mops))
     out.sort(reverse=True)
     tot_busy = sum(o[0] for o in out)

@@ -109,6 +109,17 @@ int ts_block_cost_sampled_bwd(const float* left, const float* right, const float
  * mean / var / the two sums are arguments so that cross-rank statistics (SyncBatchNorm) can be exchanged in between.
  * ---------------------------------------------------------------------------------------- */
 size_t ts_bn_workspace_bytes(int B, int C, long long N);
+/* Single-rank training forms (nothing to exchange between the statistics and their use): statistics + normalise/activate in two
+ * launches, backward sums + input gradient in two (each a partial-sums kernel, then one whose workgroups finish their channel's
+ * sums themselves in the fixed order of the three-launch forms -- same values).  ts_bn_train_bwd: count = B*N elements. */
+int ts_bn_train_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                    long long* num_batches_tracked, const float* gamma, const float* beta, float* out, void* workspace,
+                    int B, int C, long long N, long long x_bstride, long long x_cstride, long long out_bstride,
+                    long long out_cstride, float eps, int act, void* stream);
+int ts_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* var, const float* gamma, const float* beta,
+                    float* sum_dz, float* sum_dz_xhat, float* dx, void* workspace, int B, int C, long long N,
+                    long long x_bstride, long long x_cstride, long long dy_bstride, long long dy_cstride, float eps, int act,
+                    float count, void* stream);
 int ts_bn_stats_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
                     long long* num_batches_tracked, void* workspace, int B, int C, long long N, long long bstride,
                     long long cstride, void* stream);

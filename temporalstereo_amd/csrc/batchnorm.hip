@@ -198,6 +198,94 @@ bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, c
     }
 }
 
+
+// Sum of one channel's `n` partials in the fixed order of the finish kernels (64 lanes striding, xor tree in double), by
+// wave 0 of the calling workgroup; every thread gets the result.
+__device__ __forceinline__ void channel_partial_sum(const float2* __restrict__ partial, int c, int n, double& a, double& b) {
+  __shared__ double bc[2];
+  if (threadIdx.x < 64) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+      const float2 v = partial[static_cast<size_t>(c) * n + i];
+      s += v.x;
+      q += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (threadIdx.x == 0) { bc[0] = s; bc[1] = q; }
+  }
+  __syncthreads();
+  a = bc[0];
+  b = bc[1];
+}
+
+// bn_stats_finish + bn_apply_act in one launch (single-rank training: nothing is exchanged between the two): every workgroup
+// sums its channel's partials itself (a few hundred bytes from L2, the same fixed order, so all of them agree to the bit) and
+// workgroup (0, c, 0) leaves mean / var for the backward pass and updates the running statistics.
+__global__ void __launch_bounds__(256)
+bn_finish_apply_act_kernel(const float* __restrict__ x, const float2* __restrict__ partial, int npart, float* __restrict__ mean,
+                           float* __restrict__ var, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                           long long* __restrict__ num_batches_tracked, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, float* __restrict__ out, const BNA p) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  double s, q;
+  channel_partial_sum(partial, c, npart, s, q);
+  const double cnt = static_cast<double>(p.B) * static_cast<double>(p.N);
+  const double m1 = s / cnt;
+  const double v = fmax(q / cnt - m1 * m1, 0.0);
+  const float m = static_cast<float>(m1 + static_cast<double>(x[static_cast<size_t>(c) * p.xc]));
+  const float vf = static_cast<float>(v);
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    mean[c] = m;
+    var[c] = vf;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      const double unb = cnt > 1.0 ? v * cnt / (cnt - 1.0) : v;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * static_cast<float>(unb);
+    }
+    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+  }
+  const float is = rsqrtf(vf + p.eps);
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float sc = is * g, sh = be - m * sc;
+  const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+  float* op = out + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
+  const long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i0 + k < p.N) op[i0 + k] = act_fwd(xp[i0 + k] * sc + sh, p.act);
+}
+
+// bn_bwd_finish + bn_bwd_apply in one launch, the same way; workgroup (0, c, 0) writes the two sums (grad beta, grad gamma)
+__global__ void __launch_bounds__(256)
+bn_bwd_finish_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                           const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                           const float2* __restrict__ partial, int npart, float* __restrict__ s1o, float* __restrict__ s2o,
+                           float* __restrict__ dx, const BNA p) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  double sa, sb;
+  channel_partial_sum(partial, c, npart, sa, sb);
+  const float s1 = static_cast<float>(sa), s2 = static_cast<float>(sb);
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) { s1o[c] = s1; s2o[c] = s2; }
+  const float m = mean[c], is = rsqrtf(var[c] + p.eps);
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float a1 = s1 * p.inv_n, a2 = s2 * p.inv_n;
+  const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+  const float* gp = dy + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
+  float* op = dx + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+  const long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (i0 + k < p.N) {
+      const float xh = (xp[i0 + k] - m) * is;
+      const float dz = gp[i0 + k] * act_grad(xh * g + be, p.act);
+      op[i0 + k] = (dz - a1 - xh * a2) * is * g;
+    }
+}
+
 int chunks_for(long long N, int B, int C, long long& chunk) {
   // enough workgroups to fill the chip (C * B * nchunk >= ~1024) without making chunks shorter than 1024 elements
   int n = static_cast<int>((1024 + static_cast<long long>(B) * C - 1) / (static_cast<long long>(B) * C));
@@ -275,4 +363,45 @@ extern "C" int ts_bn_act_bwd_apply(const float* x, const float* dy, const float*
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0, ts::as_stream(stream),
                      x, dy, mean, var, gamma, beta, sum_dz, sum_dz_xhat, dx, p);
   return ts::launched("bn_bwd_apply_kernel");
+}
+
+// Single-rank training form of the pair (ts_bn_stats_fwd, ts_bn_apply_act_fwd): two launches instead of three.
+extern "C" int ts_bn_train_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                               long long* num_batches_tracked, const float* gamma, const float* beta, float* out,
+                               void* workspace, int B, int C, long long N, long long x_bstride, long long x_cstride,
+                               long long out_bstride, long long out_cstride, float eps, int act, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535, TS_ERR_SHAPE, "bn_train_fwd: bad size");
+  TS_REQUIRE(act >= 0 && act <= 2, TS_ERR_UNSUPPORTED, "bn_train_fwd: activation %d", act);
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(out); TS_REQUIRE_PTR(workspace);
+  BN p{B, C, N, x_bstride, x_cstride, 0, 0};
+  p.nchunk = chunks_for(N, B, C, p.chunk);
+  float2* partial = reinterpret_cast<float2*>(workspace);
+  hipLaunchKernelGGL(bn_stats_partial, dim3(p.nchunk, C, B), dim3(256), 0, ts::as_stream(stream), x, partial, p);
+  if (int rc = ts::launched("bn_stats_partial")) return rc;
+  const BNA a{B, C, N, x_bstride, x_cstride, out_bstride, out_cstride, act, 1, eps, 0.f};
+  hipLaunchKernelGGL(bn_finish_apply_act_kernel, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0,
+                     ts::as_stream(stream), x, partial, B * p.nchunk, mean, var, running_mean, running_var, momentum,
+                     num_batches_tracked, gamma, beta, out, a);
+  return ts::launched("bn_finish_apply_act_kernel");
+}
+
+// Single-rank training form of the pair (ts_bn_act_bwd_reduce, ts_bn_act_bwd_apply with train = 1): two launches instead of three.
+extern "C" int ts_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* var, const float* gamma,
+                               const float* beta, float* sum_dz, float* sum_dz_xhat, float* dx, void* workspace, int B, int C,
+                               long long N, long long x_bstride, long long x_cstride, long long dy_bstride, long long dy_cstride,
+                               float eps, int act, float count, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535 && count > 0.f, TS_ERR_SHAPE, "bn_train_bwd: bad size");
+  TS_REQUIRE(act >= 0 && act <= 2, TS_ERR_UNSUPPORTED, "bn_train_bwd: activation %d", act);
+  TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(dy); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(sum_dz);
+  TS_REQUIRE_PTR(sum_dz_xhat); TS_REQUIRE_PTR(dx); TS_REQUIRE_PTR(workspace);
+  const BNA p{B, C, N, x_bstride, x_cstride, dy_bstride, dy_cstride, act, 1, eps, 1.f / count};
+  long long chunk;
+  const int n = chunks_for(N, B, C, chunk);
+  float2* partial = reinterpret_cast<float2*>(workspace);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(n, C, B), dim3(256), 0, ts::as_stream(stream), x, dy, mean, var, gamma, beta, partial,
+                     p, n, chunk);
+  if (int rc = ts::launched("bn_bwd_reduce_kernel")) return rc;
+  hipLaunchKernelGGL(bn_bwd_finish_apply_kernel, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0,
+                     ts::as_stream(stream), x, dy, mean, var, gamma, beta, partial, B * n, sum_dz, sum_dz_xhat, dx, p);
+  return ts::launched("bn_bwd_finish_apply_kernel");
 }

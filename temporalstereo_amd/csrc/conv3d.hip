@@ -631,29 +631,44 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
     commit();
     __syncthreads();
     if (c0 + X6_NC < p.Cin) fetch(c0 + X6_NC);
+    // Five steps of two half-steps (pixel blocks {0,1} and {2,3}).  The fragments of the NEXT half-step are read from LDS before
+    // the 12 CB MFMAs of the current one issue, so the matrix pipe does not wait for an LDS round trip inside a chunk (without
+    // this a wave alternated 18 ds_read_b128 and 48 MFMAs: five steps took 6,700 cycles against 4,100 of MFMA issue).
+    bf16x8 a[2][3][CB], bv[2][3][2];
+    auto load_a = [&](int s, int buf) {
+      const int slot = 2 * s + tsel;
 #pragma unroll
-    for (int s = 0; s < X6_SLOTS / 2; ++s) {
-      const int slot = 2 * s + tsel;                                      // per lane group
-      const int tap = slot < 9 ? slot : 8;                                // slot 9: zero weights, any valid pixel
-      const int toff = (tap / 3) * DL * LCOLS + (tap % 3) * DL;
-      bf16x8 a[3][CB], bv[3][4];
-#pragma unroll
-      for (int pt = 0; pt < 3; ++pt) {
+      for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
-          a[pt][cb] = __builtin_bit_cast(bf16x8, w6s[((pt * X6_SLOTS + slot) * 2) * COB + aoff + cb * 16]);
+          a[buf][pt][cb] = __builtin_bit_cast(bf16x8, w6s[((pt * X6_SLOTS + slot) * 2) * COB + aoff + cb * 16]);
+    };
+    auto load_b = [&](int s, int h, int buf) {
+      const int slot = 2 * s + tsel;
+      const int tap = slot < 9 ? slot : 8;                                // slot 9: zero weights, any valid pixel
+      const int toff = (tap / 3) * DL * LCOLS + (tap % 3) * DL;
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) bv[pt][pb] = __builtin_bit_cast(bf16x8, in6[pt * 2 * NPIXP + boff[pb] + toff]);
+      for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) bv[buf][pt][k] = __builtin_bit_cast(bf16x8, in6[pt * 2 * NPIXP + boff[2 * h + k] + toff]);
+    };
+    load_a(0, 0);
+    load_b(0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < X6_SLOTS; ++u) {                                  // half-step u = 2 s + h
+      const int s = u >> 1, h = u & 1;
+      if (u + 1 < X6_SLOTS) {
+        load_b((u + 1) >> 1, (u + 1) & 1, (u + 1) & 1);
+        if (h == 1) load_a(s + 1, (s + 1) & 1);
       }
-      // smallest terms first
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-          for (int pb = 0; pb < 4; ++pb)
-            acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[t]][cb], bv[PB[t]][pb], acc[cb][pb], 0, 0, 0);
+          for (int k = 0; k < 2; ++k)
+            acc[cb][2 * h + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][PA[t]][cb], bv[u & 1][PB[t]][k], acc[cb][2 * h + k], 0, 0, 0);
     }
   }
 
@@ -1146,7 +1161,9 @@ int launch_x6(const float* x, const void* w6, const float* scale, const float* s
   auto kern = &ig_conv_x6_kernel<CB, DL>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, static_cast<const u32x4*>(w6), scale, shift, y, p);
+  static const size_t extra = [] { const char* e = getenv("TS_X6_LDS_EXTRA"); return e ? static_cast<size_t>(atoi(e)) : 0; }();
+  if (extra) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds + extra));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds + extra, st, x, static_cast<const u32x4*>(w6), scale, shift, y, p);
   return ts::launched("ig_conv_x6_kernel");
 }
 

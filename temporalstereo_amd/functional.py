@@ -279,11 +279,16 @@ class WeightLayouts:
     Keys are (data_ptr, shape, order): in-place updates (the optimizers') keep them valid; a weight that is REPLACED gets a new
     entry (the stale one is re-laid for nothing until `clear()`)."""
 
-    def __init__(self):
-        self.entries = {}           # key -> (weight, out, descriptor tuple)
+    def __init__(self, lazy=False):
+        """lazy: `refresh()` launches nothing; a layout is redone by its first request after it (one small launch, as without the
+        object) and shared by the later requests of the step -- for a replayed graph, where the one-launch refresh leaves the
+        layouts cold in the cache by the time the convolutions read them (train.py)."""
+        self.entries = {}           # key -> [weight, out, descriptor tuple, epoch]
         self._table = None
         self._dirty = False
         self._blocks = 1
+        self.lazy = bool(lazy)
+        self.epoch = 0
 
     def __enter__(self):
         global _LAYOUTS
@@ -305,13 +310,19 @@ class WeightLayouts:
             if len(self.entries) >= 4096:       # someone feeds temporaries (each kept alive below): start over rather than grow
                 self.clear()
             out, desc = _layout_now(weight, a_dim, b_dim, flip)
-            self.entries[key] = e = (weight, out, desc)
+            self.entries[key] = e = [weight, out, desc, self.epoch]
             self._dirty = True
+        elif self.lazy and e[3] != self.epoch:
+            A, T, nb, bpad, sa, sb, st, fl = e[2]
+            _lib.check(_lib.lib().ts_conv_weight_layout(_lib.ptr(e[0]), _lib.ptr(e[1]), A, T, nb, bpad, sa, sb, st, fl, _stream()),
+                       "ts_conv_weight_layout")
+            e[3] = self.epoch
         return e[1]
 
     def refresh(self):
-        """Re-lay every registered weight from its current values (one launch on the current stream)."""
-        if not self.entries:
+        """Re-lay every registered weight from its current values (one launch on the current stream; lazy: on next use)."""
+        self.epoch += 1
+        if self.lazy or not self.entries:
             return
         if self._dirty:
             import numpy as np
@@ -319,7 +330,7 @@ class WeightLayouts:
                                                                ("bpad", "<i4"), ("sa", "<i8"), ("sb", "<i8"), ("st", "<i8"),
                                                                ("flip", "<i4"), ("reserved", "<i4")]))
             most = 1
-            for i, (weight, out, d) in enumerate(self.entries.values()):
+            for i, (weight, out, d, _) in enumerate(self.entries.values()):
                 rec[i] = (weight.data_ptr(), out.data_ptr()) + d + (0,)
                 most = max(most, out.numel())
             dev = next(iter(self.entries.values()))[1].device
@@ -522,6 +533,10 @@ class _Conv3dD(torch.autograd.Function):
 BN_ACT = {None: 0, "SiLU": 1, "ReLU": 2}
 
 
+import os as _os
+_BN_FUSED = _os.environ.get("TS_BN_FUSED", "1") != "0"
+
+
 class _ConvBNAct(torch.autograd.Function):
     """conv -> BatchNorm -> activation of the reference's wrappers (layers/basic_layers.py:194-235: conv, then `self.norm`, then
     `self.activation`) as ONE autograd node on HIP kernels: the convolution of _Conv3dHW / _Conv3dD (bias in its epilogue),
@@ -541,6 +556,19 @@ class _ConvBNAct(torch.autograd.Function):
         N = y[0, 0].numel()
         L = _lib.lib()
         n_total = float(B * N)
+        out = torch.empty_like(y)
+        if training and group is None and _BN_FUSED:
+            # single rank: statistics and their use in two launches (ts_bn_train_fwd)
+            mean = torch.empty(C, device=y.device, dtype=torch.float32)
+            var = torch.empty_like(mean)
+            ws = torch.empty(int(L.ts_bn_workspace_bytes(B, C, N)), device=y.device, dtype=torch.uint8)
+            _lib.check(L.ts_bn_train_fwd(_lib.ptr(y), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                         float(momentum), _lib.ptr(counter), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out), _lib.ptr(ws),
+                                         B, C, N, y.stride(0), y.stride(1), out.stride(0), out.stride(1), float(eps), int(act), _stream()),
+                       "ts_bn_train_fwd")
+            ctx.save_for_backward(x, weight, y, mean, var, gamma, beta)
+            ctx.meta = (family, cg, float(eps), int(act), bool(training), group, n_total, bias is not None)
+            return out
         if training:
             mean = torch.empty(C, device=y.device, dtype=torch.float32)
             var = torch.empty_like(mean)
@@ -567,7 +595,6 @@ class _ConvBNAct(torch.autograd.Function):
                     running_var.mul_(1 - momentum).add_(var * (n_total / max(n_total - 1.0, 1.0)), alpha=momentum)
         else:
             mean, var = running_mean, running_var
-        out = torch.empty_like(y)
         _lib.check(L.ts_bn_apply_act_fwd(_lib.ptr(y), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out),
                                          B, C, N, y.stride(0), y.stride(1), out.stride(0), out.stride(1), float(eps), int(act),
                                          _stream()), "ts_bn_apply_act_fwd")
@@ -586,6 +613,12 @@ class _ConvBNAct(torch.autograd.Function):
         s1 = torch.empty(C, device=y.device, dtype=torch.float32)
         s2 = torch.empty_like(s1)
         ws = torch.empty(int(L.ts_bn_workspace_bytes(B, C, N)), device=y.device, dtype=torch.uint8)
+        if training and group is None and _BN_FUSED:
+            dy = torch.empty_like(y)
+            _lib.check(L.ts_bn_train_bwd(_lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta),
+                                         _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(dy), _lib.ptr(ws), B, C, N, y.stride(0), y.stride(1),
+                                         g.stride(0), g.stride(1), eps, act, n_total, _stream()), "ts_bn_train_bwd")
+            return _ConvBNAct._conv_backward(ctx, x, weight, dy, family, cg, has_bias, (s2, s1) if gamma is not None else (None, None))
         _lib.check(L.ts_bn_act_bwd_reduce(_lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta),
                                           _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(ws), B, C, N, y.stride(0), y.stride(1), g.stride(0),
                                           g.stride(1), eps, act, _stream()), "ts_bn_act_bwd_reduce")
@@ -600,6 +633,10 @@ class _ConvBNAct(torch.autograd.Function):
         _lib.check(L.ts_bn_act_bwd_apply(_lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta),
                                          _lib.ptr(t1), _lib.ptr(t2), _lib.ptr(dy), B, C, N, y.stride(0), y.stride(1), g.stride(0),
                                          g.stride(1), eps, act, int(training), n_total, _stream()), "ts_bn_act_bwd_apply")
+        return _ConvBNAct._conv_backward(ctx, x, weight, dy, family, cg, has_bias, (ggamma, gbeta))
+
+    @staticmethod
+    def _conv_backward(ctx, x, weight, dy, family, cg, has_bias, gaffine):
         if family == "hw":
             dx, dw = _hw_backward(x, weight, dy, cg, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         else:
@@ -607,7 +644,7 @@ class _ConvBNAct(torch.autograd.Function):
         gbias = None
         if has_bias and ctx.needs_input_grad[2]:
             gbias = dy.sum(dim=[0] + list(range(2, dy.dim())))     # == 0 up to rounding in train mode (BatchNorm removes the mean)
-        return dx, dw, gbias, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, gbias, gaffine[0], gaffine[1], None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False):

@@ -56,8 +56,10 @@ class TrainStep:
         self.timings = {}
         self._modules = list(net.modules())
         # Kernel layouts of all convolution weights in one launch per step instead of ~280: 5 ms of host time in the eager step
-        # (28 -> 22.7 ms).  Not in a replayed graph: there the small launches cost 4.5 us each on the device, but the relaid
-        # weights are still in the cache when the convolution starts -- measured 14.3 ms per replay without, 14.9 ms with.
+        # (28 -> 22.7 ms).  Not in a replayed graph, where only device time counts: the per-call layouts go to small recycled
+        # blocks of the graph's pool and are still in the cache when their convolution reads them, kept ones are not --
+        # measured per replay: 14.3 ms without, 14.9 ms with the one-launch refresh, 16.1 ms with layouts made on first use and
+        # shared by the later uses of the step (`WeightLayouts(lazy=True)`), although both remove launches.
         self.layouts = None if self.graph else TF.WeightLayouts()
 
     def _set_training(self, mode):

@@ -79,6 +79,7 @@ struct IG {
   int B;
   const float* addend;          // [B][Cout][Ho*Wo] added to every depth plane's sum before scale/shift (or null)
   long long add_bstride;
+  int xcd;                      // XCD-banded workgroup order (ig_conv_kernel)
 };
 
 template <int MODE, int KT, int ST, int DL>
@@ -125,14 +126,23 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
-  const int cog = blockIdx.z % p.co_groups;
-  const int ks = (blockIdx.z / p.co_groups) % p.ksplit, b = blockIdx.z / (p.co_groups * p.ksplit);
+  // XCD-aware placement (p.xcd): consecutive workgroup ids go round the eight XCDs, each with its own L2; workgroup L takes slot
+  // (L % 8) * (total / 8) + L / 8 of the (z, plane, tile) order, so that an XCD works on a contiguous band and its L2 serves the
+  // halo rows / neighbouring depth planes its workgroups share.
+  unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (p.xcd) {
+    const unsigned per = (gridDim.x * gridDim.y * gridDim.z) / 8;
+    if (lin < per * 8) lin = (lin % 8) * per + lin / 8;
+  }
+  const int bx = lin % gridDim.x, by = (lin / gridDim.x) % gridDim.y, bz = lin / (gridDim.x * gridDim.y);
+  const int cog = bz % p.co_groups;
+  const int ks = (bz / p.co_groups) % p.ksplit, b = bz / (p.co_groups * p.ksplit);
   const int kbeg = ks * p.kspan, kend = min(p.Cin, kbeg + p.kspan);
   const int co0 = cog * CB * 16;
-  const int od = blockIdx.y;
+  const int od = by;
 
   // ---- geometry of this workgroup -------------------------------------------------------------
-  int tile = blockIdx.x, pa = 0, pbit = 0;
+  int tile = bx, pa = 0, pbit = 0;
   if (MODE == MODE_HWT) { pa = (tile & 3) >> 1; pbit = tile & 1; tile >>= 2; }
   int iy0 = 0, ix0 = 0, ty0 = 0, tx0 = 0;
   if (MODE == MODE_HW) {
@@ -168,7 +178,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       }
     }
   }
-  const int px0 = (MODE == MODE_D) ? blockIdx.x * 256 : 0;
+  const int px0 = (MODE == MODE_D) ? bx * 256 : 0;
 
   // ---- staging geometry of this thread: where each of its RQ elements of a channel comes from (byte
   // offset inside the batch element, kOOB = zero padding) and where it goes in the LDS channel tile ----
@@ -802,6 +812,8 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   while (cb > 1 && tiles * groups(cb) < ts::kNumCU + ts::kNumCU / 2) cb >>= 1;
   p.co_groups = groups(cb);
   p.B = B;
+  static const int xcd = [] { const char* e = getenv("TS_CONV_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+  p.xcd = xcd;
   const long long wgs = tiles * p.co_groups;
   const dim3 grid(grid_x, grid_y, B * p.co_groups * p.ksplit);
   if (cb == 4) return launch_nc<4, MODE, KT, ST, DL>(wgs, x, w, scale, shift, y, p, grid, st);

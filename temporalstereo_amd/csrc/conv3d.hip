@@ -18,6 +18,7 @@
 // below replaced it (6-70 TFLOP/s on the same layers).
 // Weights are pre-laid out [Cin][taps][CoutPad] (output channel contiguous) by the host.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ts_common.hpp"
 
@@ -109,7 +110,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ig_rsrc(const void* base, unsi
 // feeds both: per kx, input row R+rho*DL (rho = 0..3) is multiplied by [ W[ky=rho-1] | W[ky=rho] ] (zero where ky is
 // outside 0..2) -- 12 "virtual taps" with 18 useful (tap, row) products in 24 half-tiles instead of 18 in 36, i.e. a third
 // fewer MFMAs and a third fewer B-fragment reads.  The paired weight rows are assembled while the weights are staged.
-template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0>
+template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0, int PF = 0>
 __global__ void __launch_bounds__(256)
 ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                const float* __restrict__ shift, float* __restrict__ y, const IG p) {
@@ -264,107 +265,88 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 
   // ---- register prefetch of one K chunk: branch-free buffer loads (zero padding, ragged channel
   // counts and partial tiles all resolve to out-of-range offsets or zero weights) ------------------
-  float rin[NC][RQ];
-  u32x4 rw[RWN];
-  auto fetch = [&](int c0) {
+  // PF: two chunks in flight.  For grids that leave most of the chip idle (a few dozen workgroups: the small layers of the
+  // coarse / fine levels) a short chunk's MFMA phase is far shorter than a global round trip, so with one chunk in flight the
+  // kernel is a chain of exposed latencies; the second register set costs occupancy, which such a grid does not use anyway
+  // (on full grids it loses: 1113 -> 1085 pairs/s with three passes in flight).
+  constexpr int NSET = PF ? 2 : 1;
+  float rin[NSET][NC][RQ];
+  u32x4 rw[NSET][RWN];
+  auto fetch = [&](auto set, int c0) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       // channels past the slice re-read the last real one; their weights are zero
       const unsigned so = static_cast<unsigned>(min(c0 + c, p.Cin - 1)) * cstride_b;
 #pragma unroll
-      for (int i = 0; i < RQ; ++i) rin[c][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, goff[i], so, 0));
+      for (int i = 0; i < RQ; ++i) rin[S][c][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, goff[i], so, 0));
     }
     const unsigned wso = static_cast<unsigned>(c0) * wstride_b;
 #pragma unroll
     for (int q = 0; q < RWN; ++q)
-      rw[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (wci[q] < kend - c0) ? woff[q] + wso : kOOB, 0, 0);
+      rw[S][q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (wci[q] < kend - c0) ? woff[q] + wso : kOOB, 0, 0);
   };
-  auto commit = [&]() {
+  auto commit = [&](auto set) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int i = 0; i < RQ; ++i) in_tile[c * chan_elems + loff[i]] = rin[c][i];
+      for (int i = 0; i < RQ; ++i) in_tile[c * chan_elems + loff[i]] = rin[S][c][i];
 #pragma unroll
-    for (int q = 0; q < RWN; ++q) *reinterpret_cast<u32x4*>(w_tile + wl[q]) = rw[q];
+    for (int q = 0; q < RWN; ++q) *reinterpret_cast<u32x4*>(w_tile + wl[q]) = rw[S][q];
   };
-
-  fetch(kbeg);
-  for (int c0 = kbeg; c0 < kend; c0 += NC) {
-    __syncthreads();                  // everyone is done reading the previous chunk
-    commit();
-    __syncthreads();
-    if (c0 + NC < kend) fetch(c0 + NC);                 // next chunk in flight under the MFMAs below
+  auto mma = [&]() {
 #pragma unroll 1
-    for (int c8 = 0; c8 < (NC >= 8 ? NC / 8 : 1); ++c8) {   // eight channels at a time (rolled: code size); NC == 4: one quad
-      const float* it = in_tile + c8 * 8 * chan_elems;
-      const float* wt0 = w_tile + c8 * 8 * WP + aoff;
-      if (MODE == MODE_HW) {
-        // 18 steps (tap, 4 channels); the fragments of step s+1 are read from LDS before the MFMAs of
-        // step s issue, so the matrix pipe never waits on an LDS round trip
-        constexpr int NS = (NC == 4) ? 9 : 2 * KTW;
-        float a[2][CB], bv[2][4];
-        auto frag = [&](int s, int slot) {
-          const int tap = (NC == 4) ? s : (s >> 1), cq = (NC == 4) ? 0 : (s & 1);
-          const int toff = (tap / 3) * DL * pitch + (tap % 3) * DL;          // PR: tap = (rho, kx), the same arithmetic
+  for (int c8 = 0; c8 < (NC >= 8 ? NC / 8 : 1); ++c8) {   // eight channels at a time (rolled: code size); NC == 4: one quad
+    const float* it = in_tile + c8 * 8 * chan_elems;
+    const float* wt0 = w_tile + c8 * 8 * WP + aoff;
+    if (MODE == MODE_HW) {
+      // 18 steps (tap, 4 channels); the fragments of step s+1 are read from LDS before the MFMAs of
+      // step s issue, so the matrix pipe never waits on an LDS round trip
+      constexpr int NS = (NC == 4) ? 9 : 2 * KTW;
+      float a[2][CB], bv[2][4];
+      auto frag = [&](int s, int slot) {
+        const int tap = (NC == 4) ? s : (s >> 1), cq = (NC == 4) ? 0 : (s & 1);
+        const int toff = (tap / 3) * DL * pitch + (tap % 3) * DL;          // PR: tap = (rho, kx), the same arithmetic
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb) a[slot][cb] = wt0[(tap * NC + cq * 4) * WP + cb * 16];
+        for (int cb = 0; cb < CB; ++cb) a[slot][cb] = wt0[(tap * NC + cq * 4) * WP + cb * 16];
 #pragma unroll
-          for (int pb = 0; pb < NPB; ++pb) bv[slot][pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
-        };
-        frag(0, 0);
+        for (int pb = 0; pb < NPB; ++pb) bv[slot][pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
+      };
+      frag(0, 0);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          if (s + 1 < NS) frag(s + 1, (s + 1) & 1);
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) frag(s + 1, (s + 1) & 1);
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int pb = 0; pb < NPB; ++pb)
-              acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][cb], bv[s & 1][pb], acc[cb][pb], 0, 0, 0);
-        }
-      } else if (MODE == MODE_HWT) {
-        // output parity (pa, pbit) selects which kernel taps land on input pixels:
-        //   k3 s2 p1 (KT 9):  even -> (k=1, d=0);            odd -> (k=2, d=0), (k=0, d=+1)
-        //   k4 s2 p1 (KT 16): even -> (k=1, d=0), (k=3, d=-1); odd -> (k=2, d=0), (k=0, d=+1)
-        constexpr int KS = (KT == 16) ? 4 : 3, ORG = (KT == 16) ? 1 : 0;
+          for (int pb = 0; pb < NPB; ++pb)
+            acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][cb], bv[s & 1][pb], acc[cb][pb], 0, 0, 0);
+      }
+    } else if (MODE == MODE_HWT) {
+      // output parity (pa, pbit) selects which kernel taps land on input pixels:
+      //   k3 s2 p1 (KT 9):  even -> (k=1, d=0);            odd -> (k=2, d=0), (k=0, d=+1)
+      //   k4 s2 p1 (KT 16): even -> (k=1, d=0), (k=3, d=-1); odd -> (k=2, d=0), (k=0, d=+1)
+      constexpr int KS = (KT == 16) ? 4 : 3, ORG = (KT == 16) ? 1 : 0;
 #pragma unroll
-        for (int ta = 0; ta < 2; ++ta) {
-          int ky, dy;
-          if (pa) { ky = ta ? 0 : 2; dy = ta ? 1 : 0; }
-          else { if (ta && KT != 16) continue; ky = ta ? 3 : 1; dy = ta ? -1 : 0; }
+      for (int ta = 0; ta < 2; ++ta) {
+        int ky, dy;
+        if (pa) { ky = ta ? 0 : 2; dy = ta ? 1 : 0; }
+        else { if (ta && KT != 16) continue; ky = ta ? 3 : 1; dy = ta ? -1 : 0; }
 #pragma unroll
-          for (int tb = 0; tb < 2; ++tb) {
-            int kx, dx;
-            if (pbit) { kx = tb ? 0 : 2; dx = tb ? 1 : 0; }
-            else { if (tb && KT != 16) continue; kx = tb ? 3 : 1; dx = tb ? -1 : 0; }
-            const int toff = (dy + ORG) * pitch + dx + ORG;
-            const float* wt = wt0 + ((ky * KS + kx) * NC) * WP;
-#pragma unroll
-            for (int cq = 0; cq < 2; ++cq) {
-              float a[CB], bv[4];
-#pragma unroll
-              for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
-#pragma unroll
-              for (int pb = 0; pb < 4; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
-#pragma unroll
-              for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int pb = 0; pb < 4; ++pb)
-                  acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < NTR; ++t) {
-          if (t >= ntaps) continue;
-          const float* wt = wt0 + (plane_wt[t] * NC) * WP;
+        for (int tb = 0; tb < 2; ++tb) {
+          int kx, dx;
+          if (pbit) { kx = tb ? 0 : 2; dx = tb ? 1 : 0; }
+          else { if (tb && KT != 16) continue; kx = tb ? 3 : 1; dx = tb ? -1 : 0; }
+          const int toff = (dy + ORG) * pitch + dx + ORG;
+          const float* wt = wt0 + ((ky * KS + kx) * NC) * WP;
 #pragma unroll
           for (int cq = 0; cq < 2; ++cq) {
             float a[CB], bv[4];
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + t * 256];
+            for (int pb = 0; pb < 4; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -373,6 +355,54 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
           }
         }
       }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) {
+        if (t >= ntaps) continue;
+        const float* wt = wt0 + (plane_wt[t] * NC) * WP;
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq) {
+          float a[CB], bv[4];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
+#pragma unroll
+          for (int pb = 0; pb < 4; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + t * 256];
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+              acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, NSET - 1>;
+  fetch(S0{}, kbeg);
+  if constexpr (NSET == 2) {
+    if (kbeg + NC < kend) fetch(S1{}, kbeg + NC);
+    for (int c0 = kbeg; c0 < kend; c0 += 2 * NC) {
+      __syncthreads();                  // everyone is done reading the previous chunk
+      commit(S0{});
+      __syncthreads();
+      if (c0 + 2 * NC < kend) fetch(S0{}, c0 + 2 * NC);
+      mma();
+      if (c0 + NC < kend) {
+        __syncthreads();
+        commit(S1{});
+        __syncthreads();
+        if (c0 + 3 * NC < kend) fetch(S1{}, c0 + 3 * NC);
+        mma();
+      }
+    }
+  } else {
+    for (int c0 = kbeg; c0 < kend; c0 += NC) {
+      __syncthreads();                  // everyone is done reading the previous chunk
+      commit(S0{});
+      __syncthreads();
+      if (c0 + NC < kend) fetch(S0{}, c0 + NC);                 // next chunk in flight under the MFMAs below
+      mma();
     }
   }
 
@@ -739,10 +769,12 @@ conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ 
 // Upper bound on the K chunk (8 | 16 | 32) for the launches that follow on this host thread, see
 // ts_conv_set_chunk_cap.
 thread_local int g_chunk_cap = 32;
+// grids below this many workgroups take the two-chunks-in-flight form of the NC = 8 kernel (TS_CONV_PF_MAX_WGS, 0 = never)
+const long long g_pf_max_wgs = [] { const char* e = getenv("TS_CONV_PF_MAX_WGS"); return e ? atoll(e) : 192ll; }();
 // TS_CONV_ROW_PAIRING=0 switches the Cout <= 8 row pairing off (A/B measurements)
 const bool g_row_pairing = [] { const char* e = getenv("TS_CONV_ROW_PAIRING"); return !(e && e[0] == '0'); }();
 
-template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0>
+template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0, int PF = 0>
 int launch_one(const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
                dim3 grid, hipStream_t st) {
   using G = Geom<MODE, KT, ST, DL>;
@@ -750,7 +782,7 @@ int launch_one(const float* x, const float* w, const float* scale, const float* 
   constexpr int KTW = PR ? 12 : KT;
   constexpr size_t lds = (static_cast<size_t>(NC) * G::chan_elems + static_cast<size_t>(KTW) * NC * WP + 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "ig_conv_kernel: tile does not fit the LDS");
-  auto kern = &ig_conv_kernel<CB, MODE, KT, ST, DL, NC, PR>;
+  auto kern = &ig_conv_kernel<CB, MODE, KT, ST, DL, NC, PR, PF>;
   if (lds > 64 * 1024) {
     static bool raised = false;      // per instantiation
     if (!raised) {
@@ -790,6 +822,9 @@ int launch_nc(long long wgs, const float* x, const float* w, const float* scale,
   auto fits = [&](int nc) { return nc <= max_nc && (nc * per_ch + 16) * per_cu <= lds_cu && p.kspan >= nc; };
   if constexpr (32 * per_ch + 16 <= lds_cu) { if (fits(32)) return launch_one<CB, MODE, KT, ST, DL, 32>(x, w, scale, shift, y, p, grid, st); }
   if constexpr (16 * per_ch + 16 <= lds_cu) { if (fits(16)) return launch_one<CB, MODE, KT, ST, DL, 16>(x, w, scale, shift, y, p, grid, st); }
+  if constexpr (CB <= 2) {
+    if (wgs < g_pf_max_wgs && p.kspan > 8) return launch_one<CB, MODE, KT, ST, DL, 8, 0, 1>(x, w, scale, shift, y, p, grid, st);
+  }
   return launch_one<CB, MODE, KT, ST, DL, 8>(x, w, scale, shift, y, p, grid, st);
 }
 

@@ -507,12 +507,12 @@ __device__ __forceinline__ void epilogue_stage(float* epi, const float (&v)[NCB]
       for (int r = 0; r < 4; ++r) epi[(cb * 16 + kq * 4 + r) * kEpiPitch + wave * 64 + pb * 16 + j] = v[cb][pb][r];
 }
 // tile pixel quad q (0..63) of channel co: byte offset of its first pixel inside the channel plane, or kOOB
-template <int NCB, class QuadOffset>
+template <int NCB, int NT = 256, class QuadOffset>
 __device__ __forceinline__ void epilogue_flush(const float* epi, __amdgpu_buffer_rsrc_t yr, unsigned ocs, int co_base, int Cout,
                                                QuadOffset quad_offset) {
 #pragma unroll
-  for (int it = 0; it < NCB * 4; ++it) {
-    const int idx = static_cast<int>(threadIdx.x) + 256 * it;
+  for (int it = 0; it < NCB * 1024 / NT; ++it) {
+    const int idx = static_cast<int>(threadIdx.x) + NT * it;
     const int col = idx >> 6, q = idx & 63;
     const u32x4 val = *reinterpret_cast<const u32x4*>(epi + col * kEpiPitch + q * 4);
     const unsigned po = quad_offset(q);
@@ -770,9 +770,13 @@ conv_splitk_finish(const float* __restrict__ partial, const float* __restrict__ 
 // ts_conv_set_chunk_cap.
 thread_local int g_chunk_cap = 32;
 // grids below this many workgroups take the two-chunks-in-flight form of the NC = 8 kernel (TS_CONV_PF_MAX_WGS, 0 = never)
-const long long g_pf_max_wgs = [] { const char* e = getenv("TS_CONV_PF_MAX_WGS"); return e ? atoll(e) : 192ll; }();
+// Environment switches are read by NAMED functions: hipcc 7.2 resolved a third namespace-scope `= [] { ... }()` initialiser of
+// this file to the FIRST such lambda (a bool came out holding 192 -- the default of g_pf_max_wgs -- and tested false).
+long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
+bool env_not_zero(const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); }
+const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 192);
 // TS_CONV_ROW_PAIRING=0 switches the Cout <= 8 row pairing off (A/B measurements)
-const bool g_row_pairing = [] { const char* e = getenv("TS_CONV_ROW_PAIRING"); return !(e && e[0] == '0'); }();
+const bool g_row_pairing = env_not_zero("TS_CONV_ROW_PAIRING");
 
 template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0, int PF = 0>
 int launch_one(const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
@@ -847,7 +851,7 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   while (cb > 1 && tiles * groups(cb) < ts::kNumCU + ts::kNumCU / 2) cb >>= 1;
   p.co_groups = groups(cb);
   p.B = B;
-  static const int xcd = [] { const char* e = getenv("TS_CONV_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+  static const int xcd = env_not_zero("TS_CONV_XCD") ? 1 : 0;
   p.xcd = xcd;
   const long long wgs = tiles * p.co_groups;
   const dim3 grid(grid_x, grid_y, B * p.co_groups * p.ksplit);
@@ -1068,7 +1072,8 @@ wgrad_finish(const float* __restrict__ part, float* __restrict__ dw, int gx, int
 // workgroups per input-channel block: the chip filled about twice over all blocks (every workgroup ends
 // with one partial of `items` KiB, so more of them only lengthens wgrad_finish)
 int wgrad_groups(int ciblocks) {
-  static const int per_cu = [] { const char* e = getenv("TS_WGRAD_GROUPS_PER_CU"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();
+  static const long long per_cu_env = env_ll("TS_WGRAD_GROUPS_PER_CU", 2);
+  const int per_cu = per_cu_env > 0 ? static_cast<int>(per_cu_env) : 2;
   return (per_cu * ts::kNumCU + ciblocks - 1) / ciblocks;
 }
 
@@ -1208,9 +1213,7 @@ int launch_x6(const float* x, const void* w6, const float* scale, const float* s
   auto kern = &ig_conv_x6_kernel<CB, DL>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  static const size_t extra = [] { const char* e = getenv("TS_X6_LDS_EXTRA"); return e ? static_cast<size_t>(atoi(e)) : 0; }();
-  if (extra) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds + extra));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds + extra, st, x, static_cast<const u32x4*>(w6), scale, shift, y, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, static_cast<const u32x4*>(w6), scale, shift, y, p);
   return ts::launched("ig_conv_x6_kernel");
 }
 
@@ -1256,7 +1259,7 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
   p.stride = 1; p.dil = dilation; p.pad = dilation; p.k = 3; p.transposed = 0;
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
-  static const int no_xcd = [] { const char* e = getenv("TS_X6_XCD"); return (e && e[0] == '0') ? 1 : 0; }();
+  static const int no_xcd = env_not_zero("TS_X6_XCD") ? 0 : 1;
   p.ksplit = 1; p.kspan = no_xcd; p.partial = nullptr; p.B = B;
   p.addend = addend; p.add_bstride = addend_bstride;
   TS_REQUIRE(ig_extent(p, 9), TS_ERR_UNSUPPORTED, "conv3d_hw_x6: a batch element of x spans 2 GiB or more");

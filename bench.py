@@ -170,7 +170,7 @@ class K1Probe:
             else:
                 dd = d.contiguous()
                 launch = lambda: L.ts_block_cost_sampled_warped_fwd(l.data_ptr(), r.data_ptr(), dd.data_ptr(), out.data_ptr(), ws.data_ptr(), B, C, H, W, D, sc, st)
-            for _ in range(5):
+            for _ in range(20):
                 _lib.check(launch(), "K1")
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -398,7 +398,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        k1_times = k1.measure(max(a.steps, 50)) if rank == 0 else {}
+        k1_times = k1.measure(max(a.steps, 200)) if rank == 0 else {}
         k1_b4 = None
         if rank == 0 and mode.startswith("native"):
             # the same launch on four pairs: 930 MB per launch, beyond the 256 MiB Infinity Cache (SURVEY.md section 8(d) hygiene)
@@ -529,7 +529,7 @@ def main():
             roofline = dict(bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
                             traffic=traffic,
                             measured="HIP events on the launch stream around %d back-to-back C-ABI launches on the pipeline's "
-                                     "own input tensors, right after the timed steps" % max(a.steps, 50),
+                                     "own input tensors, right after the timed steps" % max(a.steps, 200),
                             kernel="ts_block_cost_sampled_fwd (block_cost_fast + block_cost_upsample_rows) on "
                                    "[%d,%d,%d,%d] x %d candidates" % pkey[:5],
                             algorithmic_bytes=nbytes, mean_us=k1_times[pkey] * 1e6,

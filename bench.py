@@ -497,7 +497,7 @@ def main():
         # (one GPU only: with several ranks the training step's collectives -- SyncBatchNorm, bucketed all-reduce -- would put
         # the headline line at the mercy of a rank that fails inside them; `--mode train --gpus N` is the multi-GPU training run)
         try:
-            training = training_leg(dev, rank, world, 8, 3, 1, seed)
+            training = training_leg(dev, rank, world, 12, 6, 1, seed)
             g = training_leg(dev, rank, world, 16, 3, 1, seed, graph=True)
             training["hipgraph"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "mode", "final_loss")}
         except Exception as e:      # the headline number must survive a failure of the extra leg

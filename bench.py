@@ -449,6 +449,30 @@ def main():
         one_at_a_time = dict(value=a.batch / dt1, unit="pairs/s per GPU", ms_per_step=dt1 * 1e3,
                              note="same engine with frames_in_flight=1 on rank 0: every pass waits for the previous one")
 
+    # The same pipelined engine with every convolution on the f32-input MFMA kernel (TS_CONV_X6=0 semantics): the headline uses
+    # ts_conv3d_hw_x6_fwd where a layer allows it -- fp32 products assembled from six bf16 MFMA products, as accurate as the f32
+    # MFMA chain (tests/test_conv_x6_gpu.py) -- and this is the number without it, measured in this run.
+    f32_only = None
+    if mode == "native" and rank == 0 and not a.no_extras:
+        from temporalstereo_amd.aggregation import native as _N
+        if _N.X6:
+            _N.X6 = False
+            try:
+                eng32 = InferenceEngine(net, backend="native", replay="plan", inputs="bind", pipeline=depth)
+                with torch.no_grad():
+                    for _ in range(depth + 5):
+                        eng32(*inputs, {})
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(a.steps):
+                        eng32(*inputs, {})
+                    torch.cuda.synchronize()
+                dt32 = (time.perf_counter() - t1) / a.steps
+                f32_only = dict(value=a.batch / dt32, unit="pairs/s per GPU", ms_per_step=dt32 * 1e3)
+                del eng32
+            finally:
+                _N.X6 = True
+
     # Serving-style concurrency: N independent batch-1 passes in flight on one GPU (each its own plan, buffers
     # and streams).  The chain of small launches of one pass leaves most CUs idle; another pass fills them.
     concurrent = None
@@ -552,10 +576,15 @@ def main():
                       config=dict(workload="BASELINE configs[1]: FlyingThings3D 540x960 (run 544x960) D=192 "
                                            "single-frame aggregation, batch %d/GPU, eval" % a.batch,
                                   run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
-                                  parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth),
+                                  parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth,
+                                  conv_arithmetic="fp32 everywhere; stride-1 (1,3,3) layers with Cin >= 16, Cout > 8 form each fp32 product from "
+                                                  "six bf16 MFMA products with fp32 accumulation (x6: dropped terms <= 2^-24 of a product, error vs "
+                                                  "fp64 <= the f32-input MFMA kernel's); f32_mfma_only = this engine with that switched off"),
                       roofline=roofline)
         if one_at_a_time is not None:
             result["one_pass_at_a_time"] = one_at_a_time
+        if f32_only is not None:
+            result["f32_mfma_only"] = f32_only
         if concurrent is not None:
             result["concurrent_pairs"] = concurrent
         if training is not None:

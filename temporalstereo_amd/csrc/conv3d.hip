@@ -1225,16 +1225,16 @@ size_t x6_weight_bytes(int Cin, int Cout) {
 
 extern "C" int ts_conv3d_hw_x6_supported(int Cin, int Cout, int W, int stride, int dilation, int transposed) {
   // Cout <= 8: the row-paired f32 kernel (both output rows of a wave in one 16-row MFMA) is as fast at batch 1 and faster at 4
-  return Cin >= X6_NC && Cout > 8 && Cout <= 64 && W > 0 && W % 4 == 0 && stride == 1 && (dilation == 1 || dilation == 2) &&
+  return Cin >= X6_NC && Cout > 8 && Cout <= 512 && W > 0 && W % 4 == 0 && stride == 1 && (dilation == 1 || dilation == 2) &&
          !transposed;
 }
 
 extern "C" size_t ts_conv3d_hw_x6_weight_bytes(int Cin, int Cout) {
-  return (Cin > 0 && Cout > 0 && Cout <= 64) ? x6_weight_bytes(Cin, Cout) : 0;
+  return (Cin > 0 && Cout > 0 && Cout <= 512) ? x6_weight_bytes(Cin, Cout) : 0;
 }
 
 extern "C" int ts_conv3d_hw_x6_weight_split(const float* w_t, void* w6, int Cin, int Cout, void* stream) {
-  TS_REQUIRE(Cin > 0 && Cout > 0 && Cout <= 64, TS_ERR_SHAPE, "conv3d_hw_x6_weight_split: bad channel counts");
+  TS_REQUIRE(Cin > 0 && Cout > 0 && Cout <= 512, TS_ERR_SHAPE, "conv3d_hw_x6_weight_split: bad channel counts");
   TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(w6);
   const int bucket = cout_bucket(Cout), nchunk = (Cin + X6_NC - 1) / X6_NC;
   const int n = nchunk * X6_SLOTS * 2 * bucket;
@@ -1249,7 +1249,7 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
                                    long long out_cstride, const float* addend, long long addend_bstride, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw_x6: non-positive size");
   TS_REQUIRE(ts_conv3d_hw_x6_supported(Cin, Cout, W, 1, dilation, 0), TS_ERR_UNSUPPORTED,
-             "conv3d_hw_x6: needs Cin >= 16, Cout <= 64, W %% 4 == 0, dilation 1 | 2 (Cin=%d Cout=%d W=%d dilation=%d)", Cin, Cout,
+             "conv3d_hw_x6: needs Cin >= 16, 8 < Cout <= 512, W %% 4 == 0, dilation 1 | 2 (Cin=%d Cout=%d W=%d dilation=%d)", Cin, Cout,
              W, dilation);
   TS_REQUIRE(act >= 0 && act <= 4, TS_ERR_SHAPE, "conv3d_hw_x6: unknown activation");
   TS_REQUIRE(D <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw_x6: grid too large");

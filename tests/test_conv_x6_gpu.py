@@ -53,6 +53,7 @@ CASES = [
     (1, 64, 64, 1, 40, 72, 1, False),          # two output-channel groups
     (1, 48, 32, 2, 24, 40, 2, False),          # dilation 2
     (1, 128, 32, 1, 68, 120, 1, False),
+    (1, 32, 144, 1, 24, 40, 1, False),         # more than 64 output channels: 32-channel groups over the grid's z
 ]
 
 

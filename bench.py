@@ -374,11 +374,19 @@ def main():
     depth = a.frames_in_flight if mode == "native" else 1
     runner = InferenceEngine(net, backend=mode.split("-")[0], replay=replay, inputs="bind", pipeline=depth)
 
+    # N-buffered producer: with N passes in flight the (out-of-scope) backbone writes frame k's features into buffer set k mod N
+    # while the passes on the other sets are still running -- every pipeline slot is bound to its OWN input tensors (set 0 =
+    # `inputs`, the one the parity check and the K1 probe look at; the others hold different frames)
+    input_sets = [inputs] + [make_inputs(dev, seed + rank + 7919 * i, a.batch) for i in range(1, depth)]
+    calls = [0]
+
     def step():
+        ins = input_sets[calls[0] % depth]
+        calls[0] += 1
         with torch.no_grad():
             if runner is not None:
-                return runner(*inputs, {})
-            return net(*inputs, {})
+                return runner(*ins, {})
+            return net(*ins, {})
 
     with K1Probe() as k1:
         for _ in range(depth):  # set-up, not benchmark steps: record the launch plan of every buffer set / capture the graph
@@ -398,6 +406,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        while calls[0] % depth != 0:     # (not timed) `out` below = the pass on buffer set 0, the frame the oracle is run on
+            step()
+        out = step()
+        torch.cuda.synchronize()
         k1_times = k1.measure(max(a.steps, 200)) if rank == 0 else {}
         k1_b4 = None
         if rank == 0 and mode.startswith("native"):
@@ -576,7 +588,7 @@ def main():
                       config=dict(workload="BASELINE configs[1]: FlyingThings3D 540x960 (run 544x960) D=192 "
                                            "single-frame aggregation, batch %d/GPU, eval" % a.batch,
                                   run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
-                                  parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth,
+                                  parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth, input_buffer_sets=depth,
                                   conv_arithmetic="fp32 everywhere; stride-1 (1,3,3) layers with Cin >= 16, Cout > 8 form each fp32 product from "
                                                   "six bf16 MFMA products with fp32 accumulation (x6: dropped terms <= 2^-24 of a product, error vs "
                                                   "fp64 <= the f32-input MFMA kernel's); f32_mfma_only = this engine with that switched off"),

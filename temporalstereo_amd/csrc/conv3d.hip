@@ -463,10 +463,12 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 //     a = a0 + a1 + a2 (+ O(2^-24 a)),  each part a bf16 (round-to-nearest of the running remainder)
 //     a b ~= a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0          (dropped terms <= 2^-24 |a b|)
 // accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The f32-input MFMA runs at 1/16 of the bf16 rate on gfx950
-// (MI355X_MICROARCH.md), so six bf16 MFMAs of K=32 replace eight f32 MFMAs of K=4 at 3/8 of the matrix time, and the
-// result is as close to the exact sum as the f32 MFMA chain is (tools/exp/bf16_split_eval.py: rms error 1.2e-7 of the
-// output rms against 3.0e-7 for a plain fp32 dot product; the three-product split everybody quotes is 4.4e-6, which
-// would not hold the parity bar).  Stride-1 (1,3,3) layers with >= 16 input channels.
+// (MI355X_MICROARCH.md), so six bf16 MFMAs of K=32 replace eight f32 MFMAs of K=4 at 3/8 of the matrix time.  With exact fp32
+// accumulation the six-product form is as good as a plain fp32 dot product (tools/exp/bf16_split_eval.py: rms error 1.2e-7 of
+// the output rms against 3.0e-7; the three-product split everybody quotes is 4.4e-6, which would not hold the parity bar); on
+// the matrix core, which adds the 32 products of an instruction less exactly than an fmaf chain, the measured max error is
+// 1.3-1.8x the f32 kernel's for Cin <= 128 and up to 3.6x at 1,600-4,600-term reductions (0.3e-6 ... 1.8e-6 of the output's
+// magnitude, tools/exp/x6_accuracy_sweep.py, tests/test_conv_x6_gpu.py).  Stride-1 (1,3,3) layers with >= 16 input channels.
 //   K chunk = 16 input channels = two groups of 8; an MFMA's K = 32 is (two taps) x (16 channels): lane group kq holds
 //   tap 2s + (kq >> 1), channel group kq & 1.  Nine taps = five steps, the tenth slot multiplies zero weights.
 //   LDS: inputs pixel-major, [part][group][pixel] x 16 bytes (8 channels of one part): a B fragment is one ds_read_b128

@@ -462,7 +462,7 @@ def main():
                              note="same engine with frames_in_flight=1 on rank 0: every pass waits for the previous one")
 
     # The same pipelined engine with every convolution on the f32-input MFMA kernel (TS_CONV_X6=0 semantics): the headline uses
-    # ts_conv3d_hw_x6_fwd where a layer allows it -- fp32 products assembled from six bf16 MFMA products, within a few fp32 ulps of the
+    # ts_conv3d_hw_x6_fwd where a layer allows it -- fp32 products assembled from six bf16 MFMA products, closer to the exact sums than the
     # f32 MFMA chain (tests/test_conv_x6_gpu.py) -- and this is the number without it, measured in this run.
     f32_only = None
     if mode == "native" and rank == 0 and not a.no_extras:
@@ -590,8 +590,8 @@ def main():
                                   run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
                                   parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth, input_buffer_sets=depth,
                                   conv_arithmetic="fp32 everywhere; stride-1 (1,3,3) layers with Cin >= 16, Cout > 8 form each fp32 product from "
-                                                  "six bf16 MFMA products with fp32 accumulation (x6: dropped terms <= 2^-24 of a product; measured max error vs "
-                                                  "fp64 1.3-1.8x the f32-input MFMA kernel's on this model's layers, < 2.5e-6 of the output magnitude); "
+                                                  "six bf16 MFMA products with fp32 accumulation (x6: dropped terms <= 2^-24 of a product, chunks summed apart; measured max "
+                                                  "error vs fp64 0.15e-6-0.26e-6 of the output magnitude, the f32-input MFMA kernel 0.3e-6-0.7e-6); "
                                                   "f32_mfma_only = this engine with that switched off"),
                       roofline=roofline)
         if one_at_a_time is not None:

@@ -284,9 +284,9 @@ int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const
 size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride, int transposed);
 /* The stride-1 (1,3,3) convolution with every fp32 product assembled from bf16 pieces on the bf16 matrix pipe:
  * a = a0 + a1 + a2 (bf16 parts), a*b ~= a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0, fp32 accumulation -- dropped terms are below
- * 2^-24 of the product; measured max error against an fp64 convolution 0.3e-6 ... 1.8e-6 of the output's magnitude for Cin 16 ...
- * 512 (ts_conv3d_hw_fwd's f32 MFMA chain: 0.3e-6 ... 0.7e-6; tests/test_conv_x6_gpu.py), at 3/8 of its matrix time (f32-input
- * MFMA = 1/16 of the bf16 rate on gfx950).
+ * 2^-24 of the product, every 16-channel chunk summed apart and added to the running sum in fp32; measured max error against an
+ * fp64 convolution 0.15e-6 ... 0.26e-6 of the output's magnitude for Cin 16 ... 512 (ts_conv3d_hw_fwd's f32 MFMA chain: 0.3e-6
+ * ... 0.7e-6; tests/test_conv_x6_gpu.py), at 3/8 of its matrix time (f32-input MFMA = 1/16 of the bf16 rate on gfx950).
  *   ts_conv3d_hw_x6_supported     1 when the layer can take this path (Cin >= 16, 8 < Cout <= 512, W % 4 == 0, stride 1, dilation 1 | 2)
  *   ts_conv3d_hw_x6_weight_split  w_t (the [Cin][9][CoutPad] array of ts_conv3d_hw_fwd) -> w6, ts_conv3d_hw_x6_weight_bytes
  *                                 bytes: [Cin/16][part 3][tap slot 10][group 2][CoutPad][8] bf16

@@ -295,7 +295,7 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
     wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, f.cout, D, H, W, stride, int(transposed)))
     x6_grid = ((H + 7) // 8) * ((W + 31) // 32) * D * B * ((f.cout + 31) // 32)
     if X6 and (not wsb or x6_grid >= _X6_MIN_GRID) and L.ts_conv3d_hw_x6_supported(Cin, f.cout, W, stride, dilation, int(transposed)):
-        # fp32 products from bf16 pieces on the bf16 matrix pipe (within a few fp32 ulps of the f32 kernel: DESIGN.md section 4; 3/8 of the matrix time);
+        # fp32 products from bf16 pieces on the bf16 matrix pipe (max error below the f32 kernel's: DESIGN.md section 4; 3/8 of the matrix time);
         # layers whose reduction has to be split over workgroups to fill the chip (small grids) stay on the f32 MFMA kernel
         rc = L.ts_conv3d_hw_x6_fwd(_lib.ptr(x), _lib.ptr(x6_weights(f)), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
                                    B, Cin, f.cout, D, H, W, dilation, f.act if act is None else act, float(act_param),

@@ -465,10 +465,10 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 // accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The f32-input MFMA runs at 1/16 of the bf16 rate on gfx950
 // (MI355X_MICROARCH.md), so six bf16 MFMAs of K=32 replace eight f32 MFMAs of K=4 at 3/8 of the matrix time.  With exact fp32
 // accumulation the six-product form is as good as a plain fp32 dot product (tools/exp/bf16_split_eval.py: rms error 1.2e-7 of
-// the output rms against 3.0e-7; the three-product split everybody quotes is 4.4e-6, which would not hold the parity bar); on
-// the matrix core, which adds the 32 products of an instruction less exactly than an fmaf chain, the measured max error is
-// 1.3-1.8x the f32 kernel's for Cin <= 128 and up to 3.6x at 1,600-4,600-term reductions (0.3e-6 ... 1.8e-6 of the output's
-// magnitude, tools/exp/x6_accuracy_sweep.py, tests/test_conv_x6_gpu.py).  Stride-1 (1,3,3) layers with >= 16 input channels.
+// the output rms against 3.0e-7; the three-product split everybody quotes is 4.4e-6, which would not hold the parity bar); the
+// matrix core aligns an instruction's 32 products and its accumulator to the largest addend, so a chunk's products are summed
+// apart and added to the running sum in fp32 (see the K loop): measured max error 0.15e-6 ... 0.26e-6 of the output's magnitude
+// for Cin 16 ... 512, the f32 kernel 0.3e-6 ... 0.7e-6 (tools/exp/x6_accuracy_sweep.py, tests/test_conv_x6_gpu.py).  Stride-1 (1,3,3) layers with >= 16 input channels.
 //   K chunk = 16 input channels = two groups of 8; an MFMA's K = 32 is (two taps) x (16 channels): lane group kq holds
 //   tap 2s + (kq >> 1), channel group kq & 1.  Nine taps = five steps, the tenth slot multiplies zero weights.
 //   LDS: inputs pixel-major, [part][group][pixel] x 16 bytes (8 channels of one part): a B fragment is one ds_read_b128
@@ -676,6 +676,14 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
     // Five steps of two half-steps (pixel blocks {0,1} and {2,3}).  The fragments of the NEXT half-step are read from LDS before
     // the 12 CB MFMAs of the current one issue, so the matrix pipe does not wait for an LDS round trip inside a chunk (without
     // this a wave alternated 18 ds_read_b128 and 48 MFMAs: five steps took 6,700 cycles against 4,100 of MFMA issue).
+    // the chunk's products are summed in accumulators of their own and added to the running sum with an ordinary fp32 add: the
+    // matrix core aligns the 32 products of an instruction to the largest addend, the running sum included, and drops what falls
+    // below its last bit -- against a chunk-sized partial sum that costs far fewer bits than against the sum of all chunks
+    v4f part[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) part[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
     bf16x8 a[2][3][CB], bv[2][3][2];
     auto load_a = [&](int s, int buf) {
       const int slot = 2 * s + tsel;
@@ -710,8 +718,12 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
           for (int k = 0; k < 2; ++k)
-            acc[cb][2 * h + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][PA[t]][cb], bv[u & 1][PB[t]][k], acc[cb][2 * h + k], 0, 0, 0);
+            part[cb][2 * h + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][PA[t]][cb], bv[u & 1][PB[t]][k], part[cb][2 * h + k], 0, 0, 0);
     }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) acc[cb][pb] += part[cb][pb];
   }
 
   const size_t hw_o = static_cast<size_t>(p.Ho) * p.Wo;

@@ -1,9 +1,10 @@
 """ts_conv3d_hw_x6_fwd: the stride-1 (1,3,3) convolution with fp32 products assembled from bf16 pieces (six bf16 MFMAs per
-product block, fp32 accumulation) against an fp64 convolution, next to the f32-MFMA kernel it replaces (reference: the Conv3d
-wrappers of layers/basic_layers.py:194-235 in eval mode, BatchNorm folded to scale / shift).  Measured (tools/exp/
-x6_accuracy_sweep.py): max error / max |output| 0.3e-6 ... 1.8e-6 for Cin 16 ... 512, the f32 kernel 0.3e-6 ... 0.7e-6 -- up to
-3.6x the f32 chain's at reductions of 1,600 terms and more (the matrix core adds the 32 products of one bf16 instruction with
-less than fp32's exact rounding), 1.3-1.8x for Cin <= 128, the widest layers of the model."""
+product block, a chunk's products summed apart and added to the running sum in fp32) against an fp64 convolution, next to the
+f32-MFMA kernel it replaces (reference: the Conv3d wrappers of layers/basic_layers.py:194-235 in eval mode, BatchNorm folded to
+scale / shift).  Measured (tools/exp/x6_accuracy_sweep.py): max error / max |output| 0.15e-6 ... 0.26e-6 for Cin 16 ... 512, the
+f32 kernel 0.3e-6 ... 0.7e-6 -- the split form is the more accurate of the two at every reduction length.  (Accumulating all
+chunks inside the matrix core's accumulator instead was up to 3.6x WORSE than the f32 chain at 1,600+ terms: the core aligns an
+instruction's 32 products to the largest addend, the accumulator included.)"""
 import numpy as np
 import pytest
 import torch
@@ -64,7 +65,7 @@ CASES = [
     (1, 48, 32, 2, 24, 40, 2, False),          # dilation 2
     (1, 128, 32, 1, 68, 120, 1, False),
     (1, 32, 144, 1, 24, 40, 1, False),         # more than 64 output channels: 32-channel groups over the grid's z
-    (1, 512, 16, 1, 32, 64, 1, False),         # 4,608-term reductions: the error of the split form is largest here
+    (1, 512, 16, 1, 32, 64, 1, False),         # 4,608-term reductions
 ]
 
 
@@ -74,11 +75,11 @@ def test_x6_is_as_accurate_as_the_f32_mfma_kernel(case):
     B, Cin, Cout, D, H, W, dil, add = case
     for act in (N.ACT_NONE, N.ACT_SILU):
         e6, e32, scale = _run(B, Cin, Cout, D, H, W, dil, act, add, seed=Cin * 7 + Cout)
-        # both within a few fp32 ulps of the exact result: the f32 chain within 1e-6 of the output's magnitude, the split form
-        # within 2.5e-6 of it and no worse than 4x the f32 chain (+1 ulp of slack)
+        # both within a few fp32 ulps of the exact result; the split form within 1e-6 of the output's magnitude and no worse than
+        # the f32 chain (+1 ulp of slack)
         assert e32 <= 4e-6 * max(scale, 1.0), (e32, scale)
-        assert e6 <= 2.5e-6 * max(scale, 1.0), (e6, scale)
-        assert e6 <= 4.0 * e32 + 2.5e-7 * max(scale, 1.0), (e6, e32, scale)
+        assert e6 <= 1e-6 * max(scale, 1.0), (e6, scale)
+        assert e6 <= 1.0 * e32 + 2.5e-7 * max(scale, 1.0), (e6, e32, scale)
 
 
 def test_x6_layer_selection():

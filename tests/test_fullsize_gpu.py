@@ -188,8 +188,8 @@ def test_every_stage_and_level_teacher_forced_at_stated_batch(name):
         rep.dump("parity_stagewise.json")
 
 
-# seeds per configuration: 8 on the headline configuration, 13 sequences in all (each frame also runs the fp64 oracle)
-_SEEDS = dict(zip(PT.CONFIGS, (8, 2, 1, 2)))
+# seeds per configuration: 8 on the headline configuration, 15 sequences in all (each frame also runs the fp64 oracle)
+_SEEDS = dict(zip(PT.CONFIGS, (8, 3, 1, 3)))       # (a median over two seeds is their maximum: three at least where there is more than one)
 
 
 @pytest.mark.parametrize("name", list(PT.CONFIGS))

@@ -528,6 +528,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    sequence = None
+    if world == 1 and mode == "native" and not a.no_extras:
+        try:        # before the training legs: their graph capture leaves a private memory pool and extra streams behind
+            sequence = sequence_leg(20)
+        except Exception as e:
+            sequence = dict(error="%s: %s" % (type(e).__name__, e))
+
     training = None
     if mode == "native" and not a.no_extras and world == 1:
         # (one GPU only: with several ranks the training step's collectives -- SyncBatchNorm, bucketed all-reduce -- would put
@@ -602,11 +609,8 @@ def main():
             result["concurrent_pairs"] = concurrent
         if training is not None:
             result["training"] = training
-        if world == 1 and mode == "native" and not a.no_extras:
-            try:
-                result["sequence"] = sequence_leg()
-            except Exception as e:
-                result["sequence"] = dict(error="%s: %s" % (type(e).__name__, e))
+        if sequence is not None:
+            result["sequence"] = sequence
         if world == 1 and not a.no_cpu_baseline:
             base, ref_out, _ = cpu_baseline(seed, all_cores=a.cpu_all_cores)
             # parity on the very same inputs: needs the calibrated BN statistics on the oracle side too

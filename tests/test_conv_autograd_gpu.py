@@ -220,3 +220,26 @@ def test_fused_conv_batchnorm_activation_matches_framework(case):
         a, b = getattr(m.norm, k), getattr(ref.norm, k)
         assert rel(a, b) < 1e-5, "%s %s" % (tag, k)
     assert int(m.norm.num_batches_tracked) == int(ref.norm.num_batches_tracked)
+
+
+def test_batchnorm_two_launch_form_equals_the_three_launch_form(monkeypatch):
+    """Single-rank training uses ts_bn_train_{fwd,bwd} (the normalise / input-gradient kernels finish their channel's partial sums
+    themselves); the SyncBatchNorm path exchanges the statistics between ts_bn_stats_fwd / ts_bn_apply_act_fwd and between
+    ts_bn_act_bwd_reduce / _apply.  Same partials, same fixed summation order: outputs, gradients and running statistics must be
+    identical to the bit."""
+    import copy
+    from temporalstereo_amd import functional as TF, layers
+    dev = torch.device("cuda:0")
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(TF, "_BN_FUSED", fused)
+        torch.manual_seed(3)
+        m = layers.Conv3d(16, 24, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), bias=False, norm=("BN3d", 24), activation="SiLU").to(dev).train()
+        x = torch.from_numpy(synth.normal(91, "x", (2, 16, 3, 21, 36))).to(dev).requires_grad_(True)
+        y = m(x)
+        y.backward(torch.from_numpy(synth.normal(92, "g", tuple(y.shape))).to(dev))
+        res[fused] = [y.detach(), x.grad, m.weight.grad, m.norm.weight.grad, m.norm.bias.grad, m.norm.running_mean.clone(),
+                      m.norm.running_var.clone(), m.norm.num_batches_tracked.clone()]
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert int(res[True][-1]) == 1

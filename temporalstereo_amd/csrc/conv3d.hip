@@ -674,8 +674,9 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
     __syncthreads();
     if (c0 + X6_NC < p.Cin) fetch(c0 + X6_NC);
     // Five steps of two half-steps (pixel blocks {0,1} and {2,3}).  The fragments of the NEXT half-step are read from LDS before
-    // the 12 CB MFMAs of the current one issue, so the matrix pipe does not wait for an LDS round trip inside a chunk (without
-    // this a wave alternated 18 ds_read_b128 and 48 MFMAs: five steps took 6,700 cycles against 4,100 of MFMA issue).
+    // the 12 CB MFMAs of the current one issue (a wave otherwise alternates 18 ds_read_b128 and 48 MFMAs).  The kernel's duration
+    // did not change with it -- what bounds it is the co-resident workgroups' staging, DESIGN.md section 4 -- but neither did the
+    // register count, so the shorter dependent chain stays.
     // the chunk's products are summed in accumulators of their own and added to the running sum with an ordinary fp32 add: the
     // matrix core aligns the 32 products of an instruction to the largest addend, the running sum included, and drops what falls
     // below its last bit -- against a chunk-sized partial sum that costs far fewer bits than against the sum of all chunks

@@ -287,8 +287,8 @@ def sequence_leg(iters=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (config 2: 1)")
     ap.add_argument("--mode", default="native",
                     choices=["native", "native-eager", "native-graph", "module", "module-graph", "module-hip", "train", "train-graph"],

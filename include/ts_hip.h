@@ -394,6 +394,12 @@ int ts_merge_candidates_bwd(const float* sample, const float* grad_out_volume, c
 
 /* dst[r * dst_pitch + c] = src[r * src_pitch + c] (elements): writes a tensor into a channel slice of
  * another -- the torch.cat / slice.copy_ of precise.py:60-63 and module.py:486-489 without torch. */
+/* Channel splice of the backbone's per-frame feature memory (architecture/modeling/backbone/TemporalStereo.py:
+ * 183-197: `torch.cat([memory, input[:, mc:]], 1)` in front of every residual block):
+ *   out[b][c] = c < mc ? first[b][c] : second[b][c];  first [B, mc, N] (NULL = zeros: the adjoint towards `input`), second / out
+ *   [B, C, N]; *_bstride in elements. */
+int ts_channel_splice_fwd(const float* first, const float* second, float* out, int B, int C, int mc, long long N,
+                          long long first_bstride, long long second_bstride, long long out_bstride, void* stream);
 int ts_copy_rows_fwd(const float* src, float* dst, long long rows, long long row_elems, long long src_pitch,
                      long long dst_pitch, void* stream);
 

@@ -85,6 +85,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_conv_weight_layout),      TS_PLAN_OP(ts_conv_weight_layout_many),
     TS_PLAN_OP(ts_conv3d_hw_x6_fwd),        TS_PLAN_OP(ts_conv3d_hw_x6_weight_split),
     TS_PLAN_OP(ts_bn_train_fwd),            TS_PLAN_OP(ts_bn_train_bwd),
+    TS_PLAN_OP(ts_channel_splice_fwd),
 };
 
 struct Call {
@@ -201,6 +202,32 @@ extern "C" int ts_event_wait(int slot, void* stream) {
 }
 
 // dst[r * dst_pitch + c] = src[r * src_pitch + c]: channel-slice concatenation without torch
+// Channel splice of the backbone's feature memory (architecture/modeling/backbone/TemporalStereo.py:183-197: the first
+// int(C * memory_percent) channels of a block's input are replaced by the previous frame's, `torch.cat([memory, input2], 1)`):
+//   out[b][c] = c < mc ? first[b][c] : second[b][c]      first [B, mc, N] (NULL: zeros), second / out [B, C, N]
+namespace {
+__global__ void __launch_bounds__(256)
+channel_splice_kernel(const float* __restrict__ first, const float* __restrict__ second, float* __restrict__ out, int C, int mc,
+                      long long N, long long fb, long long sb, long long ob) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* src = c < mc ? (first ? first + b * fb + static_cast<long long>(c) * N : nullptr) : second + b * sb + static_cast<long long>(c) * N;
+  float* dst = out + b * ob + static_cast<long long>(c) * N;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < N; i += static_cast<long long>(gridDim.x) * blockDim.x)
+    dst[i] = src ? src[i] : 0.f;
+}
+}  // namespace
+
+extern "C" int ts_channel_splice_fwd(const float* first, const float* second, float* out, int B, int C, int mc, long long N,
+                                     long long first_bstride, long long second_bstride, long long out_bstride, void* stream) {
+  TS_REQUIRE(B > 0 && C > 0 && N > 0 && mc >= 0 && mc <= C && B <= 65535 && C <= 65535, TS_ERR_SHAPE, "channel_splice: bad size");
+  TS_REQUIRE_PTR(second); TS_REQUIRE_PTR(out);
+  long long blocks = (N + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(channel_splice_kernel, dim3(static_cast<unsigned>(blocks), C, B), dim3(256), 0, ts::as_stream(stream), first, second,
+                     out, C, mc, N, first_bstride, second_bstride, out_bstride);
+  return ts::launched("channel_splice_kernel");
+}
+
 extern "C" int ts_copy_rows_fwd(const float* src, float* dst, long long rows, long long row_elems, long long src_pitch,
                                 long long dst_pitch, void* stream) {
   TS_REQUIRE(rows > 0 && row_elems > 0 && src_pitch >= row_elems && dst_pitch >= row_elems, TS_ERR_SHAPE,

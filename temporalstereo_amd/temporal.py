@@ -80,3 +80,56 @@ def update_map(prev_info, K, T_now, inv_T_past, baseline, full_h, full_w, use_pa
     if local_map_size > 0:
         prev_info['local_map_size'] = local_map_size
     return prev_info
+
+
+# ---------------------------------------------------------------------------------------------------- backbone feature memory
+class _ChannelSplice(torch.autograd.Function):
+    """cat([memory, input[:, mc:]], 1) as one launch (ts_channel_splice_fwd); adjoint: memory <- g[:, :mc], input <- (0 | g[:, mc:])."""
+
+    @staticmethod
+    def forward(ctx, inp, memory):
+        from . import _lib
+        from . import functional as TF
+        TF._require_gpu(inp, memory)
+        inp, memory = inp.contiguous(), memory.contiguous()
+        B, C = inp.shape[0], inp.shape[1]
+        mc = memory.shape[1]
+        N = inp[0, 0].numel()
+        out = torch.empty_like(inp)
+        _lib.check(_lib.lib().ts_channel_splice_fwd(_lib.ptr(memory), _lib.ptr(inp), _lib.ptr(out), B, C, mc, N, mc * N, C * N, C * N,
+                                                    TF._stream()), "ts_channel_splice_fwd")
+        ctx.mc = mc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        from . import functional as TF
+        g = g.contiguous()
+        B, C = g.shape[0], g.shape[1]
+        N = g[0, 0].numel()
+        g_in = torch.empty_like(g)
+        _lib.check(_lib.lib().ts_channel_splice_fwd(None, _lib.ptr(g), _lib.ptr(g_in), B, C, ctx.mc, N, 0, C * N, C * N, TF._stream()),
+                   "ts_channel_splice_fwd")
+        return g_in, g[:, :ctx.mc].contiguous()
+
+
+def exchange_feature_memory(inp, memory=None, memory_percent=-1.0):
+    """The memory plumbing in front of every residual block of the reference's backbone
+    (architecture/modeling/backbone/TemporalStereo.py:183-197, :218 -- SURVEY.md section 8(f)-4):
+
+        mc = int(C * memory_percent); the block sees cat([memory, input[:, mc:]], 1) -- the previous frame's first mc channels in
+        place of this frame's -- and this frame's first mc channels become the next frame's memory.
+
+    Returns (x, new_memory).  memory None (first frame): x is `inp` itself.  A memory of the wrong width raises, as the reference's
+    assert does."""
+    C = inp.shape[1]
+    mc = int(C * memory_percent)
+    new_memory = inp[:, :mc]
+    if memory is None:
+        return inp, new_memory
+    if memory.shape[1] != mc:
+        raise AssertionError("input shape: {}; memory shape: {}!".format(tuple(inp.shape), tuple(memory.shape)))
+    if mc == 0:
+        return inp, new_memory
+    return _ChannelSplice.apply(inp, memory), new_memory

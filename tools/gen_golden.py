@@ -370,6 +370,39 @@ def loss_cases(M):
         save(name, **arrs)
 
 
+def backbone_memory_cases(M):
+    """SURVEY 8(f)-4, last clause: the reference's OWN `_inverted_residual_forward`
+    (architecture/modeling/backbone/TemporalStereo.py:183-218).  The module imports timm, which this image lacks, so the function's
+    definition is taken from the reference file's syntax tree and compiled as is (nothing is copied; the fixture holds inputs and
+    outputs only).  The timm block is replaced by identities and the values sit on a 1/8 grid, so that `out - input` is EXACTLY the
+    tensor the block is fed -- these vectors pin the memory plumbing, which is all there is to pin."""
+    import ast
+    import types
+    path = os.path.join(ref_import.REFERENCE_ROOT, "architecture", "modeling", "backbone", "TemporalStereo.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_inverted_residual_forward")
+    ns = {"torch": torch, "drop_path": lambda x, *a, **k: x}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    ref = ns["_inverted_residual_forward"]
+    ident = lambda x: x
+    block = types.SimpleNamespace(conv_pw=ident, bn1=ident, act1=ident, conv_dw=ident, bn2=ident, act2=ident, se=ident, conv_pwl=ident,
+                                  bn3=ident, drop_path_rate=0.0, training=False)
+    cases = [("feature_memory_0", 2, 24, 6, 10, 0.25, True), ("feature_memory_1", 2, 24, 6, 10, 0.25, False),
+             ("feature_memory_2", 1, 10, 5, 7, 0.5, True), ("feature_memory_3", 3, 20, 4, 9, 0.125, True)]
+    for name, B, C, H, W, pct, with_mem in cases:
+        seed = synth.SEED0 + 400 + int(name[-1])
+        grid = lambda tag, shape: (np.round(synth.uniform(seed, tag, shape, -8.0, 8.0) * 8.0) / 8.0).astype(np.float32)
+        x = grid("x", (B, C, H, W))
+        mc = int(C * pct)
+        mem = grid("m", (B, mc, H, W)) if with_mem else None
+        with torch.no_grad():
+            out, new_mem = ref(block, T(x), T(mem) if mem is not None else None, pct)
+        arrs = dict(input=x, memory_percent=np.float64(pct), has_memory=int(with_mem), out=out.numpy(), new_memory=new_mem.numpy())
+        if mem is not None:
+            arrs["memory"] = mem
+        save(name, **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -384,10 +417,14 @@ def main():
     if "--only-losses" in sys.argv:
         loss_cases(M)
         return
+    if "--only-backbone-memory" in sys.argv:
+        backbone_memory_cases(M)
+        return
     functional_cases(M)
     sibling_cases(M)
     temporal_update_cases(M)
     loss_cases(M)
+    backbone_memory_cases(M)
     aggregator_case("agg_tiny_single", TINY, synth.SEED0 + 100, 2, 96, 160, temporal=False, store_inputs=True)
     aggregator_case("agg_tiny_temporal", TINY, synth.SEED0 + 101, 2, 96, 160, temporal=True, store_inputs=True)
     aggregator_case("agg_tiny_train", TINY, synth.SEED0 + 102, 2, 96, 160, temporal=False, store_inputs=True,

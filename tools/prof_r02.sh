@@ -14,7 +14,7 @@ python tools/pmc_summary.py $F "%calib%" >> $O/pmc_fetch_k1.txt; python tools/pm
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/trace -o t -- bash -c "cd $GRAFT_REPO_ROOT && python bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json" > $O/trace.log 2>&1)
 T=$(find $O/trace -name "*.db" | head -1)
 python tools/prof_summary.py $T 200 --by-grid > $O/kernels_by_grid.txt
-cp "$(find $O/trace -name "*kernel_stats.csv" | head -1)" $O/kernel_stats.csv || true
+python tools/prof_summary.py $T 300 > $O/kernel_stats.txt
 # MFMA utilisation at batch 4
 (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d $O/mfma -o m -- bash -c "cd $GRAFT_REPO_ROOT && python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --batch 4" > $O/mfma.log 2>&1)
 M=$(find $O/mfma -name "*.db" | head -1)

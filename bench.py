@@ -28,8 +28,6 @@ import time
 # the one framework pass this script makes (BatchNorm calibration) should not trigger MIOpen's
 # exhaustive solver search (seconds of naive-kernel benchmarking that would drown a profile)
 os.environ.setdefault("MIOPEN_FIND_MODE", "2")
-# hipGraph replays of the training step (train-graph): see temporalstereo_amd/train.py; read when the HIP runtime starts
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import numpy as np
 import torch
@@ -37,6 +35,13 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# hipGraph replays of the training step (train-graph leg): explicit opt-in, before anything touches the GPU (temporalstereo_amd/train.py)
+from temporalstereo_amd import train as _ts_train  # noqa: E402
+try:
+    _ts_train.enable_graph_replay()
+except RuntimeError:          # imported as a module by a process that already used the GPU: only the train-graph leg needs it
+    pass
 
 import synth  # noqa: E402  (deterministic synthetic inputs, shared with the tests)
 
@@ -297,6 +302,10 @@ def main():
                          "forward with the framework's own (MIOpen) convolutions; module-hip: nn.Module forward "
                          "with the HIP convolution Functions (unfused BatchNorm / activation); -graph: replayed "
                          "as one hipGraph")
+    ap.add_argument("--condition-s", type=float, default=1.5,
+                    help="upper bound (seconds) of the untimed device-conditioning phase in front of the warm-up steps: the same pass "
+                         "repeated in batches of 10 until two consecutive batches agree to 1 %% (at least 0.3 s), so that the timed region "
+                         "does not start on a GPU that is still ramping its clocks; reported as `conditioning`; 0 switches it off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true", help="cpu_baseline: also one pass on ALL host threads (slow: oversubscribed)")
     ap.add_argument("--no-extras", action="store_true", help="skip the `training` and `sequence` objects of the default line")
@@ -392,6 +401,27 @@ def main():
         for _ in range(depth):  # set-up, not benchmark steps: record the launch plan of every buffer set / capture the graph
             out = step()
         torch.cuda.synchronize()
+        # Device conditioning (protocol): a fresh process reaches its first timed step ~10 passes (~10 ms of GPU
+        # work) after start-up, on a device that is still leaving its idle power state -- the round-2 driver line was 27 % below
+        # the steady rate for that reason alone.  Bounded, untimed, reported; the warm-up and the timed steps follow unchanged.
+        conditioning = None
+        if a.condition_s > 0:
+            tc0 = time.perf_counter()
+            trace, n_cond = [], 0
+            while True:
+                tb = time.perf_counter()
+                for _ in range(10):
+                    out = step()
+                torch.cuda.synchronize()
+                trace.append((time.perf_counter() - tb) * 100.0)          # ms per pass of this batch
+                n_cond += 10
+                el = time.perf_counter() - tc0
+                settled = len(trace) >= 2 and abs(trace[-1] - trace[-2]) <= 0.01 * trace[-1]
+                if el >= a.condition_s or (el >= 0.3 and settled):
+                    break
+            conditioning = dict(passes=n_cond, seconds=time.perf_counter() - tc0, bound_s=a.condition_s,
+                                first_batch_ms_per_pass=trace[0], last_batch_ms_per_pass=trace[-1],
+                                note="untimed; batches of 10 passes until two consecutive batches agree to 1 % (>= 0.3 s) or the bound")
         for _ in range(a.warmup):
             out = step()
         torch.cuda.synchronize()
@@ -601,6 +631,8 @@ def main():
                                                   "error vs fp64 0.15e-6-0.26e-6 of the output magnitude, the f32-input MFMA kernel 0.3e-6-0.7e-6); "
                                                   "f32_mfma_only = this engine with that switched off"),
                       roofline=roofline)
+        if conditioning is not None:
+            result["conditioning"] = conditioning
         if one_at_a_time is not None:
             result["one_pass_at_a_time"] = one_at_a_time
         if f32_only is not None:

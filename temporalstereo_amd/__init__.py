@@ -7,12 +7,6 @@ mirror the reference's interfaces.  See DESIGN.md / INTEGRATION.md.
 """
 __version__ = "0.1.0"
 
-import os as _os
-
-# hipGraph replays (train.TrainStep(graph=True)): ROCm 7.2's pre-built-packet replay is not safe for graphs of that size
-# (see train.py); the setting is read when the HIP runtime starts, so it goes in before anything touches the GPU.
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-
 from .functional import (cat_fms, dif_fms, correlation, correlation1d, block_cost, topk_softargmax, soft_argmin, argmin_select,  # noqa: F401
                          FunctionSoftsplat, project_to_3d)
 from .registry import (AGGREGATION_REGISTRY, PREDICTION_REGISTRY, build_aggregation, build_prediction,  # noqa: F401

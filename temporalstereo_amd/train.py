@@ -15,11 +15,11 @@ an autograd Function except train-mode BatchNorm / activations (framework ops; S
 Issued op by op the step is host-bound (~1900 launches through the framework's autograd per T=2 step; the kernels themselves
 take about 60 % of the wall time).  `graph=True` captures previous frames + state update + forward + losses + backward ONCE into a
 hipGraph and replays it per step on static copies of the inputs (the step copies each call's tensors into them); gradient
-exchange, clipping and the optimizer stay outside.  With more than one rank the captured BatchNorm is the per-rank one
-(collectives are not captured), which the step reports as `sync_bn: False`.  ROCm 7.2's replay of pre-built AQL packets
+exchange, clipping and the optimizer stay outside.  ROCm 7.2's replay of pre-built AQL packets
 ("graph packet capture") computes garbage gradients from the second or third replay of a graph of this size on (loss finite,
-gradients 1e35 / NaN; bit-stable with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, tools/exp/graph_env.sh), so graph mode insists on that
-setting in the environment -- `temporalstereo_amd` sets it on import when nothing else has.
+gradients 1e35 / NaN; bit-stable with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0), so graph mode insists that this setting was in place
+BEFORE the HIP runtime started: either in the environment the process was started with, or through `enable_graph_replay()`
+called before anything touched the GPU.  Importing the package changes nothing in the environment.
 """
 import contextlib
 import os
@@ -33,21 +33,66 @@ from . import temporal
 from .losses import DispSmoothL1Loss, WarssersteinDistanceLoss
 
 
+_GRAPH_VAR = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+_set_before_runtime = False
+
+
+def _initial_environment():
+    """The environment this process was exec'd with (what the HIP runtime's static initialisers can have seen at the earliest)."""
+    try:
+        with open("/proc/self/environ", "rb") as fh:
+            items = fh.read().split(b"\0")
+        return dict(kv.decode(errors="replace").split("=", 1) for kv in items if b"=" in kv)
+    except OSError:
+        return {}
+
+
+def graph_replay_safe():
+    """True when DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is known to have been set before the HIP runtime read its settings."""
+    if os.environ.get(_GRAPH_VAR) != "0":
+        return False
+    return _set_before_runtime or _initial_environment().get(_GRAPH_VAR) == "0"
+
+
+def enable_graph_replay():
+    """Explicit opt-in for TrainStep(graph=True): put DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 into the environment.  Only effective
+    before the HIP runtime starts, so it raises once the GPU has been touched (unless the setting was there from the start)."""
+    global _set_before_runtime
+    if graph_replay_safe():
+        return
+    if torch.cuda.is_initialized():
+        raise RuntimeError("enable_graph_replay() must run before the first GPU call of the process: the HIP runtime has already "
+                           "read its settings (start the process with %s=0 instead)" % _GRAPH_VAR)
+    os.environ[_GRAPH_VAR] = "0"
+    _set_before_runtime = True
+
+
+# the reference's training configuration (projects/TemporalStereo/configs/sceneflow.yaml:21-24, :61-67)
+REFERENCE_L1_WEIGHTS = (2.0, 1.0, 0.7, 0.5)
+REFERENCE_WARS_WEIGHTS = (1.0, 0.7, 0.5)
+REFERENCE_WARS_GLOBAL_WEIGHT = 2.0
+REFERENCE_LR = 1e-3
+
+
 class TrainStep:
-    def __init__(self, net, max_disp=192, local_map_size=1, lr=1e-4, clip=0.1, sync_bn=True, bucket_bytes=32 << 20, baseline=1.0,
-                 graph=False):
+    def __init__(self, net, max_disp=192, local_map_size=1, lr=REFERENCE_LR, clip=0.1, sync_bn=True, bucket_bytes=32 << 20, baseline=1.0,
+                 graph=False, l1_weights=REFERENCE_L1_WEIGHTS, l1_global_weight=1.0, wars_weights=REFERENCE_WARS_WEIGHTS,
+                 wars_global_weight=REFERENCE_WARS_GLOBAL_WEIGHT):
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.graph = bool(graph)
-        if self.graph and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
-            raise RuntimeError("TrainStep(graph=True) needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP "
-                               "runtime starts (ROCm 7.2 replays pre-built graph packets incorrectly; see train.py)")
+        if self.graph and not graph_replay_safe():
+            raise RuntimeError("TrainStep(graph=True) needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in place before the HIP runtime starts "
+                               "(ROCm 7.2 replays pre-built graph packets incorrectly; see train.py): start the process with it, or "
+                               "call temporalstereo_amd.train.enable_graph_replay() before the first GPU call")
         self.sync_bn = bool(sync_bn) and self.world > 1 and not self.graph
         if self.sync_bn:
             net = tsd.sync_batchnorm(net)
         self.net = net
         tsd.broadcast_parameters(net)
-        self.l1 = DispSmoothL1Loss(max_disp=max_disp, rescale=True)
-        self.wars = WarssersteinDistanceLoss(max_disp=max_disp)
+        self.l1 = DispSmoothL1Loss(max_disp=max_disp, rescale=True, global_weight=l1_global_weight,
+                                   weights=list(l1_weights) if l1_weights is not None else None)
+        self.wars = WarssersteinDistanceLoss(max_disp=max_disp, global_weight=wars_global_weight,
+                                             weights=list(wars_weights) if wars_weights is not None else None)
         self.local_map_size, self.clip, self.baseline = local_map_size, clip, baseline
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.opt = torch.optim.RMSprop(self.params, lr=lr)

@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the hipGraph-replayed training step (tests/test_train_step_gpu.py) needs ROCm 7.2's graph packet capture switched off before
+    # the HIP runtime starts; the library no longer does that on import -- the test harness opts in here, before any GPU call
+    from temporalstereo_amd import train
+    train.enable_graph_replay()
 
 
 @pytest.fixture(scope="session")

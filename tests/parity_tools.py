@@ -98,6 +98,46 @@ class Case:
                                    use_past_cost=True, local_map_size=c["n_local"])
 
 
+CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_planted.npz")
+
+
+def load_checkpoint(path=None):
+    """The committed contractive checkpoint (tools/train_checkpoint.py: this repository's own training step on planted scenes)."""
+    with np.load(path or os.environ.get("TS_CKPT", CKPT)) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+class PlantedCase(Case):
+    """One configuration + seed on a planted-disparity scene (synth.stereo_sequence) with the trained checkpoint: inputs that are
+    stereo, poses that move the scene rigidly, a ground truth per frame, weights that make the pyramid contractive."""
+
+    def __init__(self, c, seed, dev, ckpt=None):
+        import bench
+        self.c, self.seed, self.dev = c, seed, dev
+        self.max_disp = 16 * c["num_sample"]
+        self.net = bench.build_model(dev, seed, c["num_sample"])
+        self.net.load_state_dict(load_checkpoint(ckpt), strict=True)
+        self.net.eval()
+        sc = synth.stereo_sequence(seed, c["B"], c["H"], c["W"], frames=c["frames"], max_disp=self.max_disp, fx=c["fx"], baseline=c["baseline"])
+        T = torch.from_numpy
+        self.frames_cpu = [([T(x) for x in lf], [T(x) for x in rf], T(il), T(ir)) for lf, rf, il, ir in sc["frames"]]
+        self.frames_gpu = [to_dev(f, dev) for f in self.frames_cpu]
+        self.gt = [T(g) for g in sc["gt"]]
+        self.K = T(sc["K"])
+        self.T = [T(t) for t in sc["T"]]
+        self.eye = torch.eye(4).expand(c["B"], 4, 4).contiguous()
+        self.sd = {k: v.detach().cpu() for k, v in self.net.state_dict().items()}
+        self.cfg = dict(coarse=dict(num_sample=c["num_sample"]))
+        self.input_checksum = [synth.checksum([f[0], f[1], f[2], f[3]]) for f in sc["frames"]]
+
+
+def epe(disp, gt, max_disp):
+    """EPE = mean |d - gt| over the valid mask 0 < gt < max_disp (data/evaluation/pixel_error.py:33-63), in float64."""
+    a, g = disp.detach().double().cpu(), gt.double().cpu()
+    m = (g > 0) & (g < max_disp)
+    return float((a - g).abs()[m].mean())
+
+
 def state_for_aggregation(info):
     """The entries of prev_info the aggregation reads."""
     return {k: v for k, v in info.items() if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}

@@ -7,8 +7,12 @@ sequence, configs[4] B=2 temporal): the all-HIP native path against the CPU orac
  2. per-level teacher forcing -- every pyramid level gets the oracle's level inputs; its low-resolution disparity may
     differ from the oracle's ONLY at pixels where the oracle's own top-k selection (or candidate order) is a near-tie
     closer than twice the measured cost error at that pixel;
- 3. end to end -- whole sequences, nothing forced, over several seeds: |dEPE| < 1e-3 px (BASELINE.json) on the
-    full-resolution disparity of every frame with every pixel included.
+ 3. end to end -- whole sequences, nothing forced: |dEPE| < 1e-3 px (BASELINE.json) on the full-resolution disparity
+    asserted for EVERY seed and EVERY frame, on inputs that are stereo (planted disparity, rigid scene under the poses:
+    synth.stereo_sequence) with the committed trained checkpoint (tests/golden/ckpt_planted.npz), (a) against fixtures the
+    imported REFERENCE produced with that checkpoint at the stated batches (tests/golden/planted_*.npz) and (b) against
+    the CPU oracle on further seeds.  The random-weight / independent-noise protocol of rounds 1-2 is kept as a
+    labelled stress test: an untrained pyramid is not contractive, so only its bulk can be asserted.
 """
 import os
 
@@ -188,35 +192,113 @@ def test_every_stage_and_level_teacher_forced_at_stated_batch(name):
         rep.dump("parity_stagewise.json")
 
 
-# seeds per configuration: 8 on the headline configuration, 15 sequences in all (each frame also runs the fp64 oracle)
-_SEEDS = dict(zip(PT.CONFIGS, (8, 3, 1, 3)))       # (a median over two seeds is their maximum: three at least where there is more than one)
+def _clone_info(info):
+    return {k: (v.clone() if torch.is_tensor(v) else ({a: b.clone() for a, b in v.items()} if isinstance(v, dict) else v)) for k, v in info.items()}
+
+
+def _native_sequence(case):
+    """The product path end to end: launch-plan engine per frame, update_map between frames.  -> list of full-resolution maps."""
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    eng = InferenceEngine(case.net, backend="native", replay="plan")
+    info, outs = {}, []
+    for t in range(case.c["frames"]):
+        if t > 0:
+            info = case.native_update(t, info)
+        on = eng(*case.frames_gpu[t], dict(info))
+        info = _clone_info(on[5])
+        outs.append((on[0][0].detach().clone(), on[0][1].detach().clone()))
+    return outs, info
+
+
+_PLANTED = ("planted_c1_s0", "planted_c1_s1", "planted_c1_s2", "planted_c2_s0", "planted_c3_s0", "planted_c4_s0")
+
+
+@pytest.mark.parametrize("fixture", _PLANTED)
+def test_end_to_end_against_reference_fixtures_every_frame(fixture):
+    """|dEPE| < 1e-3 px per frame against what the imported REFERENCE computed (tools/gen_golden.py planted_cases: its aggregator
+    with the committed checkpoint, its own update_map between frames, BASELINE configurations at their stated batches).  EPE is
+    over all pixels against the planted ground truth; the stored sub-sampled maps also bound the per-pixel difference."""
+    import numpy as np
+    import synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture + ".npz"))
+    name = str(g["config"])
+    c = PT.CONFIGS[name]
+    assert (c["B"], c["H"], c["W"], c["frames"], c["n_local"]) == tuple(int(g[k]) for k in ("B", "H", "W", "frames", "n_local"))
+    dev = torch.device("cuda:0")
+    case = PT.PlantedCase(c, int(g["seed"]), dev)
+    for t in range(c["frames"]):          # the inputs are regenerated from the seed: bit for bit, or the comparison means nothing
+        assert abs(case.input_checksum[t] - float(g["input_checksum_%d" % t])) <= 1e-9 * abs(float(g["input_checksum_%d" % t])), \
+            "frame %d: synthetic inputs were not regenerated identically on this host" % t
+    outs, info = _native_sequence(case)
+    rep = PT.Report()
+    sub = int(g["sub"])
+    try:
+        for t, (full, quarter) in enumerate(outs):
+            e = PT.epe(full, case.gt[t], case.max_disp)
+            ref = torch.from_numpy(g["disp_full_sub_%d" % t]).double()
+            d = (full[:, :, ::sub, ::sub].cpu().double() - ref).abs()
+            dq = (quarter[:, :, ::max(sub // 2, 1), ::max(sub // 2, 1)].cpu().double() - torch.from_numpy(g["disp_precise_sub_%d" % t]).double()).abs()
+            rep.add(what="end to end vs reference fixture", fixture=fixture, config=name, frame=t, epe=e, epe_reference=float(g["epe_%d" % t]),
+                    delta_epe=abs(e - float(g["epe_%d" % t])), mean_abs=float(d.mean()), max_abs=float(d.max()), quarter_max_abs=float(dq.max()))
+            assert abs(e - float(g["epe_%d" % t])) < 1e-3, "%s frame %d: EPE %.6f vs the reference's %.6f" % (fixture, t, e, float(g["epe_%d" % t]))
+            assert float(d.mean()) < 1e-3, "%s frame %d: mean |disparity - reference| %.3g px" % (fixture, t, float(d.mean()))
+            assert float((d > 0.05).double().mean()) < 1e-4, "%s frame %d: %.4f%% of the pixels off by > 0.05 px" % (fixture, t, 100 * float((d > 0.05).double().mean()))
+        dm = (info["cost_memory"]["disp_sample"].cpu().double() - torch.from_numpy(g["mem_out_disp_sample"]).double()).abs()
+        rep.add(what="final cost memory vs reference fixture", fixture=fixture, mean_abs=float(dm.mean()), max_abs=float(dm.max()))
+        assert float(dm.mean()) < 1e-3
+    finally:
+        rep.dump("parity_end_to_end_planted.json")
+
+
+# seeds per configuration for the oracle-side sweep (the oracle is a CPU pass per frame: configs[3] is 32 of them per seed)
+_SEEDS = dict(zip(PT.CONFIGS, (6, 2, 1, 2)))
 
 
 @pytest.mark.parametrize("name", list(PT.CONFIGS))
-def test_end_to_end_delta_epe_at_stated_batch_over_seeds(name):
-    """Whole sequences through the product path (engine + update_map), nothing forced, every pixel counted.
+def test_end_to_end_delta_epe_every_seed_every_frame(name):
+    """Whole sequences through the product path (engine + update_map) against the CPU oracle (fp32) carrying its own state,
+    nothing forced, every pixel counted, planted scenes + trained checkpoint: |dEPE| < 1e-3 px for EVERY seed and EVERY frame."""
+    import synth
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    c = PT.CONFIGS[name]
+    rep = PT.Report()
+    try:
+        for k in range(_SEEDS[name]):
+            seed = synth.SEED0 + 100 + 7 * k
+            case = PT.PlantedCase(c, seed, dev)
+            outs, _ = _native_sequence(case)
+            io32 = {}
+            for t in range(c["frames"]):
+                o32 = case.oracle_frame(t, io32)[0]; io32 = o32[5]
+                e_n, e_o = PT.epe(outs[t][0], case.gt[t], case.max_disp), PT.epe(o32[0][0], case.gt[t], case.max_disp)
+                d = (outs[t][0].cpu().double() - o32[0][0].double()).abs()
+                rep.add(what="end to end vs oracle, planted scene + checkpoint", config=name, seed=seed, frame=t, epe=e_n, epe_oracle=e_o,
+                        delta_epe=abs(e_n - e_o), mean_abs=float(d.mean()), max_abs=float(d.max()))
+                assert abs(e_n - e_o) < 1e-3, "%s seed %d frame %d: EPE %.6f vs the oracle's %.6f" % (name, seed, t, e_n, e_o)
+                assert float(d.mean()) < 1e-3, "%s seed %d frame %d: mean |disparity - oracle| %.3g px" % (name, seed, t, float(d.mean()))
+    finally:
+        rep.dump("parity_end_to_end_planted.json")
 
-    What can be asserted end to end on RANDOM-weight networks is bounded by the reference itself: the same CPU oracle
-    run in fp32 and in fp64 -- i.e. the reference against its own exact arithmetic -- moves single frames by a |dEPE|
-    of 2e-6 ... 4.6e-3 px depending on the seed (median 1e-4), because an untrained pyramid is not contractive (a
-    coarse-level rounding difference reaches full resolution times 16 and flips top-k selections on the way), and a
-    temporal frame by 0.01 ... 0.2 px (sort keys of local-map / memory / range candidates nearly coincide by
-    construction; by the fourth frame the fp32 and fp64 oracles share no pixel to 0.01 px).  A trained checkpoint is
-    contractive; none exists offline.  So:
-      single frames   |dEPE| < 1e-3 px (BASELINE.json) in the median over the seeds and for every seed whose own fp32
-                      noise floor allows it; no seed beyond twice the worst noise floor seen over the seeds
-      temporal frames within three times the oracle's own fp32-vs-fp64 distance (tight temporal parity is what the
-                      teacher-forced test above asserts, at the stated batches, with the oracle's state)."""
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# STRESS (not the parity bar): random weights on independent noise features, the protocol of rounds 1-2.  An untrained pyramid
+# is not contractive -- the CPU oracle in fp32 vs the same oracle in fp64 moves single frames by up to 4.6e-3 px and temporal
+# frames by 0.01-0.2 px -- so only the bulk is asserted here; the 1e-3 px bar is asserted above, per seed and per frame.
+_STRESS_SEEDS = dict(zip(PT.CONFIGS, (3, 1, 0, 0)))
+
+
+@pytest.mark.parametrize("name", [n for n in PT.CONFIGS if _STRESS_SEEDS[n]])
+def test_stress_random_weights_end_to_end_bulk(name):
     import synth
     from temporalstereo_amd.aggregation.engine import InferenceEngine
-    assert torch.cuda.is_available(), "GPU tests need an MI355X"
     dev = torch.device("cuda:0")
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     c = PT.CONFIGS[name]
     rep = PT.Report()
     single, floor_single, temporal, floor_temporal = [], [], [], []
     try:
-        for k in range(_SEEDS[name]):
+        for k in range(_STRESS_SEEDS[name]):
             seed = synth.SEED0 + 100 + 7 * k
             case = PT.Case(c, seed, dev)
             eng = InferenceEngine(case.net, backend="native", replay="plan")
@@ -227,26 +309,19 @@ def test_end_to_end_delta_epe_at_stated_batch_over_seeds(name):
                 if t > 0:
                     inat = case.native_update(t, inat)
                 on = eng(*case.frames_gpu[t], dict(inat))
-                inat = {kk: (vv.clone() if torch.is_tensor(vv) else ({a: b.clone() for a, b in vv.items()} if isinstance(vv, dict) else vv))
-                        for kk, vv in on[5].items()}
+                inat = _clone_info(on[5])
                 d, mad = PT.delta_epe(on[0][0], o32[0][0], seed + 10 * t, case.max_disp)
                 f, fmad = PT.delta_epe(o32[0][0], o64[0][0], seed + 10 * t, case.max_disp)
                 d64, mad64 = PT.delta_epe(on[0][0], o64[0][0], seed + 10 * t, case.max_disp)
-                rep.add(what="end to end, full-resolution disparity", config=name, seed=seed, frame=t, delta_epe=d, mean_abs=mad,
+                rep.add(what="STRESS random weights, end to end", config=name, seed=seed, frame=t, delta_epe=d, mean_abs=mad,
                         oracle_fp32_vs_fp64_delta_epe=f, oracle_fp32_vs_fp64_mean_abs=fmad, vs_fp64_delta_epe=d64, vs_fp64_mean_abs=mad64)
-                # the fp32 oracle is itself one rounding of the exact network, and not the same one on every host (its fp32
-                # kernels differ between CPUs): a frame counts with its distance to the nearer of the two arbiters
-                d = min(d, d64)
-                (single if t == 0 else temporal).append(d)
+                (single if t == 0 else temporal).append(min(d, d64))
                 (floor_single if t == 0 else floor_temporal).append(f)
     finally:
-        rep.dump("parity_end_to_end.json")
+        rep.dump("parity_end_to_end_stress.json")
     if SOFT:
         return
-    med = sorted(single)[len(single) // 2]
-    assert med < 1e-3, "%s: median |dEPE| over %d seeds %.3g px" % (name, len(single), med)
-    cap = max(1e-3, 2 * max(floor_single))
-    assert max(single) < cap, "%s: worst seed |dEPE| %.3g px (oracle fp32-vs-fp64 worst %.3g)" % (name, max(single), max(floor_single))
+    assert max(single) < max(1e-3, 2 * max(floor_single), 5e-3), "%s: worst seed |dEPE| %.3g px (oracle fp32-vs-fp64 worst %.3g)" % (name, max(single), max(floor_single))
     if temporal:
-        assert max(temporal) < 3 * max(floor_temporal), \
+        assert max(temporal) < max(3 * max(floor_temporal), 0.05), \
             "%s: temporal frames |dEPE| %.3g px vs the oracle's own fp32-vs-fp64 %.3g" % (name, max(temporal), max(floor_temporal))

@@ -256,18 +256,10 @@ def aggregator_case(name, dims, seed, B, H, W, temporal, store_inputs, training=
     save(name, **arrs)
 
 
-def temporal_update_cases(M):
-    """K2c: the reference's OWN `update_map` (projects/TemporalStereo/TemporalStereo.py:326-461) executed here.
-
-    The method lives inside a pytorch_lightning module whose import needs packages this image lacks, so its
-    function definition is taken from the reference file's syntax tree and compiled as is (nothing is copied into
-    this repository; the fixture holds inputs and outputs only).  It runs against the reference's real
-    project_to_3d; the one foreign piece is FunctionSoftsplat, which exists only as cupy/CUDA kernels
-    (softsplat.py:252,269-270) and is bound to oracle.splat.softsplat -- so these vectors pin the glue (intrinsics
-    scaling, pose composition, disparity <-> depth, metric, plane selection, state bookkeeping), not the splat
-    arithmetic, which stays pinned by the analytic tests of tests/test_oracle_splat.py."""
+def reference_update_map():
+    """The reference's OWN `update_map` (projects/TemporalStereo/TemporalStereo.py:326-461), compiled from its file's syntax tree
+    (the LightningModule around it needs packages this image lacks); FunctionSoftsplat (CUDA-only) is bound to oracle.splat."""
     import ast
-    import types
     import torch.nn.functional as F
     from architecture.modeling.layers import project_to_3d
     sys.path.insert(0, ROOT)
@@ -279,7 +271,133 @@ def temporal_update_cases(M):
     ns = {"torch": torch, "F": F, "project_to_3d": project_to_3d, "EXPMAX": 50,
           "FunctionSoftsplat": lambda tenInput, tenFlow, tenMetric, strType: osplat.softsplat(tenInput, tenFlow, tenMetric, strType)}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
-    update_map = ns["update_map"]
+    return ns["update_map"]
+
+
+def planted_cases(M, only=None):
+    """Full-size end-to-end fixtures: the REFERENCE aggregator with the committed contractive checkpoint
+    (tests/golden/ckpt_planted.npz, trained by this repository's own TrainStep: tools/train_checkpoint.py) on planted-disparity
+    scenes (tests/synth.stereo_sequence) at the BASELINE configurations' stated batches, sequences driven by the reference's own
+    update_map.  Stored per frame: the full-resolution disparity sub-sampled, its EPE against the planted ground truth over ALL
+    pixels (float64), the 1/4-resolution disparity, and a digest of the inputs so that the test side can tell whether it
+    regenerated them bit for bit."""
+    import types
+    import parity_tools as PT
+    update_map = reference_update_map()
+    ckpt = PT.load_checkpoint()
+    # (fixture name, configuration, seed offset, sub-sampling of the stored full-resolution map)
+    plan = [("planted_c1_s0", 0, 0, 2), ("planted_c1_s1", 0, 1, 4), ("planted_c1_s2", 0, 2, 4),
+            ("planted_c2_s0", 1, 0, 4), ("planted_c3_s0", 2, 0, 8), ("planted_c4_s0", 3, 0, 4)]
+    names = list(PT.CONFIGS)
+    for name, ci, k, sub in plan:
+        if only and name not in only:
+            continue
+        c = PT.CONFIGS[names[ci]]
+        seed = synth.SEED0 + 500 + 10 * ci + k
+        B, H, W, frames = c["B"], c["H"], c["W"], c["frames"]
+        max_disp = 16 * c["num_sample"]
+        dims = dict(SCENEFLOW); dims['coarse'] = dict(SCENEFLOW['coarse'], num_sample=c["num_sample"])
+        net = build_reference_aggregator(dims)
+        net.load_state_dict(ckpt, strict=True)
+        net.eval()
+        sc = synth.stereo_sequence(seed, B, H, W, frames=frames, max_disp=max_disp, fx=c["fx"], baseline=c["baseline"])
+        me = types.SimpleNamespace(with_previous=True, use_past_cost=True, local_map_size=c["n_local"])
+        eye = torch.eye(4).expand(B, 4, 4).contiguous()
+        arrs = dict(config=names[ci], seed=seed, B=B, H=H, W=W, frames=frames, sub=sub, max_disp=max_disp, num_sample=c["num_sample"],
+                    n_local=c["n_local"], fx=c["fx"], baseline=c["baseline"])
+        info = {}
+        for t in range(frames):
+            lf, rf, il, ir = sc["frames"][t]
+            arrs["input_checksum_%d" % t] = np.float64(synth.checksum([lf, rf, il, ir]))
+            if t > 0:
+                batch = {"baseline": torch.full((B, 1, 1, 1), float(c["baseline"])), ("color_aug", t, "l"): torch.zeros(B, 3, H, W),
+                         ("K", 0): T(sc["K"]), ("inv_T", t - 1, "l"): eye, ("T", t, "l"): T(sc["T"][t])}
+                with torch.no_grad():
+                    _, info = update_map(me, batch, info, t)
+            with torch.no_grad():
+                disps, costs, samples, offs, ranges, info = net([T(x) for x in lf], [T(x) for x in rf], T(il), T(ir), info)
+            gt = T(sc["gt"][t])
+            arrs["epe_%d" % t] = np.float64(PT.epe(disps[0], gt, max_disp))
+            arrs["epe_quarter_%d" % t] = np.float64(PT.epe(torch.nn.functional.interpolate(disps[1] * 4, size=(H, W), mode='bilinear', align_corners=True), gt, max_disp))
+            arrs["disp_full_sub_%d" % t] = disps[0][:, :, ::sub, ::sub]
+            arrs["disp_precise_sub_%d" % t] = disps[1][:, :, ::max(sub // 2, 1), ::max(sub // 2, 1)]
+            arrs["disp_full_mean_%d" % t] = np.float64(disps[0].double().mean())
+        arrs["mem_out_disp_sample"] = info['cost_memory']['disp_sample']
+        arrs["mem_out_cost_volume"] = info['cost_memory']['cost_volume']
+        save(name, **arrs)
+        print("   ", name, "EPE per frame", [float(arrs["epe_%d" % t]) for t in range(frames)])
+
+
+def planted_gradient_case(M):
+    """Gradient fixture of the whole aggregator: the reference's aggregator in train() mode with the
+    committed checkpoint on a small planted scene, the reference's OWN loss objects with the sceneflow.yaml weights behind the
+    wrapper's full-resolution rescale (projects/TemporalStereo/TemporalStereo.py:305-309), loss.backward() by the framework's
+    autograd.  Stored: the loss terms, the gradients of the six feature maps, the gradients of a list of named weights, and for
+    EVERY parameter the gradient's norm and its projection on a seeded random direction (two numbers per tensor pin all 526)."""
+    import torch.nn.functional as F
+    import parity_tools as PT
+    from architecture.modeling.losses import DispSmoothL1Loss, WarssersteinDistanceLoss
+    B, H, W, ns = 2, 128, 192, 4
+    max_disp = 16 * ns
+    seed = synth.SEED0 + 600
+    dims = dict(SCENEFLOW); dims['coarse'] = dict(SCENEFLOW['coarse'], num_sample=ns)
+    net = build_reference_aggregator(dims)
+    net.load_state_dict(PT.load_checkpoint(), strict=True)
+    net.train()
+    sc = synth.stereo_sequence(seed, B, H, W, frames=1, max_disp=max_disp, fx=300.0, baseline=1.0)
+    lf, rf, il, ir = sc["frames"][0]
+    lf = [T(x).requires_grad_(True) for x in lf]
+    rf = [T(x).requires_grad_(True) for x in rf]
+    gt = T(sc["gt"][0])
+    disps, costs, samples, offs, ranges, info = net(lf, rf, T(il), T(ir), {})
+    full = [F.interpolate(d * W / d.shape[-1], size=(H, W), mode='bilinear', align_corners=True) for d in disps]
+    l1 = DispSmoothL1Loss(max_disp=max_disp, weights=[2.0, 1.0, 0.7, 0.5])(full, gt)
+    wd = WarssersteinDistanceLoss(max_disp=max_disp, global_weight=2.0, weights=[1.0, 0.7, 0.5])(costs, offs, samples, gt)
+    total = sum(l1.values()) + sum(wd.values())
+    total.backward()
+    arrs = dict(seed=seed, B=B, H=H, W=W, num_sample=ns, max_disp=max_disp, fx=300.0, total=total.detach(),
+                input_checksum=np.float64(synth.checksum([sc["frames"][0][0], sc["frames"][0][1], il, ir])))
+    for k, v in list(l1.items()) + list(wd.items()):
+        arrs["loss::" + k] = v.detach()
+    for i in range(3):          # every fourth channel in full + norm and a seeded projection of the whole tensor
+        for side, ts in (("left", lf), ("right", rf)):
+            g = ts[i].grad
+            arrs["g_%s_%d" % (side, i)] = g[:, ::4]
+            arrs["g_%s_%d_norm" % (side, i)] = np.float64(g.double().norm())
+            arrs["g_%s_%d_proj" % (side, i)] = np.float64((g.double().flatten() * T(synth.normal(seed, "projf%s%d" % (side, i), (g.numel(),))).double()).sum())
+    named = dict(net.named_parameters())
+    picks = [k for k in named if k.endswith(("init3d.0.conv.0.weight", "init3d.0.conv.0.bias", "init3d.0.conv.1.weight", "past_conv.weight",
+                                             "pred_heads.cost_head.1.weight", "pred_heads.off_head.1.weight", "pred_heads.cost_head.0.weight",
+                                             "init3d.0.conv.1.norm.weight", "init3d.0.conv.1.norm.bias", "fuse.conv_5x5.weight"))]
+    picks += [k for k in named if k.startswith("precise.refinement.") and k.endswith(("deconv4.weight", "deconv2.weight", "deconv2.bias", "conv4.0.weight",
+                                                                                         "deconv4.norm.weight"))]
+    picks += [k for k in named if "init3d.1." in k and k.endswith(".weight") and k.startswith("fine.")][:8]
+    picks += [k for k in named if "convex_upsample" in k and k.endswith(".weight") and k.startswith("coarse.")][:4]
+    picks = [k for k in dict.fromkeys(picks) if named[k].grad is not None and named[k].numel() <= 40000]
+    arrs["picked"] = np.array(picks)
+    for k in picks:
+        arrs["gw::" + k] = named[k].grad
+    keys = sorted(k for k in named if named[k].grad is not None)
+    arrs["all_keys"] = np.array(keys)
+    arrs["all_norm"] = np.array([float(named[k].grad.double().norm()) for k in keys])
+    arrs["all_proj"] = np.array([float((named[k].grad.double().flatten() * T(synth.normal(seed, "proj" + k, (named[k].numel(),))).double()).sum()) for k in keys])
+    arrs["no_grad_keys"] = np.array(sorted(k for k in named if named[k].grad is None))
+    save("planted_train_grads", **arrs)
+    print("    picked", len(picks), "of", len(keys), "parameters with gradients; total loss", float(total.detach()))
+
+
+def temporal_update_cases(M):
+    """K2c: the reference's OWN `update_map` (projects/TemporalStereo/TemporalStereo.py:326-461) executed here.
+
+    The method lives inside a pytorch_lightning module whose import needs packages this image lacks, so its
+    function definition is taken from the reference file's syntax tree and compiled as is (nothing is copied into
+    this repository; the fixture holds inputs and outputs only).  It runs against the reference's real
+    project_to_3d; the one foreign piece is FunctionSoftsplat, which exists only as cupy/CUDA kernels
+    (softsplat.py:252,269-270) and is bound to oracle.splat.softsplat -- so these vectors pin the glue (intrinsics
+    scaling, pose composition, disparity <-> depth, metric, plane selection, state bookkeeping), not the splat
+    arithmetic, which stays pinned by the analytic tests of tests/test_oracle_splat.py."""
+    import types
+    update_map = reference_update_map()
 
     cases = [  # name, B, H, W, k, local maps in, local_map_size, use_past_cost, pre-composed pose, translation scale
         ("temporal_update_0", 2, 64, 96, 2, 2, 3, True, False, 1.0),
@@ -420,11 +538,21 @@ def main():
     if "--only-backbone-memory" in sys.argv:
         backbone_memory_cases(M)
         return
+    if "--only-planted" in sys.argv:
+        planted_cases(M, [a for a in sys.argv[1:] if a.startswith("planted_")] or None)
+        if not any(a.startswith("planted_") for a in sys.argv[1:]):
+            planted_gradient_case(M)
+        return
+    if "--only-planted-grads" in sys.argv:
+        planted_gradient_case(M)
+        return
     functional_cases(M)
     sibling_cases(M)
     temporal_update_cases(M)
     loss_cases(M)
     backbone_memory_cases(M)
+    planted_cases(M)
+    planted_gradient_case(M)
     aggregator_case("agg_tiny_single", TINY, synth.SEED0 + 100, 2, 96, 160, temporal=False, store_inputs=True)
     aggregator_case("agg_tiny_temporal", TINY, synth.SEED0 + 101, 2, 96, 160, temporal=True, store_inputs=True)
     aggregator_case("agg_tiny_train", TINY, synth.SEED0 + 102, 2, 96, 160, temporal=False, store_inputs=True,

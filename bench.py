@@ -83,6 +83,25 @@ def make_inputs(dev, seed, B, hw=None):
     return [to(x) for x in lf], [to(x) for x in rf], to(il), to(ir)
 
 
+CKPT = os.path.join(ROOT, "tests", "golden", "ckpt_planted.npz")
+
+
+def load_trained(net):
+    """The committed checkpoint (tools/train_checkpoint.py: this repository's TrainStep on planted-disparity scenes)."""
+    with np.load(CKPT) as z:
+        net.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files}, strict=True)
+    return net
+
+
+def make_planted_inputs(dev, seed, B, hw=None):
+    """One frame of a planted-disparity scene (tests/synth.stereo_sequence) -> ((left_feats, right_feats, left_image, right_image), gt)."""
+    H, W = hw or (RUN_H, RUN_W)
+    sc = synth.stereo_sequence(seed, B, H, W, frames=1, max_disp=MAX_DISP)
+    lf, rf, il, ir = sc["frames"][0]
+    to = lambda a: torch.from_numpy(a).to(dev)
+    return ([to(x) for x in lf], [to(x) for x in rf], to(il), to(ir)), torch.from_numpy(sc["gt"][0])
+
+
 def calibrate_batchnorm(net, inputs, prev_info=None):
     """One train-mode pass with momentum 1: running statistics := this input's batch statistics, so
     the random-weight network is conditioned like a trained one (same protocol as tools/gen_golden.py).
@@ -189,21 +208,14 @@ class K1Probe:
         return out_t
 
 
-def cpu_baseline(seed, budget_s=20.0, all_cores=False):
-    """The oracle aggregation (torch CPU ops, all host cores) on the same config-2 inputs."""
+def cpu_baseline(sd, inputs_cpu, budget_s=20.0, all_cores=False):
+    """The oracle aggregation (torch CPU ops) with the bench's own weights on the bench's own (buffer set 0) inputs."""
     from oracle import aggregation as oagg
-    import temporalstereo_amd as ts
-    net = ts.TEMPORALSTEREO(
-        coarse=ts.CoarseAggregation(DIMS['coarse']['in_planes'], DIMS['coarse']['C'], DIMS['coarse']['num_sample']),
-        fine=ts.FineAggregation(DIMS['fine']['in_planes'], DIMS['fine']['C'], 5),
-        precise=ts.PreciseAggregation(DIMS['precise']['in_planes'], DIMS['precise']['C'], 5))
-    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-    sd = {k: torch.from_numpy(v) for k, v in synth.state_values(shapes, seed).items()}
     # more threads than ~16 only adds oversubscription on these small tensors (256-thread runs of this
     # workload measured 76 s/pass on the GPU box's host); the count used is reported as `cores`
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    lf, rf, il, ir = make_inputs(torch.device("cpu"), seed, 1)
+    lf, rf, il, ir = inputs_cpu
     cfg = dict(coarse=dict(num_sample=DIMS['coarse']['num_sample']))
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -227,8 +239,8 @@ def cpu_baseline(seed, budget_s=20.0, all_cores=False):
         torch.set_num_threads(cores)
         extra = dict(all_host_threads=dict(cores=os.cpu_count(), value=1.0 / ta, unit="pairs/s", sample="1 pass"))
     return dict(value=n / t_acc, unit="pairs/s", cores=cores, kind="port", **extra,
-                sample="%d forward passes of the config-2 aggregation (544x960, D=192, B=1) through oracle/ "
-                       "(torch %s CPU kernels, %d threads; first pass %.2fs excluded)" % (n, torch.__version__, cores, first)), out, sd
+                sample="%d forward passes of the config-2 aggregation (544x960, D=192, B=%d) through oracle/ "
+                       "(torch %s CPU kernels, %d threads; first pass %.2fs excluded)" % (n, lf[0].shape[0], torch.__version__, cores, first)), out
 
 
 def training_leg(dev, rank, world, steps, warmup, batch, seed, graph=False):
@@ -306,6 +318,10 @@ def main():
                     help="upper bound (seconds) of the untimed device-conditioning phase in front of the warm-up steps: the same pass "
                          "repeated in batches of 10 until two consecutive batches agree to 1 %% (at least 0.3 s), so that the timed region "
                          "does not start on a GPU that is still ramping its clocks; reported as `conditioning`; 0 switches it off")
+    ap.add_argument("--random-weights", action="store_true",
+                    help="rounds 1-2 protocol: random weights with calibrated BatchNorm statistics on independent smooth-noise features "
+                         "instead of the committed trained checkpoint on a planted-disparity scene (same shapes, same kernels, same speed; "
+                         "an untrained pyramid amplifies rounding differences, so its parity block has a tail)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true", help="cpu_baseline: also one pass on ALL host threads (slow: oversubscribed)")
     ap.add_argument("--no-extras", action="store_true", help="skip the `training` and `sequence` objects of the default line")
@@ -369,8 +385,15 @@ def main():
             dist.destroy_process_group()
         return
     net = build_model(dev, seed)
-    inputs = make_inputs(dev, seed + rank, a.batch)
-    calibrate_batchnorm(net, inputs)
+    planted = os.path.exists(CKPT) and not a.random_weights
+    gt0 = None
+    if planted:
+        load_trained(net).eval()
+        inputs, gt0 = make_planted_inputs(dev, seed + rank, a.batch)
+    else:
+        inputs = make_inputs(dev, seed + rank, a.batch)
+        calibrate_batchnorm(net, inputs)
+    more_inputs = (lambda sd_: make_planted_inputs(dev, sd_, a.batch)[0]) if planted else (lambda sd_: make_inputs(dev, sd_, a.batch))
 
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     mode = a.mode
@@ -386,7 +409,7 @@ def main():
     # N-buffered producer: with N passes in flight the (out-of-scope) backbone writes frame k's features into buffer set k mod N
     # while the passes on the other sets are still running -- every pipeline slot is bound to its OWN input tensors (set 0 =
     # `inputs`, the one the parity check and the K1 probe look at; the others hold different frames)
-    input_sets = [inputs] + [make_inputs(dev, seed + rank + 7919 * i, a.batch) for i in range(1, depth)]
+    input_sets = [inputs] + [more_inputs(seed + rank + 7919 * i) for i in range(1, depth)]
     calls = [0]
 
     def step():
@@ -522,7 +545,7 @@ def main():
         lanes = []
         for i in range(a.inflight):
             st = torch.cuda.Stream(device=dev)
-            ins = make_inputs(dev, seed + 100 * (i + 1) + rank, a.batch)
+            ins = more_inputs(seed + 100 * (i + 1) + rank)
             with torch.cuda.stream(st):
                 eng = InferenceEngine(net, backend="native", replay="plan", inputs="bind", private_streams=True)
                 with torch.no_grad():
@@ -626,6 +649,8 @@ def main():
                                            "single-frame aggregation, batch %d/GPU, eval" % a.batch,
                                   run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
                                   parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth, input_buffer_sets=depth,
+                                  weights_and_inputs=("trained checkpoint tests/golden/ckpt_planted.npz on planted-disparity scenes (tests/synth.stereo_sequence)"
+                                                      if planted else "random weights, calibrated BatchNorm, smooth-noise features (--random-weights)"),
                                   conv_arithmetic="fp32 everywhere; stride-1 (1,3,3) layers with Cin >= 16, Cout > 8 form each fp32 product from "
                                                   "six bf16 MFMA products with fp32 accumulation (x6: dropped terms <= 2^-24 of a product, chunks summed apart; measured max "
                                                   "error vs fp64 0.15e-6-0.26e-6 of the output magnitude, the f32-input MFMA kernel 0.3e-6-0.7e-6); "
@@ -644,24 +669,28 @@ def main():
         if sequence is not None:
             result["sequence"] = sequence
         if world == 1 and not a.no_cpu_baseline:
-            base, ref_out, _ = cpu_baseline(seed, all_cores=a.cpu_all_cores)
-            # parity on the very same inputs: needs the calibrated BN statistics on the oracle side too
+            # the oracle with the very same weights (incl. BatchNorm statistics) on the very same inputs (buffer set 0): timed as the
+            # CPU baseline, and its first pass is the parity reference for `out`
             sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-            from oracle import aggregation as oagg
-            lf, rf, il, ir = make_inputs(torch.device("cpu"), seed, a.batch)
-            with torch.no_grad():
-                ref = oagg.aggregate(sd, lf, rf, il, ir, {}, cfg=dict(coarse=dict(num_sample=DIMS['coarse']['num_sample'])))
+            cpu_in = tuple([x.cpu() for x in t] if isinstance(t, list) else t.cpu() for t in inputs)
+            base, ref = cpu_baseline(sd, cpu_in, all_cores=a.cpu_all_cores)
             full, rfull = out[0][0].detach().cpu().double(), ref[0][0].double()
-            # no ground truth exists for synthetic inputs: gt* = reference output + N(0,1) clipped to
-            # (0, MAX_DISP); EPE = mean |d - gt| (data/evaluation/pixel_error.py:33-63)
-            gen = torch.Generator().manual_seed(seed)
-            gt = (rfull + torch.randn(rfull.shape, generator=gen, dtype=torch.float64)).clamp(0, MAX_DISP)
+            if gt0 is not None:
+                # planted scene: a real ground truth; EPE = mean |d - gt| over 0 < gt < max_disp (data/evaluation/pixel_error.py:33-63)
+                gt = gt0.double()
+            else:
+                # no ground truth exists for noise inputs: gt* = reference output + N(0,1) clipped to (0, MAX_DISP)
+                gen = torch.Generator().manual_seed(seed)
+                gt = (rfull + torch.randn(rfull.shape, generator=gen, dtype=torch.float64)).clamp(0, MAX_DISP)
+            valid = (gt > 0) & (gt < MAX_DISP)
+            e_ours, e_ref = float((full - gt).abs()[valid].mean()), float((rfull - gt).abs()[valid].mean())
             result["cpu_baseline"] = base
-            result["parity"] = dict(delta_epe_px=abs(float((full - gt).abs().mean()) - float((rfull - gt).abs().mean())),
+            result["parity"] = dict(delta_epe_px=abs(e_ours - e_ref), epe_px=e_ours, epe_reference_px=e_ref,
                                     mean_abs_diff_px=float((full - rfull).abs().mean()),
                                     max_abs_diff_px=float((full - rfull).abs().max()),
                                     frac_pixels_off_by_0p01=float(((full - rfull).abs() > 0.01).double().mean()),
-                                    tolerance_px=1e-3, reference="oracle/ (CPU port pinned to the reference's golden vectors)")
+                                    tolerance_px=1e-3, ground_truth="planted disparity of the synthetic scene" if gt0 is not None else "reference output + N(0,1)",
+                                    reference="oracle/ (CPU port pinned to the reference's golden vectors, incl. full-size runs of the reference with this checkpoint)")
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -353,7 +353,8 @@ def resize_bilinear(x, size, value_scale=1.0, out=None):
     B, C, h, w = x.shape
     if out is None:
         out = torch.empty((B, C, size[0], size[1]), device=x.device, dtype=torch.float32)
-    rc = _lib.lib().ts_resize_bilinear_fwd(_lib.ptr(_lib.contiguous(x)), _lib.ptr(out), B, C, h, w, size[0], size[1],
+    x = _lib.contiguous(x)                     # a named reference: a temporary's block could be re-used by a later argument's allocation
+    rc = _lib.lib().ts_resize_bilinear_fwd(_lib.ptr(x), _lib.ptr(out), B, C, h, w, size[0], size[1],
                                            float(value_scale), out.stride(0), _stream())
     _lib.check(rc, "ts_resize_bilinear_fwd")
     return out
@@ -366,7 +367,8 @@ def resize_bilinear_pair(x0, x1, size, scale0, scale1):
         raise RuntimeError("resize_bilinear_pair: shapes differ")
     o0 = torch.empty((B, C, size[0], size[1]), device=x0.device, dtype=torch.float32)
     o1 = torch.empty_like(o0)
-    rc = _lib.lib().ts_resize_bilinear_pair_fwd(_lib.ptr(_lib.contiguous(x0)), _lib.ptr(_lib.contiguous(x1)), _lib.ptr(o0), _lib.ptr(o1),
+    x0, x1 = _lib.contiguous(x0), _lib.contiguous(x1)
+    rc = _lib.lib().ts_resize_bilinear_pair_fwd(_lib.ptr(x0), _lib.ptr(x1), _lib.ptr(o0), _lib.ptr(o1),
                                                 B, C, h, w, size[0], size[1], float(scale0), float(scale1), _stream())
     _lib.check(rc, "ts_resize_bilinear_pair_fwd")
     return o0, o1
@@ -376,7 +378,8 @@ def copy_rows(src, dst):
     """dst[...] = src for a `dst` that is a channel slice of a larger contiguous tensor ([B, C, ...])."""
     B = src.shape[0]
     n = src[0].numel()
-    rc = _lib.lib().ts_copy_rows_fwd(_lib.ptr(_lib.contiguous(src)), _lib.ptr(dst), B, n, n, dst.stride(0), _stream())
+    src = _lib.contiguous(src)
+    rc = _lib.lib().ts_copy_rows_fwd(_lib.ptr(src), _lib.ptr(dst), B, n, n, dst.stride(0), _stream())
     _lib.check(rc, "ts_copy_rows_fwd")
 
 
@@ -489,7 +492,8 @@ class ConvexUp:
         out = torch.empty((B, 1, Ho, Wo), device=disp.device, dtype=torch.float32)
         low, high = torch.empty_like(out), torch.empty_like(out)
         cand = torch.empty((B, extra_front + 5, Ho, Wo), device=disp.device, dtype=torch.float32)
-        rc = _lib.lib().ts_convex_upsample_candidates_fwd(_lib.ptr(m), _lib.ptr(_lib.contiguous(disp)), _lib.ptr(out), _lib.ptr(low),
+        disp = _lib.contiguous(disp)
+        rc = _lib.lib().ts_convex_upsample_candidates_fwd(_lib.ptr(m), _lib.ptr(disp), _lib.ptr(out), _lib.ptr(low),
                                                           _lib.ptr(high), _lib.ptr(cand), B, H, W, self.r, float(self.r), float(rng),
                                                           extra_front, extra_front + 5, _stream())
         _lib.check(rc, "ts_convex_upsample_candidates_fwd")
@@ -500,7 +504,8 @@ class ConvexUp:
         if m is None:
             m = self.mask(feat)
         out = torch.empty((B, 1, H * self.r, W * self.r), device=disp.device, dtype=torch.float32)
-        rc = _lib.lib().ts_convex_upsample_fwd(_lib.ptr(m), _lib.ptr(_lib.contiguous(disp)), _lib.ptr(out), B, H, W, self.r,
+        disp = _lib.contiguous(disp)
+        rc = _lib.lib().ts_convex_upsample_fwd(_lib.ptr(m), _lib.ptr(disp), _lib.ptr(out), B, H, W, self.r,
                                                float(self.r), _stream())
         _lib.check(rc, "ts_convex_upsample_fwd")
         return out

@@ -234,7 +234,8 @@ class _Correlation(torch.autograd.Function):
         B, C, H, W = left.shape
         gl = torch.empty_like(left) if ctx.needs_input_grad[0] else None
         gr = torch.empty_like(right) if ctx.needs_input_grad[1] else None
-        _lib.check(_lib.lib().ts_correlation_bwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(out), _lib.ptr(_lib.contiguous(g)),
+        g = _lib.contiguous(g)
+        _lib.check(_lib.lib().ts_correlation_bwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(out), _lib.ptr(g),
                                                  _lib.ptr(gl), _lib.ptr(gr), B, C, H, W, ph, pw, keep, _stream()), "ts_correlation_bwd")
         return gl, gr, None, None, None
 
@@ -787,7 +788,12 @@ class _Pool5AvgMax(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         B, C, D, H, W = x.shape
         gx = torch.empty_like(x)
-        rc = _lib.lib().ts_pool3d5_avgmax_bwd(_lib.ptr(x), _lib.ptr(g_avg.contiguous()), _lib.ptr(g_max.contiguous()),
+        # Named references, not temporaries: under torch.cat the two gradients arrive as channel slices, `.contiguous()` makes copies,
+        # and a copy that is only alive inside `_lib.ptr(...)` hands its block back to the allocator before the next argument is
+        # evaluated -- the second copy then lands in the SAME block and the kernel reads dMax through both pointers (round 3: the
+        # composed backward was 2-6 % off below every PyramidFusion while each per-op test, fed contiguous gradients, was green).
+        g_avg, g_max = g_avg.contiguous(), g_max.contiguous()
+        rc = _lib.lib().ts_pool3d5_avgmax_bwd(_lib.ptr(x), _lib.ptr(g_avg), _lib.ptr(g_max),
                                               _lib.ptr(gx), B, C, D, H, W, _stream())
         _lib.check(rc, "ts_pool3d5_avgmax_bwd")
         return gx
@@ -820,9 +826,10 @@ class _SortGather(torch.autograd.Function):
         (sample,) = ctx.saved_tensors
         B, DT, H, W = sample.shape
         g_v = g_v.contiguous()
+        g_s = g_s.contiguous() if g_s is not None else None
         C = g_v.shape[1]
         gv, gs = torch.empty_like(g_v), torch.empty_like(sample)
-        rc = _lib.lib().ts_merge_candidates_bwd(_lib.ptr(sample), _lib.ptr(g_v), _lib.ptr(g_s.contiguous() if g_s is not None else None),
+        rc = _lib.lib().ts_merge_candidates_bwd(_lib.ptr(sample), _lib.ptr(g_v), _lib.ptr(g_s),
                                                 _lib.ptr(gv), _lib.ptr(gs), B, C, DT, H, W, _stream())
         _lib.check(rc, "ts_merge_candidates_bwd")
         return gv, gs
@@ -894,7 +901,8 @@ class _ConvexUpsample(torch.autograd.Function):
         B, _, H, W = disp.shape
         gl = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
         gd = torch.empty_like(disp) if ctx.needs_input_grad[1] else None
-        _lib.check(_lib.lib().ts_convex_upsample_bwd(_lib.ptr(logits), _lib.ptr(disp), _lib.ptr(_lib.contiguous(g)), _lib.ptr(gl), _lib.ptr(gd),
+        g = _lib.contiguous(g)
+        _lib.check(_lib.lib().ts_convex_upsample_bwd(_lib.ptr(logits), _lib.ptr(disp), _lib.ptr(g), _lib.ptr(gl), _lib.ptr(gd),
                                                      B, H, W, r, scale, _stream()), "ts_convex_upsample_bwd")
         return gl, gd, None, None
 
@@ -927,7 +935,8 @@ class _UNetUpsample(torch.autograd.Function):
         gl = torch.empty_like(logits)
         gd = torch.empty_like(disp) if ctx.needs_input_grad[1] else None
         ws = torch.empty_like(logits)
-        _lib.check(_lib.lib().ts_unet_upsample_bwd(_lib.ptr(logits), _lib.ptr(disp), _lib.ptr(_lib.contiguous(g)), _lib.ptr(gl), _lib.ptr(gd),
+        g = _lib.contiguous(g)
+        _lib.check(_lib.lib().ts_unet_upsample_bwd(_lib.ptr(logits), _lib.ptr(disp), _lib.ptr(g), _lib.ptr(gl), _lib.ptr(gd),
                                                    _lib.ptr(ws), B, h, w, Ho, Wo, _stream()), "ts_unet_upsample_bwd")
         return gl, gd
 
@@ -1001,7 +1010,8 @@ class _SoftArgmin(torch.autograd.Function):
         B, D, H, W, temperature, normalize = ctx.meta
         gc = torch.empty_like(cost) if ctx.needs_input_grad[0] else None
         gs = torch.empty_like(sample) if ctx.needs_input_grad[1] else None
-        rc = _lib.lib().ts_softargmin_bwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(disp), _lib.ptr(_lib.contiguous(g)),
+        g = _lib.contiguous(g)
+        rc = _lib.lib().ts_softargmin_bwd(_lib.ptr(cost), _lib.ptr(sample), _lib.ptr(disp), _lib.ptr(g),
                                           _lib.ptr(gc), _lib.ptr(gs), temperature, normalize, B, D, H, W, _stream())
         _lib.check(rc, "ts_softargmin_bwd")
         return gc, gs, None, None

@@ -69,3 +69,42 @@ def test_oracle_matches_reference_at_full_size(fixture):
         assert abs(e - float(g["epe_%d" % t])) < 1e-5, (t, e, float(g["epe_%d" % t]))
         assert float(d.mean()) < 1e-4 and float(d.max()) < 2e-2, (t, float(d.mean()), float(d.max()))
     assert 0.02 < float(g["epe_0"]) < 0.5           # the checkpoint is a trained one: sub-pixel on its own training distribution
+
+
+def test_oracle_backward_matches_reference_autograd_in_float64():
+    """The oracle in train mode, differentiated by the framework in float64, against the reference's own float64 backward
+    (tests/golden/planted_train_grads.npz, keys 'f64::*'): loss terms, feature gradients, every parameter's gradient norm and
+    seeded projection.  This is what makes the oracle an arbiter for the product's backward (tests/test_backward_stagewise_gpu.py)."""
+    from oracle import aggregation as oagg
+    from oracle import losses as olo
+    g = load("planted_train_grads")
+    B, H, W, ns, max_disp, seed = (int(g[k]) for k in ("B", "H", "W", "num_sample", "max_disp", "seed"))
+    sc = synth.stereo_sequence(seed, B, H, W, frames=1, max_disp=max_disp, fx=float(g["fx"]))
+    assert abs(synth.checksum(list(sc["frames"][0])) - float(g["input_checksum"])) <= 1e-9 * abs(float(g["input_checksum"]))
+    T64 = lambda a: torch.from_numpy(a).double()
+    lf, rf, il, ir = sc["frames"][0]
+    sd = {k: (v.double().requires_grad_(not k.endswith(("running_mean", "running_var"))) if v.is_floating_point() else v)
+          for k, v in PT.load_checkpoint().items()}
+    lf64, rf64 = [T64(x).requires_grad_(True) for x in lf], [T64(x).requires_grad_(True) for x in rf]
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out = oagg.aggregate(sd, lf64, rf64, T64(il), T64(ir), {}, cfg=dict(coarse=dict(num_sample=ns)), training=True)
+    gt = T64(sc["gt"][0])
+    l1 = [w * olo.smooth_l1_loss_per_level(olo.rescale_to_full(d, (H, W)), gt, max_disp) for w, d in zip((2.0, 1.0, 0.7, 0.5), out[0])]
+    wd = [2.0 * w * olo.wasserstein_loss_per_level(c, o, s, gt, max_disp) for w, c, o, s in zip((1.0, 0.7, 0.5), out[1], out[3], out[2])]
+    for i, v in enumerate(l1):
+        assert abs(float(v) - float(g["f64::loss::l1_loss_lvl%d" % i])) < 1e-9 * abs(float(v)) + 1e-12
+    for i, v in enumerate(wd):
+        assert abs(float(v) - float(g["f64::loss::wars_loss_lvl%d" % i])) < 1e-9 * abs(float(v)) + 1e-12
+    (sum(l1) + sum(wd)).backward()
+    for i in range(3):
+        for side, ts in (("left", lf64), ("right", rf64)):
+            ref = torch.from_numpy(g["f64::g_%s_%d" % (side, i)])
+            assert float((ts[i].grad[:, ::8] - ref).norm() / ref.norm()) < 1e-8, (side, i)
+    keys = [str(k) for k in g["all_keys"]]
+    scale = float(np.max(g["f64::all_norm"]))
+    for k, n_ref, p_ref in zip(keys, g["f64::all_norm"], g["f64::all_proj"]):
+        gr = sd[k].grad
+        assert gr is not None, k
+        p = float((gr.flatten() * torch.from_numpy(synth.normal(seed, "proj" + k, (gr.numel(),))).double()).sum())
+        assert abs(float(gr.norm()) - n_ref) <= 1e-7 * n_ref + 1e-12 * scale, (k, float(gr.norm()), n_ref)
+        assert abs(p - p_ref) <= 1e-7 * n_ref + 1e-12 * scale, (k, p, p_ref)

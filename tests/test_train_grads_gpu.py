@@ -4,7 +4,8 @@ tests/golden/planted_train_grads.npz (tools/gen_golden.py planted_gradient_case)
 the committed checkpoint on a planted scene, the reference's own loss objects with the sceneflow.yaml weights, loss.backward().
 Here: the product's modules (HIP forward + backward: cost volume, conv -> BatchNorm(train) -> activation nodes, resize, pooling,
 sort + gather, upsamplers, both fused losses) on the same inputs; every loss term, the gradients of the six feature maps, 41
-named weight gradients element by element, and the norm + a seeded projection of ALL 273 parameter gradients."""
+named weight gradients element by element, and the norm + a seeded projection of ALL 273 parameter gradients.  (The fixture also
+holds the reference's float64 backward, 'f64::*': its float32 backward is within 5e-6 of it everywhere, so float32 is the arbiter.)"""
 import os
 
 import numpy as np
@@ -19,9 +20,19 @@ import synth  # noqa: E402
 from helpers import load  # noqa: E402
 
 
+SOFT = bool(int(os.environ.get("TS_PARITY_SOFT", "0")))          # collect the report without asserting (exploration)
+
+
 def _rel(a, b):
+    """-> (max |a-b| / max |b|,  ||a-b|| / ||b||,  fraction of elements further than 1e-3 max |b| apart)."""
     a, b = a.double().cpu(), b.double().cpu()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    d, m = (a - b).abs(), b.abs().max().clamp_min(1e-30)
+    return float(d.max() / m), float(d.norm() / b.norm().clamp_min(1e-30)), float((d > 1e-3 * m).double().mean())
+
+
+def _check(cond, msg):
+    if not SOFT:
+        assert cond, msg
 
 
 def test_whole_aggregator_gradients_match_the_reference_autograd():
@@ -49,26 +60,34 @@ def test_whole_aggregator_gradients_match_the_reference_autograd():
     rep = PT.Report()
     try:
         for k, v in list(l1.items()) + list(wd.items()):
-            r = abs(float(v) - float(g["loss::" + k])) / max(abs(float(g["loss::" + k])), 1e-12)
-            rep.add(what="loss term", key=k, ours=float(v), reference=float(g["loss::" + k]), rel=r)
-            assert r < 1e-4, (k, float(v), float(g["loss::" + k]))
-        worst = 0.0
+            r = abs(float(v.detach()) - float(g["loss::" + k])) / max(abs(float(g["loss::" + k])), 1e-12)
+            rep.add(what="loss term", key=k, ours=float(v.detach()), reference=float(g["loss::" + k]), rel=r)
+            _check(r < 1e-5, (k, float(v.detach()), float(g["loss::" + k])))
+        # Element by element.  A discrete step of the forward pass (top-2 selection, candidate order) that falls the other way at a
+        # near-tie would change the gradient of the few pixels behind it completely, in any two fp32 implementations; so the bar is
+        # stated robustly: almost every element within 1e-3 of the tensor's scale, and the tensor as a whole within 1e-3 in the L2
+        # sense (measured: 1e-5 -- the trained network has no such near-ties on this scene).
         for i in range(3):
             for side, ts in (("left", lf), ("right", rf)):
                 gr = ts[i].grad
-                r = _rel(gr[:, ::4], torch.from_numpy(g["g_%s_%d" % (side, i)]))
+                rmax, rl2, bad = _rel(gr[:, ::8], torch.from_numpy(g["g_%s_%d" % (side, i)]))
                 rn = abs(float(gr.double().norm()) - float(g["g_%s_%d_norm" % (side, i)])) / float(g["g_%s_%d_norm" % (side, i)])
-                rep.add(what="feature gradient", key="%s_%d" % (side, i), rel_max=r, rel_norm=rn)
-                worst = max(worst, r)
-                assert r < 2e-3 and rn < 1e-3, ("feature gradient", side, i, r, rn)
+                rep.add(what="feature gradient", key="%s_%d" % (side, i), rel_max=rmax, rel_l2=rl2, frac_off=bad, rel_norm=rn)
+                _check(rl2 < 1e-3 and bad < 1e-3 and rn < 1e-3, ("feature gradient", side, i, rmax, rl2, bad, rn))
         named = dict(net.named_parameters())
+        top = float(g["f64::all_norm"].max())
+        exactly_zero = {str(k) for k, n64 in zip(g["all_keys"], g["f64::all_norm"]) if n64 < 1e-10 * top}     # decided in float64
         for k in [str(x) for x in g["picked"]]:
-            r = _rel(named[k].grad, torch.from_numpy(g["gw::" + k]))
-            rep.add(what="weight gradient", key=k, rel_max=r)
-            assert r < 2e-3, ("weight gradient", k, r)
+            rmax, rl2, bad = _rel(named[k].grad, torch.from_numpy(g["gw::" + k]))
+            rep.add(what="weight gradient", key=k, rel_max=rmax, rel_l2=rl2, frac_off=bad)
+            if k in exactly_zero:        # a bias in front of BatchNorm: rounding noise on both sides
+                _check(float(named[k].grad.norm()) < 1e-5 * top, ("weight gradient that is exactly zero", k, float(named[k].grad.norm())))
+            else:
+                _check(rl2 < 1e-3 and rmax < 2e-3, ("weight gradient", k, rmax, rl2, bad))
         keys = [str(x) for x in g["all_keys"]]
         assert sorted(k for k in named if named[k].grad is not None) == keys          # same set of parameters receives a gradient
         assert [str(x) for x in g["no_grad_keys"]] == sorted(k for k in named if named[k].grad is None)
+        # (weights: a sum over all pixels, so a flipped pixel is diluted; 1 % of the gradient's norm in norm and projection)
         for k, n_ref, p_ref in zip(keys, g["all_norm"], g["all_proj"]):
             gr = named[k].grad.double().cpu()
             n = float(gr.norm())
@@ -76,6 +95,9 @@ def test_whole_aggregator_gradients_match_the_reference_autograd():
             rn = abs(n - n_ref) / max(n_ref, 1e-12)
             rp = abs(p - p_ref) / max(n_ref, 1e-12)             # a projection's scale is the gradient's norm
             rep.add(what="every parameter: gradient norm / projection", key=k, rel_norm=rn, rel_proj=rp)
-            assert rn < 2e-3 and rp < 2e-3, (k, n, float(n_ref), p, float(p_ref))
+            if k in exactly_zero:
+                _check(n < 1e-5 * top, (k, n))
+            else:
+                _check(rn < 1e-3 and rp < 1e-3, (k, n, float(n_ref), p, float(p_ref)))
     finally:
         rep.dump("parity_train_grads.json")

@@ -332,8 +332,10 @@ def planted_gradient_case(M):
     """Gradient fixture of the whole aggregator: the reference's aggregator in train() mode with the
     committed checkpoint on a small planted scene, the reference's OWN loss objects with the sceneflow.yaml weights behind the
     wrapper's full-resolution rescale (projects/TemporalStereo/TemporalStereo.py:305-309), loss.backward() by the framework's
-    autograd.  Stored: the loss terms, the gradients of the six feature maps, the gradients of a list of named weights, and for
-    EVERY parameter the gradient's norm and its projection on a seeded random direction (two numbers per tensor pin all 526)."""
+    autograd -- run twice: in float32 (what the reference computes) and in float64 (the same modules and inputs cast to double:
+    the exact gradient of the same function, the arbiter where fp32 backward passes through BatchNorm lose digits to
+    cancellation).  Stored for both: the loss terms, the gradients of the six feature maps (every 8th channel), the gradients of
+    a list of named weights, and for EVERY parameter the gradient's norm and its projection on a seeded random direction."""
     import torch.nn.functional as F
     import parity_tools as PT
     from architecture.modeling.losses import DispSmoothL1Loss, WarssersteinDistanceLoss
@@ -341,49 +343,58 @@ def planted_gradient_case(M):
     max_disp = 16 * ns
     seed = synth.SEED0 + 600
     dims = dict(SCENEFLOW); dims['coarse'] = dict(SCENEFLOW['coarse'], num_sample=ns)
-    net = build_reference_aggregator(dims)
-    net.load_state_dict(PT.load_checkpoint(), strict=True)
-    net.train()
     sc = synth.stereo_sequence(seed, B, H, W, frames=1, max_disp=max_disp, fx=300.0, baseline=1.0)
-    lf, rf, il, ir = sc["frames"][0]
-    lf = [T(x).requires_grad_(True) for x in lf]
-    rf = [T(x).requires_grad_(True) for x in rf]
-    gt = T(sc["gt"][0])
-    disps, costs, samples, offs, ranges, info = net(lf, rf, T(il), T(ir), {})
-    full = [F.interpolate(d * W / d.shape[-1], size=(H, W), mode='bilinear', align_corners=True) for d in disps]
-    l1 = DispSmoothL1Loss(max_disp=max_disp, weights=[2.0, 1.0, 0.7, 0.5])(full, gt)
-    wd = WarssersteinDistanceLoss(max_disp=max_disp, global_weight=2.0, weights=[1.0, 0.7, 0.5])(costs, offs, samples, gt)
-    total = sum(l1.values()) + sum(wd.values())
-    total.backward()
-    arrs = dict(seed=seed, B=B, H=H, W=W, num_sample=ns, max_disp=max_disp, fx=300.0, total=total.detach(),
-                input_checksum=np.float64(synth.checksum([sc["frames"][0][0], sc["frames"][0][1], il, ir])))
-    for k, v in list(l1.items()) + list(wd.items()):
-        arrs["loss::" + k] = v.detach()
-    for i in range(3):          # every fourth channel in full + norm and a seeded projection of the whole tensor
-        for side, ts in (("left", lf), ("right", rf)):
-            g = ts[i].grad
-            arrs["g_%s_%d" % (side, i)] = g[:, ::4]
-            arrs["g_%s_%d_norm" % (side, i)] = np.float64(g.double().norm())
-            arrs["g_%s_%d_proj" % (side, i)] = np.float64((g.double().flatten() * T(synth.normal(seed, "projf%s%d" % (side, i), (g.numel(),))).double()).sum())
-    named = dict(net.named_parameters())
-    picks = [k for k in named if k.endswith(("init3d.0.conv.0.weight", "init3d.0.conv.0.bias", "init3d.0.conv.1.weight", "past_conv.weight",
-                                             "pred_heads.cost_head.1.weight", "pred_heads.off_head.1.weight", "pred_heads.cost_head.0.weight",
-                                             "init3d.0.conv.1.norm.weight", "init3d.0.conv.1.norm.bias", "fuse.conv_5x5.weight"))]
-    picks += [k for k in named if k.startswith("precise.refinement.") and k.endswith(("deconv4.weight", "deconv2.weight", "deconv2.bias", "conv4.0.weight",
-                                                                                         "deconv4.norm.weight"))]
-    picks += [k for k in named if "init3d.1." in k and k.endswith(".weight") and k.startswith("fine.")][:8]
-    picks += [k for k in named if "convex_upsample" in k and k.endswith(".weight") and k.startswith("coarse.")][:4]
-    picks = [k for k in dict.fromkeys(picks) if named[k].grad is not None and named[k].numel() <= 40000]
-    arrs["picked"] = np.array(picks)
-    for k in picks:
-        arrs["gw::" + k] = named[k].grad
-    keys = sorted(k for k in named if named[k].grad is not None)
-    arrs["all_keys"] = np.array(keys)
-    arrs["all_norm"] = np.array([float(named[k].grad.double().norm()) for k in keys])
-    arrs["all_proj"] = np.array([float((named[k].grad.double().flatten() * T(synth.normal(seed, "proj" + k, (named[k].numel(),))).double()).sum()) for k in keys])
-    arrs["no_grad_keys"] = np.array(sorted(k for k in named if named[k].grad is None))
+    arrs = dict(seed=seed, B=B, H=H, W=W, num_sample=ns, max_disp=max_disp, fx=300.0,
+                input_checksum=np.float64(synth.checksum(list(sc["frames"][0]))))
+    for tag, dt in (("", torch.float32), ("f64::", torch.float64)):
+        torch.set_default_dtype(dt)                  # the reference creates constants (candidates, zero memory) in the default dtype
+        net = build_reference_aggregator(dims)
+        net.load_state_dict(PT.load_checkpoint(), strict=True)
+        net = net.to(dt).train()
+        lf, rf, il, ir = sc["frames"][0]
+        lf = [T(x).to(dt).requires_grad_(True) for x in lf]
+        rf = [T(x).to(dt).requires_grad_(True) for x in rf]
+        gt = T(sc["gt"][0]).to(dt)
+        disps, costs, samples, offs, ranges, info = net(lf, rf, T(il).to(dt), T(ir).to(dt), {})
+        full = [F.interpolate(d * W / d.shape[-1], size=(H, W), mode='bilinear', align_corners=True) for d in disps]
+        l1 = DispSmoothL1Loss(max_disp=max_disp, weights=[2.0, 1.0, 0.7, 0.5])(full, gt)
+        wd = WarssersteinDistanceLoss(max_disp=max_disp, global_weight=2.0, weights=[1.0, 0.7, 0.5])(costs, offs, samples, gt)
+        total = sum(l1.values()) + sum(wd.values())
+        total.backward()
+        arrs[tag + "total"] = total.detach()
+        for k, v in list(l1.items()) + list(wd.items()):
+            arrs[tag + "loss::" + k] = v.detach()
+        for i in range(3):          # every eighth channel in full + norm and a seeded projection of the whole tensor
+            for side, ts in (("left", lf), ("right", rf)):
+                g = ts[i].grad
+                arrs[tag + "g_%s_%d" % (side, i)] = g[:, ::8]
+                arrs[tag + "g_%s_%d_norm" % (side, i)] = np.float64(g.double().norm())
+        named = dict(net.named_parameters())
+        picks = [k for k in named if k.endswith(("init3d.0.conv.0.weight", "init3d.0.conv.0.bias", "init3d.0.conv.1.weight", "past_conv.weight",
+                                                 "pred_heads.cost_head.1.weight", "pred_heads.off_head.1.weight", "pred_heads.cost_head.0.weight",
+                                                 "init3d.0.conv.1.norm.weight", "init3d.0.conv.1.norm.bias", "fuse.conv_5x5.weight"))]
+        picks += [k for k in named if k.startswith("precise.refinement.") and k.endswith(("deconv4.weight", "deconv2.weight", "deconv2.bias", "conv4.0.weight",
+                                                                                             "deconv4.norm.weight"))]
+        picks += [k for k in named if "init3d.1." in k and k.endswith(".weight") and k.startswith("fine.")][:8]
+        picks += [k for k in named if "convex_upsample" in k and k.endswith(".weight") and k.startswith("coarse.")][:4]
+        picks = [k for k in dict.fromkeys(picks) if named[k].grad is not None and named[k].numel() <= 40000]
+        arrs["picked"] = np.array(picks)
+        for k in picks:
+            arrs[tag + "gw::" + k] = named[k].grad
+        keys = sorted(k for k in named if named[k].grad is not None)
+        arrs["all_keys"] = np.array(keys)
+        arrs[tag + "all_norm"] = np.array([float(named[k].grad.double().norm()) for k in keys])
+        arrs[tag + "all_proj"] = np.array([float((named[k].grad.double().flatten() * T(synth.normal(seed, "proj" + k, (named[k].numel(),))).double()).sum()) for k in keys])
+        arrs["no_grad_keys"] = np.array(sorted(k for k in named if named[k].grad is None))
+        print("    [%s] picked" % (tag or "f32"), len(picks), "of", len(keys), "parameters with gradients; total loss", float(total.detach()))
+    torch.set_default_dtype(torch.float32)
+    # how far the reference's fp32 backward is from its own exact (fp64) one: the floor of any fp32 comparison
+    worst = 0.0
+    for k in arrs["picked"]:
+        a, b = arrs["gw::" + str(k)].double(), arrs["f64::gw::" + str(k)].double()
+        worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-30)))
+    print("    reference fp32 vs fp64 backward, worst relative L2 over the picked weights: %.3g" % worst)
     save("planted_train_grads", **arrs)
-    print("    picked", len(picks), "of", len(keys), "parameters with gradients; total loss", float(total.detach()))
 
 
 def temporal_update_cases(M):

@@ -1,33 +1,35 @@
-"""Which contribution to d PyramidFusion / d input is off?  (round 3: 5-7 % in the stage-wise backward test)"""
 import os, sys
 import torch, torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from temporalstereo_amd import functional as TF
-from temporalstereo_amd.layers import Conv3d
+from temporalstereo_amd.aggregation.blocks import PyramidFusion
+from oracle import aggregation as oagg
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-def rel(a, b): return float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
-for shape in [(2, 16, 7, 16, 24), (2, 32, 6, 8, 12), (1, 8, 9, 20, 33)]:
-    x = torch.randn(*shape, device=dev)
-    ga, gm = torch.randn_like(x), torch.randn_like(x)
-    xh = x.clone().requires_grad_(True)
-    a, m = TF.pool5_avgmax(xh)
-    torch.autograd.backward([a], [ga]); g_avg_h = xh.grad.clone(); xh.grad = None
-    a, m = TF.pool5_avgmax(xh)
-    torch.autograd.backward([m], [gm]); g_max_h = xh.grad.clone(); xh.grad = None
-    a, m = TF.pool5_avgmax(xh)
-    torch.autograd.backward([a, m], [ga, gm]); g_both_h = xh.grad.clone()
-    xr = x.double().cpu().requires_grad_(True)
-    ar = F.avg_pool3d(xr, 5, 1, 2); ar.backward(ga.double().cpu()); g_avg_r = xr.grad.clone(); xr.grad = None
-    mr = F.max_pool3d(xr, 5, 1, 2); mr.backward(gm.double().cpu()); g_max_r = xr.grad.clone()
-    print(shape, "avg only %.3g  max only %.3g  both %.3g" % (rel(g_avg_h, g_avg_r), rel(g_max_h, g_max_r), rel(g_both_h, g_avg_r + g_max_r)))
-    C = shape[1]
-    conv = Conv3d(C, C, (5, 1, 1), 1, (2, 0, 0), bias=False, norm=('BN3d', C), activation='SiLU').to(dev).train()
-    xh = x.clone().requires_grad_(True)
-    y = conv(xh); y.backward(ga)
-    w = conv.weight.detach().double().cpu(); bn = conv.norm
-    xr = x.double().cpu().requires_grad_(True)
-    yr = F.silu(F.batch_norm(F.conv3d(xr, w, None, 1, (2, 0, 0)), None, None, bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu(), True, 0.0, 1e-5))
-    yr.backward(ga.double().cpu())
-    print("   conv(5,1,1)+BN+SiLU fwd %.3g  d/dx %.3g  d/dw %.3g" % (rel(y, yr), rel(xh.grad, xr.grad), rel(conv.weight.grad, torch.autograd.grad(F.silu(F.batch_norm(F.conv3d(xr, w.requires_grad_(True), None, 1, (2, 0, 0)), None, None, bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu(), True, 0.0, 1e-5)), w, ga.double().cpu())[0])))
+def rel(a, b): return float((a.detach().double().cpu() - b.detach().double().cpu()).norm() / b.detach().double().cpu().norm())
+C, shape = 16, (2, 16, 7, 16, 24)
+m = PyramidFusion(C).to(dev).train()
+x = torch.randn(*shape, device=dev)
+sd = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+def branches(xh, which, hip):
+    out = []
+    if "i" in which: out.append(xh)
+    if "c" in which: out.append(m.conv_5x5(xh) if hip else oagg.conv3d(oagg.StateView(sd, "conv_5x5.", True), xh, 1, (2, 0, 0)))
+    if "a" in which or "m" in which:
+        a, mx = TF.pool5_avgmax(xh) if hip else (F.avg_pool3d(xh, 5, 1, 2), F.max_pool3d(xh, 5, 1, 2))
+        if "a" in which: out.append(a)
+        if "m" in which: out.append(mx)
+    return out
+for which in ("ic", "ia", "im", "ca", "cm", "am", "iam", "icam", "cam"):
+    for mode in ("cat", "sum"):
+        xh = x.clone().requires_grad_(True)
+        bs = branches(xh, which, True)
+        gz = [torch.randn_like(b) for b in bs]
+        if mode == "cat":
+            torch.cat(bs, 1).backward(torch.cat(gz, 1))
+        else:
+            torch.autograd.backward(bs, gz)
+        xr = x.double().cpu().requires_grad_(True)
+        torch.autograd.backward(branches(xr, which, False), [g.double().cpu() for g in gz])
+        print(which, mode, "%.3g" % rel(xh.grad, xr.grad))

@@ -404,6 +404,34 @@ int ts_copy_rows_fwd(const float* src, float* dst, long long rows, long long row
                      long long dst_pitch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-side glue (csrc/train_ops.hip): the element-wise steps around the levels that the framework otherwise runs
+ * as ~280 tiny launches per training step, the pieces that run the UNet decoder's ConvTranspose2d(4, stride 2, padding 1)
+ * (module.py:453-457) on the convolution kernels in training, and the optimizer step.
+ *   candidates_in_range : candidates[:, off+i] = |high-low| * {0,3,4,5,8}/8 + min(low,high) (fine.py:82-87, precise.py:73-78)
+ *                         from separate low / high maps [B,1,H,W]; bwd: d/d low, d/d high (|.|' = sign, min' split at ties)
+ *   offset_head         : y = clamp(tanh(x/100), -1, 1) * delta  (PredictionHeads.regress_offset, module.py:384-390)
+ *   space_to_depth2     : z[b][(py*2+px)*C + c][y][x] = x[b][c][2y+py][2x+px]   (x [B,C,2H,2W] -> z [B,4C,H,W])
+ *   deconv2d_k4s2_weight_to_conv3 : w [Cin][Cout][4][4] -> out [(4*Cout)][9][cin_pad], the ts_conv3d_hw_fwd weight of the 3x3
+ *                         stride-1 convolution of space_to_depth2(dy) that is d/dx of the transposed convolution
+ *   deconv2d_k4s2_wgrad_from_conv3: dw3 [Cin][4*Cout][9] (ts_conv3d_hw_bwd_weight of that convolution) -> dw [Cin][Cout][4][4]
+ *   clip_rmsprop_step   : clip_grad_norm_(max_norm) + RMSprop(lr, alpha, eps; no momentum / centring / weight decay) over
+ *                         a DEVICE table of ts_opt_entry; two launches, deterministic; workspace's last float <- total norm
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ts_opt_entry { float* param; const float* grad; float* square_avg; long long n; } ts_opt_entry;
+int ts_candidates_in_range_fwd(const float* low, const float* high, float* candidates, int B, int H, int W,
+                               int channel_offset, int channels_total, void* stream);
+int ts_candidates_in_range_bwd(const float* low, const float* high, const float* grad_candidates, float* grad_low,
+                               float* grad_high, int B, int H, int W, int channel_offset, int channels_total, void* stream);
+int ts_offset_head_fwd(const float* x, float* y, long long n, float delta, void* stream);
+int ts_offset_head_bwd(const float* x, const float* grad_y, float* grad_x, long long n, float delta, void* stream);
+int ts_space_to_depth2_fwd(const float* x, float* z, int B, int C, int H, int W, void* stream);
+int ts_deconv2d_k4s2_weight_to_conv3(const float* w, float* out, int Cin, int Cout, int cin_pad, void* stream);
+int ts_deconv2d_k4s2_wgrad_from_conv3(const float* dw3, float* dw, int Cin, int Cout, void* stream);
+size_t ts_clip_rmsprop_workspace_bytes(int n_tensors);
+int ts_clip_rmsprop_step(const void* table, int n_tensors, float max_norm, float lr, float alpha, float eps,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Native replay runtime (no reference counterpart; the reference runs eagerly under PyTorch).
  * A plan is the recorded sequence of launching calls of one pass -- device pointers, shapes and
  * streams baked in, the contract of a CUDA graph with static buffers -- re-issued by one host call.

@@ -36,6 +36,15 @@ SIGNATURES = {
     "ts_block_cost_int_bwd": (c_int, [c_f32p] * 5 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_bwd": (c_int, [c_f32p] * 7 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_calib_stream": (c_int, [c_int, c_ptr, c_ptr, c_size, c_ptr]),
+    "ts_candidates_in_range_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [c_ptr]),
+    "ts_candidates_in_range_bwd": (c_int, [c_f32p] * 5 + [c_int] * 5 + [c_ptr]),
+    "ts_offset_head_fwd": (c_int, [c_f32p] * 2 + [ctypes.c_longlong, c_float, c_ptr]),
+    "ts_offset_head_bwd": (c_int, [c_f32p] * 3 + [ctypes.c_longlong, c_float, c_ptr]),
+    "ts_space_to_depth2_fwd": (c_int, [c_f32p] * 2 + [c_int] * 4 + [c_ptr]),
+    "ts_deconv2d_k4s2_weight_to_conv3": (c_int, [c_f32p] * 2 + [c_int] * 3 + [c_ptr]),
+    "ts_deconv2d_k4s2_wgrad_from_conv3": (c_int, [c_f32p] * 2 + [c_int] * 2 + [c_ptr]),
+    "ts_clip_rmsprop_workspace_bytes": (c_size, [c_int]),
+    "ts_clip_rmsprop_step": (c_int, [c_ptr, c_int] + [c_float] * 4 + [c_ptr, c_size, c_ptr]),
     "ts_topk_softargmax_fwd": (c_int, [c_f32p] * 7 + [c_int] * 5 + [c_ptr]),
     "ts_topk_softargmax_bwd": (c_int, [c_f32p] * 9 + [c_int] * 5 + [c_ptr]),
     "ts_softargmin_fwd": (c_int, [c_f32p] * 3 + [c_float, c_int] + [c_int] * 4 + [c_ptr]),

@@ -137,6 +137,8 @@ class PredictionHeads(nn.Module):
         self.off_head = head()
 
     def regress_offset(self, off):
+        if _on_hip(off):
+            return TF.offset_head(off, self.delta)
         return torch.tanh(off / 100).clamp(-1, 1) * self.delta
 
     def forward(self, init_cost):
@@ -200,4 +202,6 @@ class UNet(nn.Module):
     def decoder(self, disp, feat, feat2x):
         feat = self.deconv4(self.fuse(feat))
         feat = self.concat(torch.cat([feat, feat2x], dim=1))
+        if _on_hip(feat):      # nn.ConvTranspose2d(4, stride 2, padding 1) on the HIP kernels, forward and backward (module.py:457)
+            return self.upsample(TF.conv_transpose2d_k4s2(feat, self.deconv2.weight, self.deconv2.bias), disp)
         return self.upsample(self.deconv2(feat), disp)

@@ -131,8 +131,11 @@ class FineAggregation(_Level):
         self.weight_init()
 
     def generate_disparity_sample(self, low_disparity, high_disparity, num_sample, prev_info):
-        disp_sample = _candidates_in_range(low_disparity, high_disparity)
         local_map = prev_info.get('local_map', None)
+        if low_disparity.is_cuda and low_disparity.dtype == torch.float32 and not (local_map is not None and local_map.requires_grad):
+            use_map = local_map is not None and prev_info.get('local_map_size', 0) > 0
+            return TF.candidates_in_range(low_disparity, high_disparity, local_map if use_map else None)      # one launch each way
+        disp_sample = _candidates_in_range(low_disparity, high_disparity)
         if local_map is not None and prev_info.get('local_map_size', 0) > 0:      # fine.py:89-93
             H, W = low_disparity.shape[-2:]
             local_map = F.interpolate(local_map * W / local_map.shape[-1], size=(H, W), mode='bilinear',
@@ -165,6 +168,8 @@ class PreciseAggregation(_Level):
         self.weight_init()
 
     def generate_disparity_sample(self, low_disparity, high_disparity, num_sample):
+        if low_disparity.is_cuda and low_disparity.dtype == torch.float32:
+            return TF.candidates_in_range(low_disparity, high_disparity)
         return _candidates_in_range(low_disparity, high_disparity)
 
     def forward(self, left, right, low_disparity, high_disparity, left_image, right_image, prev_info: dict):

@@ -86,6 +86,11 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_conv3d_hw_x6_fwd),        TS_PLAN_OP(ts_conv3d_hw_x6_weight_split),
     TS_PLAN_OP(ts_bn_train_fwd),            TS_PLAN_OP(ts_bn_train_bwd),
     TS_PLAN_OP(ts_channel_splice_fwd),
+    TS_PLAN_OP(ts_candidates_in_range_fwd), TS_PLAN_OP(ts_candidates_in_range_bwd),
+    TS_PLAN_OP(ts_offset_head_fwd),         TS_PLAN_OP(ts_offset_head_bwd),
+    TS_PLAN_OP(ts_space_to_depth2_fwd),
+    TS_PLAN_OP(ts_deconv2d_k4s2_weight_to_conv3), TS_PLAN_OP(ts_deconv2d_k4s2_wgrad_from_conv3),
+    TS_PLAN_OP(ts_clip_rmsprop_step),
 };
 
 struct Call {

@@ -297,6 +297,7 @@ class WeightLayouts:
         object) and shared by the later requests of the step -- for a replayed graph, where the one-launch refresh leaves the
         layouts cold in the cache by the time the convolutions read them (train.py)."""
         self.entries = {}           # key -> [weight, out, descriptor tuple, epoch]
+        self.custom = {}            # key -> [weight, out, make, epoch]
         self._table = None
         self._dirty = False
         self._blocks = 1
@@ -314,7 +315,7 @@ class WeightLayouts:
         return False
 
     def clear(self):
-        self.entries, self._table, self._dirty = {}, None, False
+        self.entries, self.custom, self._table, self._dirty = {}, {}, None, False
 
     def get(self, weight, a_dim, b_dim, flip):
         key = (weight.data_ptr(), tuple(weight.shape), a_dim, b_dim, bool(flip))
@@ -332,9 +333,24 @@ class WeightLayouts:
             e[3] = self.epoch
         return e[1]
 
+    def get_custom(self, weight, tag, make):
+        """A kernel form of `weight` that is not a plain [A][taps][pad(B)] re-layout (the 3x3 form of a 4x4 transposed
+        convolution): `make(weight, out=None) -> out` fills it; kept and refreshed (one launch each) like the table entries."""
+        key = (weight.data_ptr(), tuple(weight.shape), tag)
+        e = self.custom.get(key)
+        if e is None:
+            e = self.custom[key] = [weight, make(weight, None), make, self.epoch]
+        elif self.lazy and e[3] != self.epoch:
+            make(e[0], e[1])
+            e[3] = self.epoch
+        return e[1]
+
     def refresh(self):
         """Re-lay every registered weight from its current values (one launch on the current stream; lazy: on next use)."""
         self.epoch += 1
+        if not self.lazy:
+            for e in self.custom.values():
+                e[2](e[0], e[1])
         if self.lazy or not self.entries:
             return
         if self._dirty:
@@ -385,6 +401,8 @@ def _shift_vec(bias, n):
     """[coutp] epilogue shift holding the bias (the kernels add it to the raw sum: scale stays 1)."""
     if bias is None:
         return None
+    if bias.numel() == n and bias.is_contiguous():
+        return bias.detach()                    # Cout is its own bucket (8, 16, 32, 64): nothing to pad, no launch
     v = torch.zeros(n, device=bias.device, dtype=torch.float32)
     v[:bias.numel()] = bias.detach()
     return v
@@ -543,6 +561,115 @@ class _Conv3dD(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+_ONES = {}
+
+
+def _ones(n, device):
+    key = (n, device)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
+    return _ONES[key]
+
+
+def _zeros_const(n, device, _cache={}):
+    key = (n, device)
+    if key not in _cache:
+        _cache[key] = torch.zeros(n, device=device, dtype=torch.float32)
+    return _cache[key]
+
+
+def _dc_conv3_weight(weight, out=None):
+    """[Cin][Cout][4][4] -> [(4*Cout)][9][pad(Cin)]: weight of the 3x3 convolution that is d/dx of the transposed convolution."""
+    Cin, Cout = weight.shape[0], weight.shape[1]
+    cpad = _cpad(Cin)
+    if out is None:
+        out = torch.empty((4 * Cout, 9, cpad), device=weight.device, dtype=torch.float32)
+    w = weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    _lib.check(_lib.lib().ts_deconv2d_k4s2_weight_to_conv3(_lib.ptr(w), _lib.ptr(out), Cin, Cout, cpad, _stream()),
+               "ts_deconv2d_k4s2_weight_to_conv3")
+    return out
+
+
+def _dc_forward(x, weight, bias=None):
+    """Raw ConvTranspose2d(kernel 4, stride 2, padding 1) (+ bias) of UNet.deconv4 / deconv2 (module.py:453-457): ts_deconv2d_k4s2_fwd."""
+    _require_gpu(x, weight)
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[1]
+    w_t = _layout(weight, 0, 1)                                                   # [ci][16 taps][pad(co)]
+    pad = _cpad(Cout)
+    y = torch.empty((B, Cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    sh = _shift_vec(bias, pad) if bias is not None else _zeros_const(pad, x.device)
+    rc = _lib.lib().ts_deconv2d_k4s2_fwd(_lib.ptr(x), _lib.ptr(w_t), _lib.ptr(_ones(pad, x.device)), _lib.ptr(sh), _lib.ptr(y),
+                                         B, Cin, Cout, H, W, 0, y.stride(0), _stream())
+    _lib.check(rc, "ts_deconv2d_k4s2_fwd")
+    return x, y, (B, Cin, Cout, H, W)
+
+
+def _dc_backward(x, weight, dy, geom, need_x, need_w):
+    """d/dx = conv3x3(space_to_depth2(dy)) with the weight's 3x3 form (four parity classes, two taps per axis each: 16 of the 36
+    taps are non-zero), d/dW = the weight gradient of that same convolution gathered back to [Cin][Cout][4][4]: both on the MFMA
+    convolution kernels of the (1,3,3) family (a plane = depth 1)."""
+    B, Cin, Cout, H, W = geom
+    dy = dy.contiguous()
+    L = _lib.lib()
+    z = torch.empty((B, 4 * Cout, H, W), device=dy.device, dtype=torch.float32)
+    _lib.check(L.ts_space_to_depth2_fwd(_lib.ptr(dy), _lib.ptr(z), B, Cout, H, W, _stream()), "ts_space_to_depth2_fwd")
+    dx = dw = None
+    zc = 4 * Cout
+    if need_x:
+        if _LAYOUTS is not None and weight.is_contiguous():
+            w3 = _LAYOUTS.get_custom(weight, "dc3", _dc_conv3_weight)
+        else:
+            w3 = _dc_conv3_weight(weight)
+        dx = torch.empty_like(x)
+        wsb = _q("ts_conv3d_hw_workspace_bytes", B, zc, Cin, 1, H, W, 1, 0)
+        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
+        rc = L.ts_conv3d_hw_fwd(_lib.ptr(z), _lib.ptr(w3), None, None, _lib.ptr(dx), B, zc, Cin, 1, H, W, 1, 1, 0, 0, 0.0,
+                                z.stride(0), z.stride(1), dx.stride(0), dx.stride(1), None, 0, _lib.ptr(ws), wsb, _stream())
+        _lib.check(rc, "ts_conv3d_hw_fwd")
+    if need_w:
+        dw3 = torch.empty((Cin, zc, 9), device=x.device, dtype=torch.float32)
+        ws, nws = _wgrad_workspace(zc, Cin, 9, x.device)
+        rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(z), _lib.ptr(x), _lib.ptr(dw3), B, zc, Cin, 1, H, W, 1, 1,
+                                       z.stride(0), z.stride(1), x.stride(0), x.stride(1), _lib.ptr(ws), nws, _stream())
+        _lib.check(rc, "ts_conv3d_hw_bwd_weight")
+        dw = torch.empty_like(weight)
+        _lib.check(L.ts_deconv2d_k4s2_wgrad_from_conv3(_lib.ptr(dw3), _lib.ptr(dw), Cin, Cout, _stream()), "ts_deconv2d_k4s2_wgrad_from_conv3")
+    return dx, dw
+
+
+def deconv2d_k4s2_supported(weight_shape, stride, padding, output_padding, dilation, groups):
+    """True when a ConvTranspose2d runs on the HIP kernels: kernel 4, stride 2, padding 1, <= 32 output and <= 64 input channels."""
+    return (len(weight_shape) == 4 and tuple(weight_shape[2:]) == (4, 4) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and
+            tuple(output_padding) == (0, 0) and tuple(dilation) == (1, 1) and groups == 1 and weight_shape[1] <= 32 and weight_shape[0] <= 64)
+
+
+class _Deconv2dK4S2(torch.autograd.Function):
+    """Raw ConvTranspose2d(4, stride 2, padding 1) + bias (UNet.deconv2, module.py:457): ts_deconv2d_k4s2_fwd forward, backward on the
+    (1,3,3) convolution kernels (see _dc_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, y, ctx.geom = _dc_forward(x, weight, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw = _dc_backward(x, weight, dy, ctx.geom, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gb = dy.sum(dim=(0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, gb
+
+
+def conv_transpose2d_k4s2(x, weight, bias=None):
+    """F.conv_transpose2d(x, weight, bias, stride 2, padding 1) for 4x4 kernels on the HIP kernels (forward and backward)."""
+    return _Deconv2dK4S2.apply(x, weight, bias)
+
+
 BN_ACT = {None: 0, "SiLU": 1, "ReLU": 2}
 
 
@@ -563,6 +690,8 @@ class _ConvBNAct(torch.autograd.Function):
                 counter=None):
         if family == "hw":
             x, y, cg = _hw_forward(x, weight, geom[0], geom[1], geom[2], bias)
+        elif family == "dc":
+            x, y, cg = _dc_forward(x, weight, bias)
         else:
             x, y, cg = _d_forward(x, weight, geom[0], geom[1], geom[2], geom[3], bias)
         B, C = y.shape[0], y.shape[1]
@@ -652,6 +781,8 @@ class _ConvBNAct(torch.autograd.Function):
     def _conv_backward(ctx, x, weight, dy, family, cg, has_bias, gaffine):
         if family == "hw":
             dx, dw = _hw_backward(x, weight, dy, cg, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        elif family == "dc":
+            dx, dw = _dc_backward(x, weight, dy, cg, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         else:
             dx, dw = _d_backward(x, weight, dy, cg, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         gbias = None
@@ -726,6 +857,75 @@ def conv_transpose3d(x, weight, bias=None, stride=(1, 2, 2), padding=(0, 1, 1), 
         raise NotImplementedError("conv_transpose3d: kernel %s stride %s padding %s output_padding %s has no HIP kernel"
                                   % (tuple(weight.shape[2:]), stride, padding, output_padding))
     return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+
+
+# --------------------------------------------------------------------------------------- element-wise glue of the levels
+class _CandidatesInRange(torch.autograd.Function):
+    """fine.py:82-93 / precise.py:73-78: the five candidates |high - low| * {0,3,4,5,8}/8 + min(low, high), behind the (detached)
+    local-map candidates of the previous frames when there are any -- one launch each way instead of ~13 framework launches."""
+
+    @staticmethod
+    def forward(ctx, low, high, local_map):
+        _require_gpu(low, high, local_map)
+        low, high = _lib.contiguous(low), _lib.contiguous(high)
+        B, _, H, W = low.shape
+        nl = 0 if local_map is None else local_map.shape[1]
+        out = torch.empty((B, nl + 5, H, W), device=low.device, dtype=torch.float32)
+        L = _lib.lib()
+        if nl:
+            lm = _lib.contiguous(local_map)
+            h, w = lm.shape[-2:]
+            _lib.check(L.ts_resize_bilinear_fwd(_lib.ptr(lm), _lib.ptr(out), B, nl, h, w, H, W, float(W) / w, out.stride(0), _stream()),
+                       "ts_resize_bilinear_fwd")
+        _lib.check(L.ts_candidates_in_range_fwd(_lib.ptr(low), _lib.ptr(high), _lib.ptr(out), B, H, W, nl, nl + 5, _stream()),
+                   "ts_candidates_in_range_fwd")
+        ctx.save_for_backward(low, high)
+        ctx.nl = nl
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        low, high = ctx.saved_tensors
+        B, _, H, W = low.shape
+        g = _lib.contiguous(g)
+        gl, gh = torch.empty_like(low), torch.empty_like(high)
+        _lib.check(_lib.lib().ts_candidates_in_range_bwd(_lib.ptr(low), _lib.ptr(high), _lib.ptr(g), _lib.ptr(gl), _lib.ptr(gh), B, H, W,
+                                                         ctx.nl, ctx.nl + 5, _stream()), "ts_candidates_in_range_bwd")
+        return gl, gh, None
+
+
+def candidates_in_range(low, high, local_map=None):
+    """[B, n_local + 5, H, W]: `local_map` ([B, n_local, h, w], no gradient: the previous frames' state) resized to (H, W) with the
+    disparity rescale of fine.py:89-93 in front of the five range candidates of fine.py:82-87."""
+    if local_map is not None and local_map.requires_grad:
+        raise NotImplementedError("candidates_in_range: the local map is temporal state and carries no gradient here")
+    return _CandidatesInRange.apply(low, high, local_map)
+
+
+class _OffsetHead(torch.autograd.Function):
+    """PredictionHeads.regress_offset (module.py:384-390): tanh(x / 100).clamp(-1, 1) * delta, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, delta):
+        _require_gpu(x)
+        x = _lib.contiguous(x)
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().ts_offset_head_fwd(_lib.ptr(x), _lib.ptr(y), x.numel(), float(delta), _stream()), "ts_offset_head_fwd")
+        ctx.save_for_backward(x)
+        ctx.delta = float(delta)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _lib.contiguous(g)
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().ts_offset_head_bwd(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gx), x.numel(), ctx.delta, _stream()), "ts_offset_head_bwd")
+        return gx, None
+
+
+def offset_head(x, delta):
+    return _OffsetHead.apply(x, delta)
 
 
 # --------------------------------------------------------------------------------------- K3 element stages

@@ -156,6 +156,13 @@ class ConvTranspose2d(nn.ConvTranspose2d, _NormAct):
         if self.padding_mode != 'zeros':
             raise ValueError('Only `zeros` padding mode is supported for ConvTranspose2d')
         op = self._output_padding(x, output_size, self.stride, self.padding, self.kernel_size, 2, self.dilation)
+        if _hip_conv(x):
+            from . import functional as TF
+            if TF.deconv2d_k4s2_supported(tuple(self.weight.shape), self.stride, self.padding, tuple(op), self.dilation, self.groups):
+                act = self._fusable()
+                if act is not False:      # UNet.deconv4 (module.py:453-456): transposed conv -> BatchNorm -> ReLU as one autograd node
+                    return TF.conv_bn_act(x, self.weight, self.bias, self.norm, act, "dc", None)
+                return self._finish(TF.conv_transpose2d_k4s2(x, self.weight, self.bias))
         return self._finish(F.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, op,
                                                self.groups, self.dilation))
 

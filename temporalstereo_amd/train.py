@@ -67,6 +67,72 @@ def enable_graph_replay():
     _set_before_runtime = True
 
 
+class ClipRMSprop:
+    """clip_grad_norm_(max_norm) + torch.optim.RMSprop(lr, alpha, eps) (no momentum, not centred, no weight decay: the reference's
+    optimizer, sceneflow.yaml:21-24, under gradient_clip_val=0.1, dist_train.py:94) as TWO launches over a pointer table of all
+    parameters (ts_clip_rmsprop_step) instead of ~30 multi-tensor launches and their host-side bookkeeping.  Parameters without a
+    gradient are skipped, as the framework's optimizer does.  Deterministic (fixed-order norm reduction)."""
+
+    def __init__(self, params, lr=1e-3, alpha=0.99, eps=1e-8, max_norm=0.1):
+        import numpy as np
+        self.params = list(params)
+        self.lr, self.alpha, self.eps, self.max_norm = float(lr), float(alpha), float(eps), float(max_norm or 0.0)
+        self.param_groups = [dict(lr=self.lr, params=self.params)]          # the part of the optimizer interface schedulers use
+        self.square_avg = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.params]
+        n = len(self.params)
+        self._dtype = np.dtype([("param", "<u8"), ("grad", "<u8"), ("sq", "<u8"), ("n", "<i8")])
+        self._host = [torch.empty(n * 32, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(n * 32, dtype=torch.uint8)
+                      for _ in range(2)]
+        self._turn = 0
+        self._table = self._ws = None
+        self._static_grads = None
+        self.steps = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def total_norm(self):
+        """Gradient norm of the last step (before clipping), a 0-d device tensor."""
+        if self._ws is None:
+            return None
+        off = len(self.params) * 8 * 4                       # behind the 8 partial sums per tensor (ts_clip_rmsprop_step)
+        return self._ws[off:off + 4].view(torch.float32)[0]
+
+    def step(self):
+        from . import _lib
+        from .functional import _stream
+        ps = self.params
+        if not ps:
+            return
+        dev = ps[0].device
+        n = len(ps)
+        L = _lib.lib()
+        if self._table is None:
+            self._table = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+            nb = int(L.ts_clip_rmsprop_workspace_bytes(n))
+            self._ws = torch.empty((nb + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+        grads = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in ps)
+        if grads != self._static_grads:                      # eager steps: fresh gradient tensors every backward; graph replays: static
+            host = self._host[self._turn]
+            self._turn ^= 1
+            rec = host.numpy().view(self._dtype)
+            for i, p in enumerate(ps):
+                g = p.grad
+                if g is not None and (not g.is_contiguous() or g.dtype != torch.float32):
+                    raise RuntimeError("ClipRMSprop: gradients must be dense fp32")
+                rec[i] = (p.data_ptr(), grads[i], self.square_avg[i].data_ptr(), p.numel())
+            self._table.copy_(host, non_blocking=True)
+            self._static_grads = grads
+        lr = float(self.param_groups[0]["lr"])
+        _lib.check(L.ts_clip_rmsprop_step(_lib.ptr(self._table), n, self.max_norm, lr, self.alpha, self.eps, _lib.ptr(self._ws),
+                                          self._ws.numel(), _stream()), "ts_clip_rmsprop_step")
+        self.steps += 1
+
+
 # the reference's training configuration (projects/TemporalStereo/configs/sceneflow.yaml:21-24, :61-67)
 REFERENCE_L1_WEIGHTS = (2.0, 1.0, 0.7, 0.5)
 REFERENCE_WARS_WEIGHTS = (1.0, 0.7, 0.5)
@@ -77,13 +143,18 @@ REFERENCE_LR = 1e-3
 class TrainStep:
     def __init__(self, net, max_disp=192, local_map_size=1, lr=REFERENCE_LR, clip=0.1, sync_bn=True, bucket_bytes=32 << 20, baseline=1.0,
                  graph=False, l1_weights=REFERENCE_L1_WEIGHTS, l1_global_weight=1.0, wars_weights=REFERENCE_WARS_WEIGHTS,
-                 wars_global_weight=REFERENCE_WARS_GLOBAL_WEIGHT):
+                 wars_global_weight=REFERENCE_WARS_GLOBAL_WEIGHT, fused_optimizer=True):
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.graph = bool(graph)
         if self.graph and not graph_replay_safe():
             raise RuntimeError("TrainStep(graph=True) needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in place before the HIP runtime starts "
                                "(ROCm 7.2 replays pre-built graph packets incorrectly; see train.py): start the process with it, or "
                                "call temporalstereo_amd.train.enable_graph_replay() before the first GPU call")
+        if self.graph and self.world > 1 and sync_bn:
+            # collectives are not captured: a replayed step can only normalise with per-rank statistics, which is NOT what the
+            # reference trains with (sync_batchnorm=True, dist_train.py:94) -- refuse rather than change semantics silently
+            raise RuntimeError("TrainStep(graph=True) cannot run SyncBatchNorm across %d ranks (the statistics exchange cannot be replayed "
+                               "from a hipGraph); use graph=False, or pass sync_bn=False to accept per-rank BatchNorm explicitly" % self.world)
         self.sync_bn = bool(sync_bn) and self.world > 1 and not self.graph
         if self.sync_bn:
             net = tsd.sync_batchnorm(net)
@@ -95,17 +166,20 @@ class TrainStep:
                                              weights=list(wars_weights) if wars_weights is not None else None)
         self.local_map_size, self.clip, self.baseline = local_map_size, clip, baseline
         self.params = [p for p in net.parameters() if p.requires_grad]
-        self.opt = torch.optim.RMSprop(self.params, lr=lr)
+        on_gpu = bool(self.params) and self.params[0].is_cuda
+        self.fused_optimizer = bool(fused_optimizer) and on_gpu
+        self.opt = ClipRMSprop(self.params, lr=lr, max_norm=clip) if self.fused_optimizer else torch.optim.RMSprop(self.params, lr=lr)
         self.buckets = tsd.GradientBuckets(self.params, bucket_bytes=bucket_bytes) if self.world > 1 and not self.graph else None
         self._g = self._static = self._loss = None
         self.timings = {}
         self._modules = list(net.modules())
-        # Kernel layouts of all convolution weights in one launch per step instead of ~280: 5 ms of host time in the eager step
-        # (28 -> 22.7 ms).  Not in a replayed graph, where only device time counts: the per-call layouts go to small recycled
-        # blocks of the graph's pool and are still in the cache when their convolution reads them, kept ones are not --
-        # measured per replay: 14.3 ms without, 14.9 ms with the one-launch refresh, 16.1 ms with layouts made on first use and
-        # shared by the later uses of the step (`WeightLayouts(lazy=True)`), although both remove launches.
-        self.layouts = None if self.graph else TF.WeightLayouts()
+        # Kernel layouts of all convolution weights in one launch per step instead of ~280 (eager: 5 ms of host time, 28 -> 22.7 ms;
+        # replayed: ~270 launches of ~4.6 us, 1.2 ms of device time per step).  TS_TRAIN_GRAPH_LAYOUTS=0: round 2's choice for the
+        # replayed step (a layout launch in front of every convolution).
+        self.layouts = TF.WeightLayouts() if (not self.graph or os.environ.get("TS_TRAIN_GRAPH_LAYOUTS", "0") != "0") else None
+        # (Tried and dropped in round 3: the weight-gradient launches on a forked side stream inside the capture -- they depend only on
+        # dy, 15 % of the step's device time, small grids.  The replayed graph got SLOWER, 15.0 vs 13.4 ms: forked captures replay
+        # badly on ROCm 7.2, as the inference graph already showed)
 
     def _set_training(self, mode):
         """net.train(mode) without nn.Module.__setattr__'s bookkeeping on ~640 modules (2.4 ms of host time per step)."""
@@ -134,7 +208,7 @@ class TrainStep:
             losses = {}
             losses.update(self.l1(disps, gt))
             losses.update(self.wars(costs, offs, samples, gt))
-            total = sum(losses.values())
+            total = torch.stack(list(losses.values())).sum()        # (one cat + one reduction instead of six additions, each way)
             total.backward()
         return total.detach()
 
@@ -146,6 +220,9 @@ class TrainStep:
         elif isinstance(tree, (list, tuple)):
             for t in tree:
                 yield from TrainStep._tensors(t)
+        elif tree is not None and not isinstance(tree, (int, float, bool, str)):
+            # a numpy pose / a dict would be baked into the capture as a constant and silently ignored on later calls
+            raise TypeError("TrainStep(graph=True): inputs must be tensors in lists / tuples, got %s" % type(tree).__name__)
 
     @staticmethod
     def _clone(tree):
@@ -193,10 +270,14 @@ class TrainStep:
             if self._g is None:
                 self._capture(args)
             else:
-                for dst, src in zip(self._tensors(self._static), self._tensors(args)):
+                dsts, srcs = list(self._tensors(self._static)), list(self._tensors(args))
+                if len(dsts) != len(srcs) or any(d.shape != s.shape or d.dtype != s.dtype for d, s in zip(dsts, srcs)):
+                    raise RuntimeError("TrainStep(graph=True): this call's inputs do not have the structure / shapes / dtypes the graph was "
+                                       "captured with (%d tensors); build a new TrainStep for a new geometry" % len(dsts))
+                for dst, src in zip(dsts, srcs):
                     dst.detach().copy_(src, non_blocking=True)
             self._g.replay()
-            loss = self._loss
+            loss = self._loss.clone()                                # the graph's own buffer is overwritten by the next replay
             t1 = time.perf_counter()
             if self.world > 1:
                 self._all_reduce_flat()
@@ -207,9 +288,12 @@ class TrainStep:
             if self.buckets is not None:
                 self.buckets.finish()
         t2 = time.perf_counter()
-        if self.clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.clip)
-        self.opt.step()
+        if self.fused_optimizer:
+            self.opt.step()                                          # clip + RMSprop: two launches
+        else:
+            if self.clip:
+                torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+            self.opt.step()
         t3 = time.perf_counter()
         # host-side issue times (the device runs behind them); the exchange entry includes waiting for the reduced buckets
         self.timings = dict(forward_backward_issue_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3, clip_step_issue_ms=(t3 - t2) * 1e3)

@@ -691,9 +691,34 @@ def main():
                                     frac_pixels_off_by_0p01=float(((full - rfull).abs() > 0.01).double().mean()),
                                     tolerance_px=1e-3, ground_truth="planted disparity of the synthetic scene" if gt0 is not None else "reference output + N(0,1)",
                                     reference="oracle/ (CPU port pinned to the reference's golden vectors, incl. full-size runs of the reference with this checkpoint)")
-        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and mode == "native" and not a.no_extras:
+            # The data-parallel TRAINING step on the same N GPUs (SyncBatchNorm + bucketed all-reduce over RCCL), as its own job with a
+            # timeout: a rank that hangs inside a collective must not take the headline line with it.  The inference ranks are done
+            # (process group destroyed above); rank 0 launches `bench.py --mode train --gpus N` and embeds its `training` object.
+            import subprocess
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                                "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE") and not k.startswith("TORCHELASTIC_")}
+            try:
+                import signal
+                child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--mode", "train", "--gpus", str(world), "--steps", "10",
+                                          "--warmup", "4", "--batch", str(a.batch)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                         start_new_session=True)                    # its own process group: the launcher AND its ranks
+                try:
+                    so, se = child.communicate(timeout=float(os.environ.get("TS_BENCH_TRAIN_TIMEOUT", "300")))
+                    lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+                    result["training"] = json.loads(lines[-1])["training"] if (child.returncode == 0 and lines) else \
+                        dict(error="exit code %d: %s" % (child.returncode, (se or so)[-400:]))
+                except subprocess.TimeoutExpired:
+                    os.killpg(child.pid, signal.SIGKILL)                              # exactly the group started above
+                    child.communicate()
+                    result["training"] = dict(error="timed out (a rank stuck in a collective?)")
+            except Exception as e:          # the headline must survive anything the extra leg does
+                result["training"] = dict(error="%s: %s" % (type(e).__name__, e))
+        print(json.dumps(result), flush=True)
     return result
 
 

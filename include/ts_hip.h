@@ -109,6 +109,11 @@ int ts_block_cost_sampled_bwd(const float* left, const float* right, const float
  * mean / var / the two sums are arguments so that cross-rank statistics (SyncBatchNorm) can be exchanged in between.
  * ---------------------------------------------------------------------------------------- */
 size_t ts_bn_workspace_bytes(int B, int C, long long N);
+/* SyncBatchNorm merge: gathered = the ranks' [mean(C) | biased var(C) | count] records of ts_bn_stats_fwd (world x (2C+1) floats, one
+ * all_gather) -> statistics of the whole batch (parallel-variance formula, double), running statistics updated with momentum
+ * (NULL: not tracked), *inv_count = 1 / total count on the device (the backward sums are scaled with it: no host read). */
+int ts_bn_sync_merge(const float* gathered, int world, int C, float* mean, float* var, float* running_mean,
+                     float* running_var, float momentum, float* inv_count, void* stream);
 /* Single-rank training forms (nothing to exchange between the statistics and their use): statistics + normalise/activate in two
  * launches, backward sums + input gradient in two (each a partial-sums kernel, then one whose workgroups finish their channel's
  * sums themselves in the fixed order of the three-launch forms -- same values).  ts_bn_train_bwd: count = B*N elements. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "ts_argmax_select_fwd": (c_int, [c_f32p] * 4 + [c_int] * 4 + [c_ptr]),
     "ts_bn_workspace_bytes": (c_size, [c_int, c_int, ctypes.c_longlong]),
     "ts_channel_splice_fwd": (c_int, [c_f32p] * 3 + [c_int] * 3 + [ctypes.c_longlong] * 4 + [c_ptr]),
+    "ts_bn_sync_merge": (c_int, [c_f32p, c_int, c_int] + [c_f32p] * 4 + [c_float, c_f32p, c_ptr]),
     "ts_bn_train_fwd": (c_int, [c_f32p] * 5 + [c_float, c_ptr] + [c_f32p] * 3 + [c_ptr, c_int, c_int] + [ctypes.c_longlong] * 5 +
                         [c_float, c_int, c_ptr]),
     "ts_bn_train_bwd": (c_int, [c_f32p] * 9 + [c_ptr, c_int, c_int] + [ctypes.c_longlong] * 5 + [c_float, c_int, c_float, c_ptr]),

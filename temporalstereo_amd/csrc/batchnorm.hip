@@ -365,6 +365,42 @@ extern "C" int ts_bn_act_bwd_apply(const float* x, const float* dy, const float*
   return ts::launched("bn_bwd_apply_kernel");
 }
 
+// SyncBatchNorm: combine the ranks' [mean | biased var | count] records (one all_gather) into the statistics of the whole batch with
+// the parallel-variance formula, update the running statistics (unbiased variance of the global count) and leave 1 / count on the
+// device -- the backward pass scales its all-reduced sums with it, so the host never reads a count (round 2 read one per layer).
+__global__ void __launch_bounds__(64)
+bn_sync_merge_kernel(const float* __restrict__ gathered, int world, int C, float* __restrict__ mean, float* __restrict__ var,
+                     float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float* __restrict__ inv_count) {
+  const int rec = 2 * C + 1;
+  double n = 0.0;
+  for (int r = 0; r < world; ++r) n += gathered[static_cast<size_t>(r) * rec + 2 * C];
+  for (int c = threadIdx.x; c < C; c += 64) {
+    double m = 0.0;
+    for (int r = 0; r < world; ++r) m += static_cast<double>(gathered[static_cast<size_t>(r) * rec + c]) * gathered[static_cast<size_t>(r) * rec + 2 * C];
+    m /= n;
+    double v = 0.0;
+    for (int r = 0; r < world; ++r) {
+      const double d = gathered[static_cast<size_t>(r) * rec + c] - m;
+      v += (gathered[static_cast<size_t>(r) * rec + C + c] + d * d) * gathered[static_cast<size_t>(r) * rec + 2 * C];
+    }
+    v /= n;
+    mean[c] = static_cast<float>(m);
+    var[c] = static_cast<float>(v);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * static_cast<float>(m);
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * static_cast<float>(v * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+  }
+  if (threadIdx.x == 0 && inv_count) *inv_count = static_cast<float>(1.0 / n);
+}
+
+extern "C" int ts_bn_sync_merge(const float* gathered, int world, int C, float* mean, float* var, float* running_mean,
+                                float* running_var, float momentum, float* inv_count, void* stream) {
+  TS_REQUIRE(world > 0 && C > 0, TS_ERR_SHAPE, "bn_sync_merge: bad size");
+  TS_REQUIRE_PTR(gathered); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var);
+  hipLaunchKernelGGL(bn_sync_merge_kernel, dim3(1), dim3(64), 0, ts::as_stream(stream), gathered, world, C, mean, var, running_mean,
+                     running_var, momentum, inv_count);
+  return ts::launched("bn_sync_merge_kernel");
+}
+
 // Single-rank training form of the pair (ts_bn_stats_fwd, ts_bn_apply_act_fwd): two launches instead of three.
 extern "C" int ts_bn_train_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
                                long long* num_batches_tracked, const float* gamma, const float* beta, float* out,

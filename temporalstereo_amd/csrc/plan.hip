@@ -90,7 +90,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_offset_head_fwd),         TS_PLAN_OP(ts_offset_head_bwd),
     TS_PLAN_OP(ts_space_to_depth2_fwd),
     TS_PLAN_OP(ts_deconv2d_k4s2_weight_to_conv3), TS_PLAN_OP(ts_deconv2d_k4s2_wgrad_from_conv3),
-    TS_PLAN_OP(ts_clip_rmsprop_step),
+    TS_PLAN_OP(ts_clip_rmsprop_step),       TS_PLAN_OP(ts_bn_sync_merge),
 };
 
 struct Call {

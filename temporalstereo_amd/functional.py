@@ -671,6 +671,28 @@ def conv_transpose2d_k4s2(x, weight, bias=None):
 
 
 BN_ACT = {None: 0, "SiLU": 1, "ReLU": 2}
+_COUNTS = {}
+
+
+def _count_const(n, device):
+    key = (float(n), device)
+    if key not in _COUNTS:
+        _COUNTS[key] = torch.full((1,), float(n), device=device, dtype=torch.float32)
+    return _COUNTS[key]
+
+
+def _all_gather_flat(out, part, group):
+    """out [world * n] <- every rank's part [n] (all_gather_into_tensor where the backend has it: RCCL; a list gather otherwise)."""
+    import torch.distributed as dist
+    try:
+        dist.all_gather_into_tensor(out, part, group=group)
+    except (RuntimeError, NotImplementedError):
+        world = dist.get_world_size(group)
+        parts = [out[i * part.numel():(i + 1) * part.numel()] for i in range(world)]
+        tmp = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(tmp, part, group=group)
+        for d, t in zip(parts, tmp):
+            d.copy_(t)
 
 
 import os as _os
@@ -712,29 +734,29 @@ class _ConvBNAct(torch.autograd.Function):
             ctx.meta = (family, cg, float(eps), int(act), bool(training), group, n_total, bias is not None)
             return out
         if training:
-            mean = torch.empty(C, device=y.device, dtype=torch.float32)
-            var = torch.empty_like(mean)
+            if group is not None:       # the statistics kernel writes straight into the record that is exchanged: [mean | var | count]
+                pack = torch.empty(2 * C + 1, device=y.device, dtype=torch.float32)
+                mean, var = pack[:C], pack[C:2 * C]
+            else:
+                mean = torch.empty(C, device=y.device, dtype=torch.float32)
+                var = torch.empty_like(mean)
             ws = torch.empty(_q("ts_bn_workspace_bytes", B, C, N), device=y.device, dtype=torch.uint8)
             local_update = group is None and running_mean is not None
             _lib.check(L.ts_bn_stats_fwd(_lib.ptr(y), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(running_mean if local_update else None),
                                          _lib.ptr(running_var if local_update else None), float(momentum), _lib.ptr(counter),
                                          _lib.ptr(ws), B, C, N, y.stride(0), y.stride(1), _stream()), "ts_bn_stats_fwd")
             if group is not None:
+                # one all_gather of [mean | var | count], merged on the device (ts_bn_sync_merge); the total count stays there too
                 import torch.distributed as dist
                 world = dist.get_world_size(group)
-                pack = torch.cat([mean, var, mean.new_full((1,), n_total)])
-                allp = [torch.empty_like(pack) for _ in range(world)]
-                dist.all_gather(allp, pack, group=group)
-                allp = torch.stack(allp)
-                cnt = allp[:, -1:]
-                n_total_t = cnt.sum()
-                gmean = (allp[:, :C] * cnt).sum(0) / n_total_t
-                var = ((allp[:, C:2 * C] + (allp[:, :C] - gmean) ** 2) * cnt).sum(0) / n_total_t
-                mean = gmean
-                n_total = float(n_total_t)           # (one host read per layer; the sync path is collective-bound anyway)
-                if running_mean is not None:
-                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(var * (n_total / max(n_total - 1.0, 1.0)), alpha=momentum)
+                pack[2 * C:].copy_(_count_const(n_total, y.device))
+                allp = torch.empty(world * (2 * C + 1), device=y.device, dtype=torch.float32)
+                _all_gather_flat(allp, pack, group)
+                mean, var = torch.empty_like(mean), torch.empty_like(var)
+                inv_n = torch.empty(1, device=y.device, dtype=torch.float32)
+                _lib.check(L.ts_bn_sync_merge(_lib.ptr(allp), world, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                              float(momentum), _lib.ptr(inv_n), _stream()), "ts_bn_sync_merge")
+                n_total = inv_n                       # a device scalar from here on (backward scales its sums with it)
         else:
             mean, var = running_mean, running_var
         _lib.check(L.ts_bn_apply_act_fwd(_lib.ptr(y), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out),
@@ -766,15 +788,17 @@ class _ConvBNAct(torch.autograd.Function):
                                           g.stride(1), eps, act, _stream()), "ts_bn_act_bwd_reduce")
         ggamma, gbeta = (s2, s1) if gamma is not None else (None, None)          # local sums: the gradient exchange averages them
         t1, t2 = s1, s2
+        count = n_total
         if training and group is not None:
             import torch.distributed as dist
             pack = torch.cat([s1, s2])
             dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
-            t1, t2 = pack[:C].contiguous(), pack[C:].contiguous()
+            pack = pack * n_total                                    # n_total is 1 / (global count) on the device here: pre-scaled sums,
+            t1, t2, count = pack[:C], pack[C:], 1.0                  # the kernel's own division is by 1 (no host read of a count)
         dy = torch.empty_like(y)
         _lib.check(L.ts_bn_act_bwd_apply(_lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta),
                                          _lib.ptr(t1), _lib.ptr(t2), _lib.ptr(dy), B, C, N, y.stride(0), y.stride(1), g.stride(0),
-                                         g.stride(1), eps, act, int(training), n_total, _stream()), "ts_bn_act_bwd_apply")
+                                         g.stride(1), eps, act, int(training), count, _stream()), "ts_bn_act_bwd_apply")
         return _ConvBNAct._conv_backward(ctx, x, weight, dy, family, cg, has_bias, (ggamma, gbeta))
 
     @staticmethod

@@ -1,0 +1,78 @@
+"""GPU, two ranks: the data-parallel training step of the real aggregator (SyncBatchNorm between the HIP BatchNorm kernels + bucketed
+gradient all-reduce from backward hooks + fused clip / RMSprop) equals the single-process step on the batch of two.
+Counterpart of the reference's `pl.Trainer(strategy='ddp', sync_batchnorm=True)` (projects/TemporalStereo/dist_train.py:82-96).
+A single-GPU box cannot run RCCL with two ranks (one rank per device), so the collectives go over gloo with both ranks on device 0
+(the test hooks of bench.py: TS_BENCH_BACKEND / TS_BENCH_DEVICE); the multi-GPU RCCL run is the driver's."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _env():
+    env = dict(os.environ, TS_BENCH_BACKEND="gloo", TS_BENCH_DEVICE="0", MIOPEN_FIND_MODE="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_two_rank_step_equals_single_process_batch_of_two(tmp_path):
+    out = str(tmp_path / "rank0.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), out]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = np.load(out)
+    # single process, batch of two, plain BatchNorm (= SyncBatchNorm over both ranks' samples), no buckets
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_gpu_worker as wk
+    from temporalstereo_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    net = wk.build(dev)
+    step = TrainStep(net, max_disp=64, local_map_size=1)
+    frames, gt, K, poses = wk.scene(dev, [0, 1])
+    losses = [float(step(frames, gt, K, poses))]
+    grads1 = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters() if p.grad is not None}
+    losses.append(float(step(frames, gt, K, poses)))
+    grads2 = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters() if p.grad is not None}
+    assert int(got["launched_in_backward"]) > 0                  # from the second step on the buckets really overlap backward
+    assert sorted("g::" + k for k in grads2) == sorted(k for k in got.files if k.startswith("g::"))
+    # (each rank's loss is the mean over its own sample; the mean of the two is the batch loss: all pixels of a planted scene are valid)
+    for tag, grads, bar in (("g1::", grads1, 1e-3), ("g::", grads2, 3e-2)):     # step 2 sits behind an RMSprop update, ~ lr * sign(g) on its first step
+        top = max(float(np.linalg.norm(v)) for v in grads.values())
+        worst, where = 0.0, None
+        for k, v in grads.items():
+            n = float(np.linalg.norm(v))
+            if n < 1e-5 * top:
+                continue                                         # biases in front of BatchNorm: exact gradient 0, rounding noise
+            e = float(np.linalg.norm(got[tag + k] - v)) / n
+            if e > worst:
+                worst, where = e, k
+        assert worst < bar, (tag, where, worst)
+    for k, b in net.named_buffers():
+        if b.dtype.is_floating_point:
+            ref = b.detach().cpu().numpy()
+            assert np.abs(got["b::" + k] - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-3), k
+
+
+def test_bench_train_mode_runs_on_two_ranks():
+    """`bench.py --mode train --gpus 2` (self-spawned ranks) prints one JSON line with SyncBatchNorm on and buckets launched during backward."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "3", "--warmup", "2"],
+                       env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    tr = line["training"]
+    assert line["n_gpus"] == 2 and tr["sync_bn"] is True and tr["buckets_launched_in_backward"] > 0
+    assert np.isfinite(tr["final_loss"]) and tr["ms_per_step"] > 0

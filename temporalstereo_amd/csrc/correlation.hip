@@ -90,6 +90,129 @@ correlation_bwd_kernel(const float* __restrict__ other, const float* __restrict_
   grad[i] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row correlation on the matrix cores (round 3; the kernel above stays for 2-D patches and as the small-shape fallback).
+//
+// For a patch of height 1 -- `correlation1d`, the literal shift-and-correlate over D disparities -- the volume of one image row is a
+// BAND of the Gram matrix  P[x][x'] = sum_c L[c][x] * R[c][x']:  out[k][x] = P[x][x + dxmin + k].  P is a dense K = C contraction,
+// so it goes to v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation): a workgroup owns 64 pixels of one row, wave w
+// the 16-pixel block w; per 32-channel chunk the left strip [32][64] and the right span [32][64 + keep - 1 (+pad)] are staged in
+// LDS once (zeros outside the image) and each wave multiplies its A fragments against T = ceil((15 + keep) / 16) right tiles --
+// 16 / (16 + keep) of the products fall outside the band (8 % at D = 192).  The accumulator tiles are then written through LDS
+// into [k][x] order (a lane of an MFMA tile holds one x' and four x, i.e. four DIFFERENT planes: stored directly, every lane of
+// a store would touch its own cache line) and leave as 256-byte plane rows.
+// Against the lane-per-output form above (C x D scalar loads per output quad, 1.2-1.4 TFLOP/s): 12-18x, see
+// profiles/r03_stress_bench.txt.  Phase ablation at [4,32,192,272,480] (249 us): staging ~95 us, matrix work ~53 us (= its share of
+// the f32 MFMA peak), scatter ~23 us, plane-row stores ~80-100 us (401 MB: the HBM floor) -- the phases of a workgroup run one after
+// the other and three co-resident workgroups overlap them only partly.  Tried without gain: 16-byte staging loads from a
+// 4-aligned span start, dealing the strips of a row to one XCD (its L2 then serves the shared right row), 16-channel chunks with
+// the output tile in 64-plane passes (22 KB of LDS, 5+ workgroups per CU: SLOWER, 320 us -- three passes over the accumulators).
+constexpr int CX = 64;        // pixels per workgroup
+constexpr int CKC = 32;       // channels per staged chunk
+constexpr int CPL = 80;       // LDS pitch of the left strip  (== 16 mod 32: the four channel rows of an A fragment hit disjoint banks)
+constexpr int CPO = 69;       // LDS pitch of the [k][x] output tile (== 5 mod 32: a tile store is 2-way conflicted, the minimum)
+
+template <int TMAX>
+__global__ void __launch_bounds__(256)
+corr_row_mfma_kernel(const float* __restrict__ L, const float* __restrict__ R, float* __restrict__ out, const Corr p, int T, int pitchR) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sL = lds;                         // [CKC][CPL]
+  float* sR = lds + CKC * CPL;             // [CKC][pitchR]
+  const int xs0 = blockIdx.x * CX, y = blockIdx.y, b = blockIdx.z;
+  const int dxmin = -(p.pW / 2);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, kq = lane >> 4;
+  const size_t HW = static_cast<size_t>(p.H) * p.W;
+  const float* Lrow = L + static_cast<size_t>(b) * p.C * HW + static_cast<size_t>(y) * p.W;
+  const float* Rrow = R + static_cast<size_t>(b) * p.C * HW + static_cast<size_t>(y) * p.W;
+  const int span = 48 + 16 * T;            // right pixels the four waves touch, starting at xs0 + dxmin
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f acc[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < p.C; c0 += CKC) {
+    __syncthreads();                       // the previous chunk's fragments have been read
+    // Loads are unconditional (clamped column / channel, masked afterwards) and issued eight deep: a load behind a condition is
+    // issued alone and waited for alone, which made the first version of this loop 1.5x slower overall.
+    const int nch = min(CKC, p.C - c0);
+    {   // left strip: column tid & 63, channels (tid >> 6) + 4 m
+      const int xl = tid & 63, cb = tid >> 6;
+      const int x = xs0 + xl;
+      const bool okx = x < p.W;
+      const float* src = Lrow + static_cast<size_t>(c0) * HW + min(x, p.W - 1);
+#pragma unroll
+      for (int m = 0; m < CKC / 4; ++m) {
+        const int c = cb + 4 * m;
+        const float v = src[static_cast<size_t>(min(c, nch - 1)) * HW];
+        sL[c * CPL + xl] = (okx && c < nch) ? v : 0.f;
+      }
+    }
+    for (int rl = tid; rl < span; rl += 256) {      // right span: one column per thread, all channels of the chunk
+      const int x = xs0 + dxmin + rl;
+      const bool okx = x >= 0 && x < p.W;
+      const float* src = Rrow + static_cast<size_t>(c0) * HW + min(max(x, 0), p.W - 1);
+#pragma unroll
+      for (int c8 = 0; c8 < CKC; c8 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[static_cast<size_t>(min(c8 + u, nch - 1)) * HW];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sR[(c8 + u) * pitchR + rl] = (okx && c8 + u < nch) ? v[u] : 0.f;
+      }
+    }
+    __syncthreads();
+    float a[CKC / 4];
+#pragma unroll
+    for (int q = 0; q < CKC / 4; ++q) a[q] = sL[(4 * q + kq) * CPL + 16 * wave + j];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < T) {
+        const float* rb = sR + kq * pitchR + 16 * wave + 16 * t + j;
+#pragma unroll
+        for (int q = 0; q < CKC / 4; ++q) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], rb[4 * q * pitchR], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // ---- band of the Gram tiles -> [k][x] in LDS (over the input tiles), then plane rows
+  __syncthreads();
+  float* sO = lds;                          // [keep][CPO]
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * kq + r;            // pixel of the wave's block; j = right pixel of tile t
+        const int k = 16 * t + j - i;        // (x' - x) - dxmin
+        if (k >= 0 && k < p.keep) sO[k * CPO + 16 * wave + i] = acc[t][r];
+      }
+    }
+  }
+  __syncthreads();
+  float* op = out + ((static_cast<size_t>(b) * p.keep) * p.H + y) * p.W + xs0;
+  const bool vec = (p.W & 3) == 0;
+  for (int i = tid; i < p.keep * (CX / 4); i += 256) {
+    const int k = i >> 4, xq = (i & 15) * 4;
+    if (xs0 + xq >= p.W) continue;
+    const float* sp = sO + k * CPO + xq;
+    float4 v = make_float4(lrelu(sp[0]), lrelu(sp[1]), lrelu(sp[2]), lrelu(sp[3]));
+    float* dst = op + static_cast<size_t>(k) * HW + xq;
+    if (vec) {
+      *reinterpret_cast<float4*>(dst) = v;
+    } else {
+      dst[0] = v.x;
+      if (xs0 + xq + 1 < p.W) dst[1] = v.y;
+      if (xs0 + xq + 2 < p.W) dst[2] = v.z;
+      if (xs0 + xq + 3 < p.W) dst[3] = v.w;
+    }
+  }
+}
+
+// 0: the shape goes to the lane-per-output kernel
+int corr_row_tiles(const Corr& p) {
+  if (p.pH != 1 || p.keep > 241 || p.C < 4 || p.W < 16) return 0;
+  return (15 + p.keep + 15) / 16;
+}
+
 int check(const Corr& p) {
   TS_REQUIRE(p.B > 0 && p.C > 0 && p.H > 0 && p.W > 0, TS_ERR_SHAPE, "correlation: non-positive size");
   TS_REQUIRE(p.pH >= 1 && p.pW >= 1 && (p.pH & 1) && (p.pW & 1), TS_ERR_SHAPE, "correlation: patch sizes must be odd and >= 1");
@@ -104,6 +227,20 @@ extern "C" int ts_correlation_fwd(const float* left, const float* right, float* 
   const Corr p{B, C, H, W, patch_h, patch_w, keep};
   if (int rc = check(p)) return rc;
   TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(out);
+  if (const int T = corr_row_tiles(p)) {            // patch height 1: a band of the row's Gram matrix, on the matrix cores
+    TS_REQUIRE(H <= 65535 && B <= 65535, TS_ERR_UNSUPPORTED, "correlation: grid too large");
+    const int span = 48 + 16 * T;
+    int pitchR = span;
+    while ((pitchR & 31) != 16) ++pitchR;
+    const size_t in_b = static_cast<size_t>(CKC) * (CPL + pitchR) * 4, out_b = static_cast<size_t>(keep) * CPO * 4;
+    const size_t shm = in_b > out_b ? in_b : out_b;
+    const dim3 grid((W + CX - 1) / CX, H, B);
+    hipStream_t st = ts::as_stream(stream);
+    if (T <= 4) hipLaunchKernelGGL(corr_row_mfma_kernel<4>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR);
+    else if (T <= 8) hipLaunchKernelGGL(corr_row_mfma_kernel<8>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR);
+    else hipLaunchKernelGGL(corr_row_mfma_kernel<16>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR);
+    return ts::launched("corr_row_mfma_kernel");
+  }
   const long long n = static_cast<long long>(B) * keep * H * ((W + 3) / 4);
   hipLaunchKernelGGL(correlation_fwd_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ts::as_stream(stream),
                      left, right, out, p);

@@ -61,3 +61,18 @@ def test_correlation_vs_oracle_forward_and_backward(case):
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(lg.grad.cpu().numpy(), lr.grad.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(rg.grad.cpu().numpy(), rr.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,C,H,W,D", [(1, 32, 6, 240, 48), (2, 64, 3, 120, 192), (1, 20, 4, 77, 17), (1, 8, 2, 64, 241), (1, 4, 3, 16, 1)])
+def test_row_correlation_on_the_matrix_cores_vs_oracle(B, C, H, W, D):
+    """The MFMA form of correlation1d (a band of the row's Gram matrix, csrc/correlation.hip) at sizes where every tile / strip /
+    channel-chunk edge occurs: ragged widths, C not a multiple of the 32-channel chunk, D from 1 to the kernel's limit."""
+    import temporalstereo_amd as ts
+    from oracle import correlation as oc
+    dev = _dev()
+    l = torch.from_numpy(synth.normal(400 + D, "l", (B, C, H, W)))
+    r = torch.from_numpy(synth.normal(400 + D, "r", (B, C, H, W)))
+    want = oc.correlation1d(l.double(), r.double(), D)
+    got = ts.correlation1d(l.to(dev), r.to(dev), D)
+    scale = float(want.abs().max())
+    assert float((got.cpu().double() - want).abs().max()) < 2e-6 * scale * (C ** 0.5)

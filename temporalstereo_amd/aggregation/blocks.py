@@ -105,8 +105,13 @@ class ConvexUpsample(nn.Module):
         r, k = self.upscale_factor, self.window_size
         if k % 2 != 1:
             raise ValueError("window_size must be odd, got %d" % k)
-        if _on_hip(input):        # conv 3x3 + BatchNorm + SiLU as one fused node, the 1x1 conv on the (k,1,1) family
-            m0, bn, m3 = self.mask[0], self.mask[1], self.mask[3]
+        m0, bn, m3 = self.mask[0], self.mask[1], self.mask[3]
+        # the HIP form needs both convolutions inside the kernels' channel limits (k*k*r*r <= 64 logits: the shipped r = 2, k = 3
+        # has 36) and a BatchNorm with a fixed momentum; anything else takes the framework's modules
+        hip_ok = _on_hip(input) and bn.momentum is not None and \
+            TF.conv3d_supported(tuple(m0.weight.unsqueeze(2).shape), (1, 1, 1), (0, 1, 1), (1, 1, 1), 1) == "hw" and \
+            TF.conv3d_supported(tuple(m3.weight.unsqueeze(2).shape), (1, 1, 1), (0, 0, 0), (1, 1, 1), 1) == "d"
+        if hip_ok:                # conv 3x3 + BatchNorm + SiLU as one fused node, the 1x1 conv on the (k,1,1) family
             m = TF.conv_bn_act(input.unsqueeze(2), m0.weight.unsqueeze(2), m0.bias, bn, "SiLU", "hw", (1, 1, False))
             logits = TF.conv3d(m, m3.weight.unsqueeze(2), m3.bias, (1, 1, 1), (0, 0, 0), (1, 1, 1)).squeeze(2)
             if k == 3 and C == 1:             # softmax + 3x3 gather + weighted sum: one kernel each way

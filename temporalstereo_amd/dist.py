@@ -182,6 +182,7 @@ class GradientBuckets:
             self._ready.append(0)
         self._handles = [None] * len(self.buckets)
         self._fired = set()
+        self._next = 0                        # buckets are all-reduced strictly in index order (the same order on every rank)
 
     def paused(self):
         """Context manager: backward passes inside accumulate into .grad without communication."""
@@ -207,9 +208,14 @@ class GradientBuckets:
         bi, off = self._where[id(p)]
         self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
         self._ready[bi] += 1
-        if self._ready[bi] == len(self.buckets[bi]):
-            self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # Launch order must not depend on the rank: a data-dependent branch can make a parameter fire on one rank and not on another,
+        # and collectives issued in different orders on different ranks hang (or sum the wrong buffers).  So buckets go out strictly
+        # by index; a full bucket behind one that is not full yet waits for it (or for finish()).
+        while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
+            nb = self._next
+            self._handles[nb] = dist.all_reduce(self._flat[nb], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.launched_in_backward += 1
+            self._next += 1
 
     def finish(self):
         """Wait for every bucket, write the averaged gradients back."""
@@ -222,14 +228,12 @@ class GradientBuckets:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             used = [p for p, f in zip(self.params, flags.tolist()) if f > 0]
             used_ids = {id(p) for p in used}
-        for bi, bucket in enumerate(self.buckets):
+        for bi, bucket in enumerate(self.buckets):            # the rest, in index order again
             if self._handles[bi] is None:
                 for p in bucket:
-                    _, off = self._where[id(p)]
-                    if p.grad is None:
+                    if id(p) not in self._fired:              # no gradient on this rank in this step: contributes zero (a .grad left
+                        _, off = self._where[id(p)]           # over from an earlier step is stale and must not be averaged in)
                         self._flat[bi][off:off + p.numel()].zero_()
-                    elif id(p) not in self._fired or self._ready[bi] < len(bucket):
-                        self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
                 self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for bi, bucket in enumerate(self.buckets):
             self._handles[bi].wait()
@@ -246,6 +250,7 @@ class GradientBuckets:
             self._handles[bi] = None
             self._ready[bi] = 0
         self._fired = set()
+        self._next = 0
         if first:
             self._unused_known = True
             if len(used) != len(self.params):

@@ -98,6 +98,8 @@ class _NormAct:
         bn = self.norm
         if not isinstance(bn, nn.modules.batchnorm._BatchNorm) or not bn.affine or not bn.track_running_stats:
             return False
+        if bn.momentum is None:           # cumulative moving average: 1 / num_batches_tracked per step -- the framework's module does that
+            return False
         if self.activation is None:
             return None
         if isinstance(self.activation, nn.SiLU):

@@ -183,3 +183,37 @@ def test_real_aggregator_two_ranks_sync_batchnorm_matches_single_process(tmp_pat
             assert int(got[k]) == int(want[k]), k
             continue
         torch.testing.assert_close(got[k], want[k], rtol=1e-7, atol=1e-9, msg=lambda m, k=k: "%s: %s" % (k, m))
+
+
+def _branch_worker(rank, world, port, out):
+    """A parameter that takes part on one rank only from the second step on (data-dependent branch): the buckets must still go
+    out in the same order on both ranks, the absent rank contributing zeros."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from temporalstereo_amd import dist as tsd
+    tsd.init_distributed("gloo")
+    torch.manual_seed(0)
+    a, b, c = (nn.Parameter(torch.randn(4, 4)) for _ in range(3))
+    gb = tsd.GradientBuckets([a, b, c], bucket_bytes=16)          # one bucket per parameter
+    x = torch.ones(2, 4) * (rank + 1)
+    for step in range(3):
+        for p in (a, b, c):
+            p.grad = None
+        y = x @ a + x @ c
+        if step == 0 or rank == 0:                                   # `b` is used everywhere on the first step, then on rank 0 only
+            y = y + x @ b
+        y.sum().backward()
+        gb.finish()
+    if rank == 0:
+        torch.save({"a": a.grad.clone(), "b": b.grad.clone(), "c": c.grad.clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_buckets_keep_one_order_when_a_parameter_fires_on_one_rank_only(tmp_path):
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_branch_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    # d(sum(x @ p))/dp = column sums of x repeated: rank r contributes 2 * (r + 1) per entry; averaged over 2 ranks
+    assert torch.allclose(got["a"], torch.full((4, 4), (2 * 1 + 2 * 2) / 2.0))
+    assert torch.allclose(got["c"], torch.full((4, 4), (2 * 1 + 2 * 2) / 2.0))
+    assert torch.allclose(got["b"], torch.full((4, 4), (2 * 1 + 0.0) / 2.0))      # rank 1 did not use it: zeros, not a stale gradient

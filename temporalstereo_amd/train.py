@@ -173,9 +173,13 @@ class TrainStep:
         self._g = self._static = self._loss = None
         self.timings = {}
         self._modules = list(net.modules())
-        # Kernel layouts of all convolution weights in one launch per step instead of ~280 (eager: 5 ms of host time, 28 -> 22.7 ms;
-        # replayed: ~270 launches of ~4.6 us, 1.2 ms of device time per step).  TS_TRAIN_GRAPH_LAYOUTS=0: round 2's choice for the
-        # replayed step (a layout launch in front of every convolution).
+        # Kernel layouts of all convolution weights in one launch per step instead of ~280: 5 ms of host time in the eager step
+        # (28 -> 22.7 ms).  NOT in the replayed step, measured again in round 3 (ms per replay): a layout launch in front of every
+        # convolution call 13.4; one launch per step 14.0-14.3; one launch per 16 / 32 / 64 consecutive requests, issued just ahead of
+        # them (so that the layouts are still in the Infinity Cache when read) 14.2 / 14.1 / 14.1.  The ~270 small launches are not what
+        # the replay waits for, and with kept layouts the convolution kernels themselves run ~7 % slower (rocprof: 4.42 vs 4.12 ms per
+        # step) -- the per-call buffers are one recycled block of the graph's pool, hot in every cache level.  TS_TRAIN_GRAPH_LAYOUTS=1
+        # selects the one-launch form for the A/B.
         self.layouts = TF.WeightLayouts() if (not self.graph or os.environ.get("TS_TRAIN_GRAPH_LAYOUTS", "0") != "0") else None
         # (Tried and dropped in round 3: the weight-gradient launches on a forked side stream inside the capture -- they depend only on
         # dy, 15 % of the step's device time, small grids.  The replayed graph got SLOWER, 15.0 vs 13.4 ms: forked captures replay

@@ -432,6 +432,11 @@ int ts_offset_head_bwd(const float* x, const float* grad_y, float* grad_x, long 
 int ts_space_to_depth2_fwd(const float* x, float* z, int B, int C, int H, int W, void* stream);
 int ts_deconv2d_k4s2_weight_to_conv3(const float* w, float* out, int Cin, int Cout, int cin_pad, void* stream);
 int ts_deconv2d_k4s2_wgrad_from_conv3(const float* dw3, float* dw, int Cin, int Cout, void* stream);
+/* eval-mode BatchNorm folded into the convolution epilogue for a whole step in one launch: table = n ts_bn_fold_entry in DEVICE memory;
+ * scale[c] = gamma / sqrt(var + eps), shift[c] = beta + (bias - mean) * scale for c < C, 0 for C <= c < pad (gamma / beta / bias may be NULL) */
+typedef struct ts_bn_fold_entry { const float* gamma; const float* beta; const float* mean; const float* var; const float* bias;
+                                  float* scale; float* shift; int C, pad; } ts_bn_fold_entry;
+int ts_bn_fold_many(const void* table, int n, float eps, void* stream);
 size_t ts_clip_rmsprop_workspace_bytes(int n_tensors);
 int ts_clip_rmsprop_step(const void* table, int n_tensors, float max_norm, float lr, float alpha, float eps,
                          void* workspace, size_t workspace_bytes, void* stream);

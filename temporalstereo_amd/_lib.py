@@ -43,6 +43,7 @@ SIGNATURES = {
     "ts_space_to_depth2_fwd": (c_int, [c_f32p] * 2 + [c_int] * 4 + [c_ptr]),
     "ts_deconv2d_k4s2_weight_to_conv3": (c_int, [c_f32p] * 2 + [c_int] * 3 + [c_ptr]),
     "ts_deconv2d_k4s2_wgrad_from_conv3": (c_int, [c_f32p] * 2 + [c_int] * 2 + [c_ptr]),
+    "ts_bn_fold_many": (c_int, [c_ptr, c_int, c_float, c_ptr]),
     "ts_clip_rmsprop_workspace_bytes": (c_size, [c_int]),
     "ts_clip_rmsprop_step": (c_int, [c_ptr, c_int] + [c_float] * 4 + [c_ptr, c_size, c_ptr]),
     "ts_topk_softargmax_fwd": (c_int, [c_f32p] * 7 + [c_int] * 5 + [c_ptr]),

@@ -91,6 +91,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_space_to_depth2_fwd),
     TS_PLAN_OP(ts_deconv2d_k4s2_weight_to_conv3), TS_PLAN_OP(ts_deconv2d_k4s2_wgrad_from_conv3),
     TS_PLAN_OP(ts_clip_rmsprop_step),       TS_PLAN_OP(ts_bn_sync_merge),
+    TS_PLAN_OP(ts_bn_fold_many),
 };
 
 struct Call {

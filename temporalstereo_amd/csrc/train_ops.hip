@@ -146,6 +146,28 @@ deconv4_wgrad_from_conv3_kernel(const float* __restrict__ dw3, float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------ BatchNorm folding (eval)
+// scale[c] = gamma / sqrt(var + eps), shift[c] = beta + (bias - mean) * scale   (c < C; 0 beyond: the padded output channels)
+struct FoldEntry {          // == ts_bn_fold_entry of include/ts_hip.h (64 bytes)
+  const float* gamma; const float* beta; const float* mean; const float* var; const float* bias; float* scale; float* shift;
+  int C, pad;
+};
+static_assert(sizeof(FoldEntry) == 64, "table entry layout");
+
+__global__ void __launch_bounds__(64)
+bn_fold_many_kernel(const FoldEntry* __restrict__ table, float eps) {
+  const FoldEntry e = table[blockIdx.x];
+  for (int c = threadIdx.x; c < e.pad; c += 64) {
+    float s = 0.f, t = 0.f;
+    if (c < e.C) {
+      s = (e.gamma ? e.gamma[c] : 1.f) / sqrtf(e.var[c] + eps);
+      t = (e.beta ? e.beta[c] : 0.f) + ((e.bias ? e.bias[c] : 0.f) - e.mean[c]) * s;
+    }
+    e.scale[c] = s;
+    e.shift[c] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ clip + RMSprop
 struct OptEntry {           // == ts_opt_entry of include/ts_hip.h (32 bytes)
   float* param; const float* grad; float* square_avg; long long n;
@@ -255,6 +277,16 @@ extern "C" int ts_deconv2d_k4s2_wgrad_from_conv3(const float* dw3, float* dw, in
   TS_REQUIRE_PTR(dw3); TS_REQUIRE_PTR(dw);
   hipLaunchKernelGGL(deconv4_wgrad_from_conv3_kernel, dim3(grid_for(16ll * Cin * Cout, 256)), dim3(256), 0, ts::as_stream(stream), dw3, dw, Cin, Cout);
   return ts::launched("deconv4_wgrad_from_conv3_kernel");
+}
+
+// table: n entries of ts_bn_fold_entry in DEVICE memory; one launch folds every eval-mode BatchNorm of a step into the
+// per-channel scale / shift the convolution kernels apply in their epilogue (what aggregation/native.py does once per model,
+// here once per training step for the frames that run in eval mode: projects/TemporalStereo/TemporalStereo.py:268-274)
+extern "C" int ts_bn_fold_many(const void* table, int n, float eps, void* stream) {
+  TS_REQUIRE(n > 0 && n <= 65535, TS_ERR_SHAPE, "bn_fold_many: %d entries", n);
+  TS_REQUIRE_PTR(table);
+  hipLaunchKernelGGL(bn_fold_many_kernel, dim3(n), dim3(64), 0, ts::as_stream(stream), static_cast<const FoldEntry*>(table), eps);
+  return ts::launched("bn_fold_many_kernel");
 }
 
 extern "C" size_t ts_clip_rmsprop_workspace_bytes(int n_tensors) {

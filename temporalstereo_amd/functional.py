@@ -408,8 +408,9 @@ def _shift_vec(bias, n):
     return v
 
 
-def _hw_forward(x, weight, stride, dilation, transposed, bias=None):
-    """Raw Conv3d (1,3,3) [padding == dilation] / ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1 (+ bias)."""
+def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, act=0):
+    """Raw Conv3d (1,3,3) [padding == dilation] / ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1 (+ bias); with
+    `fold` = (scale, shift) the epilogue applies act(y * scale + shift) (an eval-mode BatchNorm folded in, bias included)."""
     _require_gpu(x, weight)
     x = x.contiguous()
     B, Cin, D, H, W = x.shape
@@ -426,9 +427,9 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None):
     L = _lib.lib()
     wsb = _q("ts_conv3d_hw_workspace_bytes", B, Cin, Cout, D, H, W, stride, int(transposed))
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
-    sh = _shift_vec(bias, _cpad(Cout))
-    rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(w_t), None, _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, D, H, W, stride, dilation,
-                            int(transposed), 0, 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
+    sc, sh = fold if fold is not None else (None, _shift_vec(bias, _cpad(Cout)))
+    rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(w_t), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, D, H, W, stride, dilation,
+                            int(transposed), int(act), 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
                             None, 0, _lib.ptr(ws), wsb, _stream())
     _lib.check(rc, "ts_conv3d_hw_fwd")
     return x, y, (B, Cin, Cout, D, H, W, stride, dilation, transposed)
@@ -491,8 +492,8 @@ class _Conv3dHW(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
-def _d_forward(x, weight, stride, dilation, padding, transposed, bias=None):
-    """Raw Conv3d (k,1,1) / ConvTranspose3d (3,1,1) stride 2, padding 1, output_padding 1 along D (+ bias)."""
+def _d_forward(x, weight, stride, dilation, padding, transposed, bias=None, fold=None, act=0):
+    """Raw Conv3d (k,1,1) / ConvTranspose3d (3,1,1) stride 2, padding 1, output_padding 1 along D (+ bias); `fold`: see _hw_forward."""
     _require_gpu(x, weight)
     x = x.contiguous()
     B, Cin, Din, H, W = x.shape
@@ -507,9 +508,9 @@ def _d_forward(x, weight, stride, dilation, padding, transposed, bias=None):
         w_t = _layout(weight, 1, 0)
         Dout = (Din + 2 * padding - dilation * (k - 1) - 1) // stride + 1
     y = torch.empty((B, Cout, Dout, H, W), device=x.device, dtype=torch.float32)
-    sh = _shift_vec(bias, _cpad(Cout))
-    rc = _lib.lib().ts_conv3d_d_fwd(_lib.ptr(x), _lib.ptr(w_t), None, _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, Din, H, W, k, stride,
-                                    dilation, padding, int(transposed), 0, 0.0, x.stride(0), x.stride(1), y.stride(0),
+    sc, sh = fold if fold is not None else (None, _shift_vec(bias, _cpad(Cout)))
+    rc = _lib.lib().ts_conv3d_d_fwd(_lib.ptr(x), _lib.ptr(w_t), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, Din, H, W, k, stride,
+                                    dilation, padding, int(transposed), int(act), 0.0, x.stride(0), x.stride(1), y.stride(0),
                                     y.stride(1), _stream())
     _lib.check(rc, "ts_conv3d_d_fwd")
     return x, y, (B, Cin, Cout, Din, H, W, k, stride, dilation, padding, transposed)
@@ -591,8 +592,9 @@ def _dc_conv3_weight(weight, out=None):
     return out
 
 
-def _dc_forward(x, weight, bias=None):
-    """Raw ConvTranspose2d(kernel 4, stride 2, padding 1) (+ bias) of UNet.deconv4 / deconv2 (module.py:453-457): ts_deconv2d_k4s2_fwd."""
+def _dc_forward(x, weight, bias=None, fold=None, act=0):
+    """Raw ConvTranspose2d(kernel 4, stride 2, padding 1) (+ bias) of UNet.deconv4 / deconv2 (module.py:453-457): ts_deconv2d_k4s2_fwd;
+    `fold`: see _hw_forward."""
     _require_gpu(x, weight)
     x = x.contiguous()
     B, Cin, H, W = x.shape
@@ -600,9 +602,12 @@ def _dc_forward(x, weight, bias=None):
     w_t = _layout(weight, 0, 1)                                                   # [ci][16 taps][pad(co)]
     pad = _cpad(Cout)
     y = torch.empty((B, Cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
-    sh = _shift_vec(bias, pad) if bias is not None else _zeros_const(pad, x.device)
-    rc = _lib.lib().ts_deconv2d_k4s2_fwd(_lib.ptr(x), _lib.ptr(w_t), _lib.ptr(_ones(pad, x.device)), _lib.ptr(sh), _lib.ptr(y),
-                                         B, Cin, Cout, H, W, 0, y.stride(0), _stream())
+    if fold is not None:
+        sc, sh = fold
+    else:
+        sc, sh = _ones(pad, x.device), (_shift_vec(bias, pad) if bias is not None else _zeros_const(pad, x.device))
+    rc = _lib.lib().ts_deconv2d_k4s2_fwd(_lib.ptr(x), _lib.ptr(w_t), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(y),
+                                         B, Cin, Cout, H, W, int(act), y.stride(0), _stream())
     _lib.check(rc, "ts_deconv2d_k4s2_fwd")
     return x, y, (B, Cin, Cout, H, W)
 
@@ -670,6 +675,60 @@ def conv_transpose2d_k4s2(x, weight, bias=None):
     return _Deconv2dK4S2.apply(x, weight, bias)
 
 
+class BNFolds:
+    """Eval-mode BatchNorm of a training step folded into the convolution epilogue.  The frames a training step runs in eval() /
+    no_grad (every previous frame, projects/TemporalStereo/TemporalStereo.py:268-274) need no batch statistics and no backward: their
+    conv -> BatchNorm -> activation is ONE convolution launch with a per-channel scale / shift, as in the inference engine -- but the
+    running statistics and the affine parameters move every step, so the folds are recomputed per step: `refresh()` does that for every
+    registered layer in one launch (ts_bn_fold_many).  Inside `with folds:` an eval-mode, gradient-free wrapper call takes the fused
+    form; its first call registers the layer (and folds it on the spot)."""
+
+    def __init__(self):
+        self.entries = {}           # key -> [gamma, beta, mean, var, bias, scale, shift, C, pad]
+        self._table, self._dirty, self._eps = None, False, None
+
+    def __enter__(self):
+        global _FOLDS
+        self._outer, _FOLDS = _FOLDS, self
+        return self
+
+    def __exit__(self, *exc):
+        global _FOLDS
+        _FOLDS = self._outer
+        return False
+
+    def _upload(self, entries):
+        import numpy as np
+        rec = np.zeros(len(entries), dtype=np.dtype([("gamma", "<u8"), ("beta", "<u8"), ("mean", "<u8"), ("var", "<u8"), ("bias", "<u8"),
+                                                      ("scale", "<u8"), ("shift", "<u8"), ("C", "<i4"), ("pad", "<i4")]))
+        for i, e in enumerate(entries):
+            rec[i] = tuple(t.data_ptr() if t is not None else 0 for t in e[:7]) + (e[7], e[8])
+        return torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(entries[0][5].device)
+
+    def get(self, gamma, beta, mean, var, bias, eps, cout):
+        key = (mean.data_ptr(), var.data_ptr(), gamma.data_ptr() if gamma is not None else 0, bias.data_ptr() if bias is not None else 0)
+        e = self.entries.get(key)
+        if e is None:
+            if self._eps is not None and float(eps) != self._eps:
+                return None                                     # one eps per table (every BatchNorm of the model has the default)
+            self._eps = float(eps)
+            pad = _cpad(cout)
+            e = [gamma, beta, mean, var, bias, torch.empty(pad, device=mean.device), torch.empty(pad, device=mean.device), int(cout), pad]
+            self.entries[key] = e
+            self._dirty = True
+            _lib.check(_lib.lib().ts_bn_fold_many(_lib.ptr(self._upload([e])), 1, self._eps, _stream()), "ts_bn_fold_many")
+        return e[5], e[6]
+
+    def refresh(self):
+        if not self.entries:
+            return
+        if self._dirty:
+            self._table = self._upload(list(self.entries.values()))
+            self._dirty = False
+        _lib.check(_lib.lib().ts_bn_fold_many(_lib.ptr(self._table), len(self.entries), self._eps, _stream()), "ts_bn_fold_many")
+
+
+_FOLDS = None
 BN_ACT = {None: 0, "SiLU": 1, "ReLU": 2}
 _COUNTS = {}
 
@@ -710,6 +769,14 @@ class _ConvBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, family, geom, eps, momentum, act, training, group,
                 counter=None):
+        if _FOLDS is not None and not training and not torch.is_grad_enabled() and running_mean is not None:
+            fold = _FOLDS.get(gamma, beta, running_mean, running_var, bias, eps, weight.shape[1] if (family == "dc" or geom[-1]) else weight.shape[0])
+            if fold is not None:        # eval frame of a training step: conv -> BatchNorm -> activation in the convolution's epilogue
+                if family == "hw":
+                    return _hw_forward(x, weight, geom[0], geom[1], geom[2], None, fold, act)[1]
+                if family == "dc":
+                    return _dc_forward(x, weight, None, fold, act)[1]
+                return _d_forward(x, weight, geom[0], geom[1], geom[2], geom[3], None, fold, act)[1]
         if family == "hw":
             x, y, cg = _hw_forward(x, weight, geom[0], geom[1], geom[2], bias)
         elif family == "dc":

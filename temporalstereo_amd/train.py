@@ -181,6 +181,9 @@ class TrainStep:
         # step) -- the per-call buffers are one recycled block of the graph's pool, hot in every cache level.  TS_TRAIN_GRAPH_LAYOUTS=1
         # selects the one-launch form for the A/B.
         self.layouts = TF.WeightLayouts() if (not self.graph or os.environ.get("TS_TRAIN_GRAPH_LAYOUTS", "0") != "0") else None
+        # the previous frames run in eval() / no_grad: their conv -> BatchNorm -> activation wrappers become one convolution launch
+        # each, the BatchNorm folded into its epilogue; all folds of the step are recomputed by one launch (functional.BNFolds)
+        self.folds = TF.BNFolds() if (on_gpu and os.environ.get("TS_TRAIN_BN_FOLDS", "1") != "0") else None
         # (Tried and dropped in round 3: the weight-gradient launches on a forked side stream inside the capture -- they depend only on
         # dy, 15 % of the step's device time, small grids.  The replayed graph got SLOWER, 15.0 vs 13.4 ms: forked captures replay
         # badly on ROCm 7.2, as the inference graph already showed)
@@ -194,9 +197,12 @@ class TrainStep:
     def _forward_backward(self, frames, gt, K, poses):
         """frames: list of (left_feats, right_feats, left_image, right_image), oldest first; poses[t] = (T_now, inv_T_past)."""
         net = self.net
-        with (self.layouts if self.layouts is not None else contextlib.nullcontext()):
+        with (self.layouts if self.layouts is not None else contextlib.nullcontext()), \
+                (self.folds if (self.folds is not None and len(frames) > 1) else contextlib.nullcontext()):
             if self.layouts is not None:
                 self.layouts.refresh()
+            if self.folds is not None and len(frames) > 1:
+                self.folds.refresh()
             info = {}
             for t, fr in enumerate(frames[:-1]):
                 self._set_training(False)

@@ -106,3 +106,44 @@ def test_clip_rmsprop_matches_the_framework_optimizer():
         assert abs(float(opt.total_norm()) - float(norm_ref)) < 1e-5 * float(norm_ref)
         for p, r in zip(ours, ref):
             assert _rel(p, r) < 1e-5
+
+
+def test_eval_batchnorm_folds_equal_the_unfused_wrappers():
+    """Inside `with BNFolds():` an eval-mode, gradient-free conv -> BatchNorm -> activation wrapper is ONE convolution launch with
+    the BatchNorm folded into its epilogue (the previous frames of a training step); it must equal the two-launch form, follow the
+    running statistics when they move (refresh), and leave train-mode / gradient-carrying calls alone."""
+    from temporalstereo_amd import functional as TF
+    from temporalstereo_amd.layers import Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    layers = [(Conv3d(16, 32, (1, 3, 3), 1, (0, 1, 1), bias=True, norm=("BN3d", 32), activation="SiLU"), (2, 16, 5, 12, 20)),
+              (Conv3d(32, 32, (3, 1, 1), (2, 1, 1), (1, 0, 0), bias=False, norm=("BN3d", 32), activation=None), (1, 32, 6, 9, 12)),
+              (ConvTranspose3d(16, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), (0, 1, 1), bias=False, norm=("BN3d", 16), activation="SiLU"), (1, 16, 3, 8, 10)),
+              (Conv2d(8, 64, 3, 1, 1, bias=False, norm=("BN", 64), activation="ReLU"), (2, 8, 16, 24)),
+              (ConvTranspose2d(32, 32, kernel_size=4, stride=2, padding=1, norm=("BN", 32), activation="ReLU"), (1, 32, 10, 12))]
+    folds = TF.BNFolds()
+    for m, shape in layers:
+        m = m.to(dev)
+        with torch.no_grad():
+            m.norm.running_mean.normal_(0, 0.3); m.norm.running_var.uniform_(0.5, 2.0)
+            m.norm.weight.uniform_(0.5, 1.5); m.norm.bias.normal_(0, 0.2)
+        m.eval()
+        x = torch.randn(*shape, device=dev)
+        with torch.no_grad():
+            want = m(x)
+            with folds:
+                got = m(x)
+            assert _rel(got, want) < 2e-6
+            m.norm.running_mean.add_(0.5)                       # the statistics move (a training step in between) ...
+            want2 = m(x)
+            with folds:
+                stale = m(x)
+                folds.refresh()                                 # ... and one launch re-folds every registered layer
+                got2 = m(x)
+            assert _rel(stale, want) < 2e-6 and _rel(got2, want2) < 2e-6 and _rel(want2, want) > 1e-3
+        n_before = len(folds.entries)
+        xg = x.clone().requires_grad_(True)
+        with folds:
+            y = m(xg)                                           # gradients enabled: the ordinary autograd node
+        assert y.requires_grad and len(folds.entries) == n_before
+    assert len(folds.entries) == len(layers)

@@ -193,9 +193,14 @@ finish_ratio_kernel(const float* __restrict__ ps, const float* __restrict__ pc, 
 __global__ void __launch_bounds__(256)
 smooth_l1_bwd_kernel(const float* __restrict__ est, const float* __restrict__ gt, const float* __restrict__ grad_loss,
                      const float* __restrict__ loss_count, float* __restrict__ gest, int B, int h, int w, int Hg, int Wg, float sh,
-                     float sw, float vs, float lo, float hi) {
+                     float sw, float vs, float lo, float hi, int lpp) {
+  // lpp lanes per low-resolution pixel (1 at equal sizes, else 16): its bilinear footprint is up to (2 Hg/h + 1)^2 full-resolution
+  // pixels -- 289 at the 1/8 level -- and one lane walking it alone left the 1/8 and 1/16 levels on 8-32 workgroups for ~95 us;
+  // the lanes take the footprint's rows in turn and meet in a fixed-order shuffle tree (still deterministic).
   const long long n = static_cast<long long>(B) * h * w;
-  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long gi = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long i = gi / lpp;
+  const int sub = static_cast<int>(gi - i * lpp);
   if (i >= n) return;
   const int x = static_cast<int>(i % w);
   const long long t = i / w;
@@ -218,7 +223,7 @@ smooth_l1_bwd_kernel(const float* __restrict__ est, const float* __restrict__ gt
   int ox1 = sw > 0.f ? static_cast<int>(ceilf((static_cast<float>(x) + 1.f) * iw)) : Wg - 1;
   oy0 = max(oy0, 0); oy1 = min(oy1, Hg - 1); ox0 = max(ox0, 0); ox1 = min(ox1, Wg - 1);
   float acc = 0.f;
-  for (int oy = oy0; oy <= oy1; ++oy) {
+  for (int oy = oy0 + sub; oy <= oy1; oy += lpp) {
     int y0, y1;
     float ly;
     lin_src(sh, oy, h, y0, y1, ly);
@@ -238,7 +243,8 @@ smooth_l1_bwd_kernel(const float* __restrict__ est, const float* __restrict__ gt
       acc += fminf(fmaxf(r, -1.f), 1.f) * wy * wx;
     }
   }
-  gest[i] = G * vs * acc;
+  for (int o = lpp >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (sub == 0) gest[i] = G * vs * acc;
 }
 
 inline float ac_scale(int in_size, int out_size) {
@@ -312,7 +318,8 @@ extern "C" int ts_disp_smooth_l1_bwd(const float* est, const float* gt, const fl
   TS_REQUIRE_PTR(est); TS_REQUIRE_PTR(gt); TS_REQUIRE_PTR(grad_loss); TS_REQUIRE_PTR(loss_count); TS_REQUIRE_PTR(grad_est);
   const long long n = static_cast<long long>(B) * h * w;
   const float vs = static_cast<float>(Wg) / static_cast<float>(w);
-  hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, ts::as_stream(stream), est, gt, grad_loss,
-                     loss_count, grad_est, B, h, w, Hg, Wg, ac_scale(h, Hg), ac_scale(w, Wg), vs, start_disp, max_disp);
+  const int lpp = (h == Hg && w == Wg) ? 1 : 16;
+  hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(blocks_for(n * lpp, 256)), dim3(256), 0, ts::as_stream(stream), est, gt, grad_loss,
+                     loss_count, grad_est, B, h, w, Hg, Wg, ac_scale(h, Hg), ac_scale(w, Wg), vs, start_disp, max_disp, lpp);
   return ts::launched("smooth_l1_bwd_kernel");
 }

@@ -614,14 +614,16 @@ def main():
             used = [k for k in k1_times if not (k[5] is True and k[:5] + ("warped",) in k1_times)]   # what the pipeline launched
             all_b = sum(k1_algorithmic_bytes(*k) for k in used)
             all_t = sum(k1_times[k] for k in used)
-            traffic = None
-            try:    # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected in-process)
-                with open(os.path.join(ROOT, "profiles", "r02_k1_hbm_traffic_pmc.json")) as fh:
-                    pm = json.load(fh)
-                if list(pm["workload_key"]) == list(pkey):
-                    traffic = pm["hbm_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
-                pass
+            traffic, traffic_file = None, None
+            for cand in ("r03_k1_hbm_traffic_pmc.json", "r02_k1_hbm_traffic_pmc.json"):
+                try:    # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected in-process)
+                    with open(os.path.join(ROOT, "profiles", cand)) as fh:
+                        pm = json.load(fh)
+                    if list(pm["workload_key"]) == list(pkey):
+                        traffic, traffic_file = pm["hbm_bytes_per_launch"], cand
+                        break
+                except (OSError, ValueError, KeyError):
+                    pass
             roofline = dict(bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
                             traffic=traffic,
                             measured="HIP events on the launch stream around %d back-to-back C-ABI launches on the pipeline's "
@@ -639,8 +641,8 @@ def main():
                             all_levels=dict(algorithmic_bytes=all_b, mean_us=all_t * 1e6,
                                             achieved=all_b / all_t / 1e9, frac=all_b / all_t / HBM_PEAK),
                             beyond_infinity_cache=k1_b4,
-                            traffic_source="profiles/r02_k1_hbm_traffic_pmc.json: FETCH_SIZE / WRITE_SIZE passes of this command under "
-                                           "rocprofv3 (tools/k1_traffic.py); a PMC pass cannot run inside the timed process")
+                            traffic_source="profiles/%s: FETCH_SIZE / WRITE_SIZE passes of this command under rocprofv3 (tools/k1_traffic.py, "
+                                           "tools/prof_r03.sh); a PMC pass cannot run inside the timed process" % traffic_file)
         result = dict(metric="stereo pairs/sec, FlyingThings3D 540x960 D=192 (aggregation hot path)",
                       value=pairs / elapsed, unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                       ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling="weak",

@@ -3,12 +3,14 @@ names (architecture/modeling/layers/basic_layers.py:10-103,151-235,289-388): `Co
 norm=(name, channels) | module | None, activation=str | (str, coeff) | module | None)`; parameters
 live at `<name>.weight/.bias` and `<name>.norm.*`.
 
-On the GPU the 3-D convolutions of the two separable families ((1,3,3) and (k,1,1), their stride-2 and
-transposed forms) run on the HIP kernels as autograd Functions (functional.conv3d / conv_transpose3d:
-forward, backward-data and backward-weight all on the matrix cores); BatchNorm and the activation stay
-framework ops here because train mode needs batch statistics / SyncBN collectives.
-The eval-mode execution with folded BatchNorm and fused activations happens one level up, in
-aggregation.native.  CPU tensors (host-logic tests) take torch's own convolution.
+On the GPU every wrapper of the model runs on the HIP kernels, forward and backward: the two separable 3-D families ((1,3,3) and
+(k,1,1), their stride-2 and transposed forms), 3x3 Conv2d (the (1,3,3) family on one plane) and ConvTranspose2d(4, stride 2, padding 1)
+(forward kernel of its own, backward as a 3x3 convolution of the space-to-depth gradient).  conv -> BatchNorm -> activation is ONE
+autograd node (functional.conv_bn_act): train-mode batch statistics from the BatchNorm kernels (exchangeable between launches:
+dist.SyncBatchNorm), running statistics in eval mode, and inside `functional.BNFolds` (the previous frames of a training step) the
+BatchNorm folded into the convolution's epilogue.  Whole-model eval execution with folded weights, fused concatenations and a recorded
+launch plan happens one level up, in aggregation.native.  CPU tensors (host-logic tests) take torch's own operators, as does anything
+outside the kernels' limits (groups, other kernel sizes, GroupNorm / InstanceNorm, momentum=None).
 """
 import torch
 import torch.nn as nn

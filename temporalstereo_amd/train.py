@@ -9,11 +9,14 @@
     backward -> gradient averaging over the ranks -> clip 0.1 -> RMSprop step                                   sceneflow.yaml:21-24
 
 The aggregation's inputs are the backbone's feature pyramids (out of scope: features are given, and `requires_grad` so that the
-cost volume's backward towards them runs as it would under the backbone).  Everything on the data path is a HIP kernel behind
-an autograd Function except train-mode BatchNorm / activations (framework ops; SyncBatchNorm of dist.py across ranks).
+cost volume's backward towards them runs as it would under the backbone).  Everything on the data path is a HIP kernel behind an
+autograd Function: cost volume, every conv -> BatchNorm -> activation wrapper (train-mode statistics from the BatchNorm kernels,
+exchanged across ranks by dist.SyncBatchNorm; the eval frames with the BatchNorm folded into the convolution), transposed 2-D
+convolutions, resize / pooling / sort + gather, candidates, offset head, upsamplers, both losses, clip + RMSprop.  What the framework
+still runs per step is ~90 small launches (torch.cat of volumes, fills, bias reductions, copies).
 
-Issued op by op the step is host-bound (~1900 launches through the framework's autograd per T=2 step; the kernels themselves
-take about 60 % of the wall time).  `graph=True` captures previous frames + state update + forward + losses + backward ONCE into a
+Issued op by op the step is host-bound (~1,160 launches through the framework's autograd per T=2 step: 19 ms against ~12 ms of
+device time).  `graph=True` captures previous frames + state update + forward + losses + backward ONCE into a
 hipGraph and replays it per step on static copies of the inputs (the step copies each call's tensors into them); gradient
 exchange, clipping and the optimizer stay outside.  ROCm 7.2's replay of pre-built AQL packets
 ("graph packet capture") computes garbage gradients from the second or third replay of a graph of this size on (loss finite,

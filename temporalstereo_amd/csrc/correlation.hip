@@ -11,6 +11,8 @@
 // One lane = 4 consecutive pixels of one output plane: the left values are one 16-byte load per channel (the same for every
 // plane of the pixel: served by L1 / L2 after the first plane), the shifted right values four clamped scalar loads selected
 // afterwards (no load sits behind a branch).  Backward: two gather kernels (deterministic, no atomics).
+#include <cstdlib>
+
 #include "ts_common.hpp"
 
 namespace {
@@ -101,8 +103,8 @@ correlation_bwd_kernel(const float* __restrict__ other, const float* __restrict_
 // 16 / (16 + keep) of the products fall outside the band (8 % at D = 192).  The accumulator tiles are then written through LDS
 // into [k][x] order (a lane of an MFMA tile holds one x' and four x, i.e. four DIFFERENT planes: stored directly, every lane of
 // a store would touch its own cache line) and leave as 256-byte plane rows.
-// Against the lane-per-output form above (C x D scalar loads per output quad, 1.2-1.4 TFLOP/s): 12-18x, see
-// profiles/r03_stress_bench.txt.  Phase ablation at [4,32,192,272,480] (249 us): staging ~95 us, matrix work ~53 us (= its share of
+// Against the lane-per-output form above (C x D scalar loads per output quad, 1.2-1.4 TFLOP/s): 17-27x, see
+// profiles/r03_stress_bench.txt.  Phase ablation at [4,32,192,272,480] (249 us before the buffer-load staging, 221 us with it): staging ~95 us, matrix work ~53 us (= its share of
 // the f32 MFMA peak), scatter ~23 us, plane-row stores ~80-100 us (401 MB: the HBM floor) -- the phases of a workgroup run one after
 // the other and three co-resident workgroups overlap them only partly.  Tried without gain: 16-byte staging loads from a
 // 4-aligned span start, dealing the strips of a row to one XCD (its L2 then serves the shared right row), 16-channel chunks with
@@ -113,96 +115,122 @@ constexpr int CPL = 80;       // LDS pitch of the left strip  (== 16 mod 32: the
 constexpr int CPO = 69;       // LDS pitch of the [k][x] output tile (== 5 mod 32: a tile store is 2-way conflicted, the minimum)
 
 template <int TMAX>
-__global__ void __launch_bounds__(256)
-corr_row_mfma_kernel(const float* __restrict__ L, const float* __restrict__ R, float* __restrict__ out, const Corr p, int T, int pitchR) {
+__global__ void __launch_bounds__(256, TMAX > 8 ? 2 : 3)
+corr_row_mfma_kernel(const float* __restrict__ L, const float* __restrict__ R, float* __restrict__ out, const Corr p, int T, int pitchR,
+                     int rows_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sL = lds;                         // [CKC][CPL]
   float* sR = lds + CKC * CPL;             // [CKC][pitchR]
-  const int xs0 = blockIdx.x * CX, y = blockIdx.y, b = blockIdx.z;
+  float* sO = lds;                         // [keep][CPO]: the output tile lives over the input tiles
+  constexpr int NCOL = TMAX > 8 ? 2 : 1;   // right-span columns per thread (span <= 48 + 16 * TMAX)
+  const int xs0 = blockIdx.x * CX, y_first = blockIdx.y * rows_per_wg, b = blockIdx.z;
+  const int y_end = min(y_first + rows_per_wg, p.H);
   const int dxmin = -(p.pW / 2);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, kq = lane >> 4;
   const size_t HW = static_cast<size_t>(p.H) * p.W;
-  const float* Lrow = L + static_cast<size_t>(b) * p.C * HW + static_cast<size_t>(y) * p.W;
-  const float* Rrow = R + static_cast<size_t>(b) * p.C * HW + static_cast<size_t>(y) * p.W;
+  const float* Lb = L + static_cast<size_t>(b) * p.C * HW;
+  const float* Rb = R + static_cast<size_t>(b) * p.C * HW;
   const int span = 48 + 16 * T;            // right pixels the four waves touch, starting at xs0 + dxmin
+  const int nchunk = (p.C + CKC - 1) / CKC;
   typedef float v4f __attribute__((ext_vector_type(4)));
   v4f acc[TMAX];
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < p.C; c0 += CKC) {
-    __syncthreads();                       // the previous chunk's fragments have been read
-    // Loads are unconditional (clamped column / channel, masked afterwards) and issued eight deep: a load behind a condition is
-    // issued alone and waited for alone, which made the first version of this loop 1.5x slower overall.
-    const int nch = min(CKC, p.C - c0);
-    {   // left strip: column tid & 63, channels (tid >> 6) + 4 m
-      const int xl = tid & 63, cb = tid >> 6;
-      const int x = xs0 + xl;
-      const bool okx = x < p.W;
-      const float* src = Lrow + static_cast<size_t>(c0) * HW + min(x, p.W - 1);
+  // this thread's share of a (row, 32-channel chunk) step: left column tid & 63 of channels (tid >> 6) + 4 m, right columns tid (+ 256)
+  // of every channel.  Buffer loads: the batch item's map behind one descriptor, the lane's part of the address ONE 32-bit offset
+  // (column, for the left strip also its channel phase), the step's part (row, chunk, channel) the scalar offset.  A column outside
+  // the image gets an out-of-range offset and a channel past the end falls off the descriptor: both read 0 -- nothing is masked at
+  // commit.  (Per-lane 64-bit pointers, hipcc's choice for plain loads here, cost 100 registers and spilled.)
+  constexpr unsigned OOR = 0x80000000u;                        // the host checks C * H * W * 4 < 2 GiB
+  const unsigned map_bytes = static_cast<unsigned>(p.C) * static_cast<unsigned>(HW) * 4u;
+  const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lb), 0, map_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Rb), 0, map_bytes, 0x00020000);
+  const int lxl = tid & 63, lcb = tid >> 6;
+  const unsigned lvo = (xs0 + lxl < p.W) ? (static_cast<unsigned>(lcb) * static_cast<unsigned>(HW) + static_cast<unsigned>(xs0 + lxl)) * 4u : OOR;
+  unsigned rvo[NCOL];
 #pragma unroll
-      for (int m = 0; m < CKC / 4; ++m) {
-        const int c = cb + 4 * m;
-        const float v = src[static_cast<size_t>(min(c, nch - 1)) * HW];
-        sL[c * CPL + xl] = (okx && c < nch) ? v : 0.f;
+  for (int n = 0; n < NCOL; ++n) {
+    const int x = xs0 + dxmin + tid + 256 * n;
+    rvo[n] = (tid + 256 * n < span && x >= 0 && x < p.W) ? static_cast<unsigned>(x) * 4u : OOR;
+  }
+  float vl[CKC / 4], vr[NCOL][CKC];
+  // The next step's loads are in flight while this step is multiplied, scattered and stored (a workgroup used to run its phases one
+  // after the other: staging was the longest of them).
+  const unsigned HWb = static_cast<unsigned>(HW) * 4u;
+  auto prefetch = [&](int y, int c0) {
+    const unsigned so = (static_cast<unsigned>(c0) * static_cast<unsigned>(HW) + static_cast<unsigned>(y) * static_cast<unsigned>(p.W)) * 4u;
+#pragma unroll
+    for (int m = 0; m < CKC / 4; ++m)
+      vl[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lrs, lvo, so + static_cast<unsigned>(4 * m) * HWb, 0));
+#pragma unroll
+    for (int c = 0; c < CKC; ++c)
+#pragma unroll
+      for (int n = 0; n < NCOL; ++n)
+        vr[n][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, rvo[n], so + static_cast<unsigned>(c) * HWb, 0));
+  };
+  if (y_first < y_end) prefetch(y_first, 0);
+#pragma unroll 1
+  for (int y = y_first; y < y_end; ++y) {
+#pragma unroll 1
+    for (int ck = 0; ck < nchunk; ++ck) {
+      const int c0 = ck * CKC;
+      __syncthreads();                     // the previous step's fragments / output rows have been read
+#pragma unroll
+      for (int m = 0; m < CKC / 4; ++m) sL[(lcb + 4 * m) * CPL + lxl] = vl[m];
+#pragma unroll
+      for (int n = 0; n < NCOL; ++n) {
+        if (tid + 256 * n < span) {
+#pragma unroll
+          for (int c = 0; c < CKC; ++c) sR[c * pitchR + tid + 256 * n] = vr[n][c];
+        }
+      }
+      __syncthreads();
+      if (ck + 1 < nchunk) prefetch(y, c0 + CKC);
+      else if (y + 1 < y_end) prefetch(y + 1, 0);
+      float a[CKC / 4];
+#pragma unroll
+      for (int q = 0; q < CKC / 4; ++q) a[q] = sL[(4 * q + kq) * CPL + 16 * wave + j];
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t < T) {
+          const float* rb = sR + kq * pitchR + 16 * wave + 16 * t + j;
+#pragma unroll
+          for (int q = 0; q < CKC / 4; ++q) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], rb[4 * q * pitchR], acc[t], 0, 0, 0);
+        }
       }
     }
-    for (int rl = tid; rl < span; rl += 256) {      // right span: one column per thread, all channels of the chunk
-      const int x = xs0 + dxmin + rl;
-      const bool okx = x >= 0 && x < p.W;
-      const float* src = Rrow + static_cast<size_t>(c0) * HW + min(max(x, 0), p.W - 1);
-#pragma unroll
-      for (int c8 = 0; c8 < CKC; c8 += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[static_cast<size_t>(min(c8 + u, nch - 1)) * HW];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sR[(c8 + u) * pitchR + rl] = (okx && c8 + u < nch) ? v[u] : 0.f;
-      }
-    }
+    // ---- band of the Gram tiles -> [k][x] in LDS (over the input tiles), then plane rows
     __syncthreads();
-    float a[CKC / 4];
-#pragma unroll
-    for (int q = 0; q < CKC / 4; ++q) a[q] = sL[(4 * q + kq) * CPL + 16 * wave + j];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
       if (t < T) {
-        const float* rb = sR + kq * pitchR + 16 * wave + 16 * t + j;
 #pragma unroll
-        for (int q = 0; q < CKC / 4; ++q) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], rb[4 * q * pitchR], acc[t], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * kq + r;            // pixel of the wave's block; j = right pixel of tile t
+          const int k = 16 * t + j - i;        // (x' - x) - dxmin
+          if (k >= 0 && k < p.keep) sO[k * CPO + 16 * wave + i] = acc[t][r];
+        }
+        acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
       }
     }
-  }
-  // ---- band of the Gram tiles -> [k][x] in LDS (over the input tiles), then plane rows
-  __syncthreads();
-  float* sO = lds;                          // [keep][CPO]
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t) {
-    if (t < T) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 4 * kq + r;            // pixel of the wave's block; j = right pixel of tile t
-        const int k = 16 * t + j - i;        // (x' - x) - dxmin
-        if (k >= 0 && k < p.keep) sO[k * CPO + 16 * wave + i] = acc[t][r];
+    __syncthreads();
+    float* op = out + ((static_cast<size_t>(b) * p.keep) * p.H + y) * p.W + xs0;
+    const bool vec = (p.W & 3) == 0;
+    for (int i = tid; i < p.keep * (CX / 4); i += 256) {
+      const int k = i >> 4, xq = (i & 15) * 4;
+      if (xs0 + xq >= p.W) continue;
+      const float* sp = sO + k * CPO + xq;
+      float4 v = make_float4(lrelu(sp[0]), lrelu(sp[1]), lrelu(sp[2]), lrelu(sp[3]));
+      float* dst = op + static_cast<size_t>(k) * HW + xq;
+      if (vec) {
+        *reinterpret_cast<float4*>(dst) = v;
+      } else {
+        dst[0] = v.x;
+        if (xs0 + xq + 1 < p.W) dst[1] = v.y;
+        if (xs0 + xq + 2 < p.W) dst[2] = v.z;
+        if (xs0 + xq + 3 < p.W) dst[3] = v.w;
       }
-    }
-  }
-  __syncthreads();
-  float* op = out + ((static_cast<size_t>(b) * p.keep) * p.H + y) * p.W + xs0;
-  const bool vec = (p.W & 3) == 0;
-  for (int i = tid; i < p.keep * (CX / 4); i += 256) {
-    const int k = i >> 4, xq = (i & 15) * 4;
-    if (xs0 + xq >= p.W) continue;
-    const float* sp = sO + k * CPO + xq;
-    float4 v = make_float4(lrelu(sp[0]), lrelu(sp[1]), lrelu(sp[2]), lrelu(sp[3]));
-    float* dst = op + static_cast<size_t>(k) * HW + xq;
-    if (vec) {
-      *reinterpret_cast<float4*>(dst) = v;
-    } else {
-      dst[0] = v.x;
-      if (xs0 + xq + 1 < p.W) dst[1] = v.y;
-      if (xs0 + xq + 2 < p.W) dst[2] = v.z;
-      if (xs0 + xq + 3 < p.W) dst[3] = v.w;
     }
   }
 }
@@ -210,6 +238,7 @@ corr_row_mfma_kernel(const float* __restrict__ L, const float* __restrict__ R, f
 // 0: the shape goes to the lane-per-output kernel
 int corr_row_tiles(const Corr& p) {
   if (p.pH != 1 || p.keep > 241 || p.C < 4 || p.W < 16) return 0;
+  if (static_cast<unsigned long long>(p.C) * p.H * p.W * 4ull >= 0x7ff00000ull) return 0;      // one buffer descriptor per batch item
   return (15 + p.keep + 15) / 16;
 }
 
@@ -234,11 +263,18 @@ extern "C" int ts_correlation_fwd(const float* left, const float* right, float* 
     while ((pitchR & 31) != 16) ++pitchR;
     const size_t in_b = static_cast<size_t>(CKC) * (CPL + pitchR) * 4, out_b = static_cast<size_t>(keep) * CPO * 4;
     const size_t shm = in_b > out_b ? in_b : out_b;
-    const dim3 grid((W + CX - 1) / CX, H, B);
+    // rows per workgroup (the next row's loads fly under this row's matrix work and stores): 2 where that still leaves four rounds of
+    // workgroups, else 1 -- measured at [4,32,272,480] D=192: 1 row 222 us, 2 rows 221, 4 rows 233, 8 rows 264 (longer chains of
+    // fewer, fatter workgroups lose more to the tail than the prefetch wins)
+    const long long strips_all = static_cast<long long>((W + CX - 1) / CX) * H * B;
+    int rpw = strips_all >= 8ll * 3 * ts::kNumCU ? 2 : 1;
+    static const int rpw_env = getenv("TS_CORR_ROWS") ? atoi(getenv("TS_CORR_ROWS")) : 0;
+    if (rpw_env > 0) rpw = rpw_env;
+    const dim3 grid((W + CX - 1) / CX, (H + rpw - 1) / rpw, B);
     hipStream_t st = ts::as_stream(stream);
-    if (T <= 4) hipLaunchKernelGGL(corr_row_mfma_kernel<4>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR);
-    else if (T <= 8) hipLaunchKernelGGL(corr_row_mfma_kernel<8>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR);
-    else hipLaunchKernelGGL(corr_row_mfma_kernel<16>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR);
+    if (T <= 4) hipLaunchKernelGGL(corr_row_mfma_kernel<4>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR, rpw);
+    else if (T <= 8) hipLaunchKernelGGL(corr_row_mfma_kernel<8>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR, rpw);
+    else hipLaunchKernelGGL(corr_row_mfma_kernel<16>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR, rpw);
     return ts::launched("corr_row_mfma_kernel");
   }
   const long long n = static_cast<long long>(B) * keep * H * ((W + 3) / 4);

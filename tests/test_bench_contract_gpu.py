@@ -29,5 +29,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] < 1.0 and r["traffic"] is not None
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    assert d["parity"]["delta_epe_px"] < d["parity"]["tolerance_px"] == 1e-3
+    par = d["parity"]
+    assert par["delta_epe_px"] < par["tolerance_px"] == 1e-3
+    # planted scene + trained checkpoint: a real ground truth, sub-pixel EPE on both sides, no tail of flipped pixels
+    assert par["ground_truth"].startswith("planted") and 0.01 < par["epe_px"] < 1.0 and abs(par["epe_px"] - par["epe_reference_px"]) < 1e-3
+    assert par["max_abs_diff_px"] < 0.05 and par["frac_pixels_off_by_0p01"] < 1e-4
     assert d["config"]["frames_in_flight"] == 3 and d["one_pass_at_a_time"]["value"] > 0
+    # protocol: the untimed conditioning phase is bounded and reported; the x6 engine is not slower than the f32-only one it is compared with
+    cond = d["conditioning"]
+    assert cond["passes"] >= 10 and cond["seconds"] <= cond["bound_s"] + 0.5
+    assert d["value"] > 0.95 * d["f32_mfma_only"]["value"]
+    tr = d["training"]
+    assert "error" not in tr and tr["ms_per_step"] > 0 and tr["hipgraph"]["ms_per_step"] < tr["ms_per_step"]

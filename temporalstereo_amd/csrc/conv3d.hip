@@ -958,7 +958,6 @@ wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* _
   constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : 256;
   constexpr int NIN = (MODE == MODE_HW) ? in_rows * in_cols : KT * 256;      // staged input pixels per channel
   constexpr int RQ = (NIN + 255) / 256;
-  constexpr int MAXIT = (KT * 4 + 3) / 4;                        // (tap, channel block) pairs per wave, worst case
   float* xs = lds;                                               // [NIN][CIP]
   float* dys = lds + NIN * CIP;                                  // [NPX][cop]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -967,9 +966,19 @@ wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* _
   const int cob = (p.Cout + 15) / 16, nitems = KT * cob;
   const unsigned HW = static_cast<unsigned>(p.H) * p.W, HWo = static_cast<unsigned>(p.Ho) * p.Wo;
 
-  v4f acc[MAXIT];
+  // Work split (round 3): a wave owns ONE 16-output-channel block and ALL taps of it, over a share of the tile's pixels -- 1, 2 or 4
+  // blocks across the waves, the pixels split 4, 2 or 1 ways.  Per 4-pixel step that is one dY fragment and KT input fragments for
+  // KT MFMAs into KT independent accumulators: (1 + KT) / KT LDS reads per MFMA and no dependent MFMA chain (the first version dealt
+  // (tap, block) pairs to the waves: two LDS reads per MFMA, every MFMA of a pair waiting for the one before it).  Worth 4 % on the
+  // largest layer (184 -> 177 us): what bounds this kernel is its staging -- 136-byte runs of a 34-pixel haloed tile row per channel
+  // plane, i.e. half-used cache lines on 264 MB of reads at the 1/4 level -- not the matrix phase; prefetching the next tile into
+  // registers under the MFMAs made it SLOWER (227 us: 143 VGPRs, one workgroup less per CU).
+  const int cbsplit = cob >= 3 ? 4 : cob, pxsplit = 4 / cbsplit;
+  const int cb = wave % cbsplit, part_px = wave / cbsplit;
+  const bool working = cb < cob;
+  v4f acc[KT];
 #pragma unroll
-  for (int i = 0; i < MAXIT; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < KT; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int sp = tile % p.tiles_per_plane;
@@ -1028,35 +1037,58 @@ wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* _
       }
     }
     __syncthreads();
-    // ---- this wave's (tap, channel block) pairs over the tile's pixels, four pixels per MFMA
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int item = wave + 4 * it;
-      if (item >= nitems) break;
-      const int tap = item / cob, cb = item - tap * cob;
-      int toff;
-      if (MODE == MODE_HW) toff = ((tap / 3) * DL * in_cols + (tap % 3) * DL);
-      else toff = tap * 256;
+    // ---- this wave's channel block: all taps over its share of the tile's pixels, four pixels per MFMA
+    if (working) {
+      const int nstep = (NPX / 4) / pxsplit, s0 = part_px * nstep;
       const float* ap = dys + kq * p.cop + cb * 16 + j;
-      const float* bp = xs + (toff + (MODE == MODE_HW ? kq * ST : kq)) * CIP + j;
-      v4f a = acc[it];
-      for (int step = 0; step < NPX / 4; ++step) {
+      const float* bp = xs + (MODE == MODE_HW ? kq * ST : kq) * CIP + j;
+#pragma unroll 2
+      for (int step = s0; step < s0 + nstep; ++step) {
         int xo;
         if (MODE == MODE_HW) xo = ((step >> 3) * ST * in_cols + (step & 7) * 4 * ST) * CIP;
         else xo = step * 4 * CIP;
-        a = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[step * 4 * p.cop], bp[xo], a, 0, 0, 0);
+        const float a = ap[step * 4 * p.cop];
+        float bv[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const int toff = (MODE == MODE_HW) ? ((t / 3) * DL * in_cols + (t % 3) * DL) : t * 256;
+          bv[t] = bp[xo + toff * CIP];
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[t], acc[t], 0, 0, 0);
       }
-      acc[it] = a;
     }
   }
-  // ---- this workgroup's partial blocks: row (item, r) of 64 lanes; lane holds co = 16 cb + 4 kq + r, ci = ci0 + j
-  float* mine = part + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * nitems * 256;
+  // ---- the pixel shares of a channel block meet in LDS (fixed order: share 0 + 1 (+ 2 + 3)), then the block leaves as this
+  // workgroup's partial: row (item = tap * cob + cb, r) of 64 lanes; lane holds co = 16 cb + 4 kq + r, ci = ci0 + j
+  if (pxsplit > 1) {
+    __syncthreads();                                              // the last tile's fragments are consumed: LDS is free
+    float* red = lds;                                             // [wave][KT][4][64]
+    if (working && part_px > 0) {
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    const int item = wave + 4 * it;
-    if (item >= nitems) break;
+      for (int t = 0; t < KT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mine[(item * 4 + r) * 64 + lane] = acc[it][r];
+        for (int r = 0; r < 4; ++r) red[((wave * KT + t) * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (working && part_px == 0) {
+      for (int q = 1; q < pxsplit; ++q) {
+        const int w2 = cb + q * cbsplit;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] += red[((w2 * KT + t) * 4 + r) * 64 + lane];
+      }
+    }
+  }
+  if (working && part_px == 0) {
+    float* mine = part + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * nitems * 256;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int item = t * cob + cb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(item * 4 + r) * 64 + lane] = acc[t][r];
+    }
   }
 }
 

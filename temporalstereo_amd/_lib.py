@@ -186,6 +186,7 @@ class _RecordingProxy:
             rc = real(*args)
             if rc == 0:
                 words = (ctypes.c_ulonglong * len(args))(*[_word(t, a) for t, a in zip(argtypes, args)])
+                rec.log.append((name, int(words[len(args) - 1]) if len(args) else 0))      # (entry point, its last word: the stream)
                 rc2 = _real_lib().ts_plan_add_call(rec.plan, name.encode(), words, len(args))
                 if rc2 != 0:
                     check(rc2, "ts_plan_add_call(%s)" % name)
@@ -203,6 +204,7 @@ class Recorder:
         if not self.plan:
             raise RuntimeError("ts_plan_create failed")
         self.keep = []
+        self.log = []               # what was recorded, in order: (entry point, stream handle) -- tools/exp/plan_streams.py
         self.proxy = _RecordingProxy(self)
 
     def __enter__(self):

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--batches", type=int, nargs="+", default=[1, 4])
     ap.add_argument("--levels", nargs="+", default=list(LEVELS))
+    ap.add_argument("--backward", action="store_true", help="also time the backward (ts_block_cost_{int,sampled}_bwd) of each level")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.lib()
@@ -75,6 +76,33 @@ def main():
                 print("K1 %-8s %-8s B=%d  %8.2f us  %8.1f MB  %7.1f GB/s  %.3f of 8.0 TB/s  %.3f of 6.29 TB/s" % (
                     name, kind, B, t * 1e6, nb / 1e6, nb / t / 1e9, nb / t / 8e12, nb / t / 6.29e12), flush=True)
                 del out
+            if a.backward:
+                # backward of the complete op: reads left, right, (disp,) grad_out once, writes grad_left, grad_right (, grad_disp) once
+                ctot = (2 * C if sampled else C) + 3 * (C // 8)
+                go = torch.randn(B, ctot, D, H, W, device=dev)
+                gl, gr, gd = torch.empty_like(left), torch.empty_like(right), torch.empty(B, D, H, W, device=dev)
+                wsb = torch.zeros(max(int(L.ts_block_cost_bwd_workspace_bytes(B, C, H, W, D, 3)), 256), device=dev, dtype=torch.uint8)
+                if sampled:
+                    fn = lambda: L.ts_block_cost_sampled_bwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(disp), _lib.ptr(go), _lib.ptr(gl), _lib.ptr(gr),
+                                                             _lib.ptr(gd), _lib.ptr(wsb), B, C, H, W, D, 3, st)
+                else:
+                    fn = lambda: L.ts_block_cost_int_bwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(go), _lib.ptr(gl), _lib.ptr(gr), _lib.ptr(wsb),
+                                                         B, C, H, W, D, 3, st)
+                for _ in range(5):
+                    _lib.check(fn(), "k1 bwd")
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n = max(a.iters // 4, 10)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) / n * 1e-3
+                nb = 4 * B * H * W * (4 * C + (2 * D if sampled else 0) + ctot * D)
+                rows.append(dict(level=name, kind="backward", batch=B, us=t * 1e6, algorithmic_bytes=nb, GBps=nb / t / 1e9, frac_of_8TBps=nb / t / 8e12))
+                print("K1 %-8s %-8s B=%d  %8.2f us  %8.1f MB  %7.1f GB/s  %.3f of 8.0 TB/s" % (name, "backward", B, t * 1e6, nb / 1e6, nb / t / 1e9, nb / t / 8e12), flush=True)
+                del go
     print(json.dumps(rows))
 
 

@@ -295,14 +295,18 @@ size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, int H, int 
  *   ts_conv3d_hw_x6_supported     1 when the layer can take this path (Cin >= 16, 8 < Cout <= 512, W % 4 == 0, stride 1, dilation 1 | 2)
  *   ts_conv3d_hw_x6_weight_split  w_t (the [Cin][9][CoutPad] array of ts_conv3d_hw_fwd) -> w6, ts_conv3d_hw_x6_weight_bytes
  *                                 bytes: [Cin/16][part 3][tap slot 10][group 2][CoutPad][8] bf16
- *   ts_conv3d_hw_x6_fwd           arguments as ts_conv3d_hw_fwd with stride 1, not transposed, no split-K workspace */
+ *   ts_conv3d_hw_x6_fwd           arguments as ts_conv3d_hw_fwd with stride 1, not transposed; workspace (ABI 5): scratch of
+ *                                 ts_conv3d_hw_x6_workspace_bytes bytes for the split-K form of small grids (a grid of a few dozen
+ *                                 workgroups is cut into 2 | 4 | 8 slices of the input channels, summed in a fixed order by a second
+ *                                 launch); NULL / too little: unsplit */
 int ts_conv3d_hw_x6_supported(int Cin, int Cout, int W, int stride, int dilation, int transposed);
 size_t ts_conv3d_hw_x6_weight_bytes(int Cin, int Cout);
+size_t ts_conv3d_hw_x6_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W);
 int ts_conv3d_hw_x6_weight_split(const float* w_t, void* w6, int Cin, int Cout, void* stream);
 int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* scale, const float* shift, float* y,
                         int B, int Cin, int Cout, int D, int H, int W, int dilation, int act, float act_param,
                         long long in_bstride, long long in_cstride, long long out_bstride, long long out_cstride,
-                        const float* addend, long long addend_bstride, void* stream);
+                        const float* addend, long long addend_bstride, void* workspace, size_t workspace_bytes, void* stream);
 int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
                     int B, int Cin, int Cout, int Din, int H, int W, int k, int stride, int dilation,
                     int padding, int transposed, int act, float act_param,

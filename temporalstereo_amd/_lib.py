@@ -80,8 +80,9 @@ SIGNATURES = {
     "ts_conv3d_hw_x6_supported": (c_int, [c_int] * 6),
     "ts_conv3d_hw_x6_weight_bytes": (ctypes.c_size_t, [c_int] * 2),
     "ts_conv3d_hw_x6_weight_split": (c_int, [c_f32p, c_ptr, c_int, c_int, c_ptr]),
+    "ts_conv3d_hw_x6_workspace_bytes": (c_size, [c_int] * 6),
     "ts_conv3d_hw_x6_fwd": (c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p] + [c_int] * 8 + [c_float] + [ctypes.c_longlong] * 4 +
-                            [c_f32p, ctypes.c_longlong, c_ptr]),
+                            [c_f32p, ctypes.c_longlong, c_ptr, c_size, c_ptr]),
     "ts_conv3d_hw_fwd": (c_int, [c_f32p] * 5 + [c_int] * 10 + [c_float] + [ctypes.c_longlong] * 4 +
                          [c_f32p, ctypes.c_longlong, c_ptr, c_size, c_ptr]),
     "ts_conv3d_hw_workspace_bytes": (c_size, [c_int] * 8),

@@ -245,7 +245,10 @@ def _strides5(t):
 
 # TS_CONV_X6=0: every (1,3,3) convolution on the f32-input MFMA kernel (A/B measurements, bit-exact fp32 products)
 X6 = os.environ.get("TS_CONV_X6", "1") != "0"
-_X6_MIN_GRID = int(os.environ.get("TS_CONV_X6_MIN_GRID", "128"))    # measured 32 ... 384: 128 best at batch 1, flat at batch 4
+# Grids below this many x6 workgroups stay on the f32 kernel (with its split-K) -- unless the x6 kernel splits the reduction itself
+# (round 3: long reductions on small grids, ts_conv3d_hw_x6_workspace_bytes > 0).  Measured 32 ... 384: 128 best at batch 1, flat at 4;
+# layer by layer: tools/exp/x6_splitk_bench.py.
+_X6_MIN_GRID = int(os.environ.get("TS_CONV_X6_MIN_GRID", "128"))
 
 
 def x6_weights(f):
@@ -294,12 +297,16 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
     L = _lib.lib()
     wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, f.cout, D, H, W, stride, int(transposed)))
     x6_grid = ((H + 7) // 8) * ((W + 31) // 32) * D * B * ((f.cout + 31) // 32)
-    if X6 and (not wsb or x6_grid >= _X6_MIN_GRID) and L.ts_conv3d_hw_x6_supported(Cin, f.cout, W, stride, dilation, int(transposed)):
+    x6_ok = X6 and L.ts_conv3d_hw_x6_supported(Cin, f.cout, W, stride, dilation, int(transposed))
+    wsb6 = int(L.ts_conv3d_hw_x6_workspace_bytes(B, Cin, f.cout, D, H, W)) if x6_ok else 0
+    if x6_ok and (not wsb or x6_grid >= _X6_MIN_GRID or wsb6):
         # fp32 products from bf16 pieces on the bf16 matrix pipe (max error below the f32 kernel's: DESIGN.md section 4; 3/8 of the matrix time);
-        # layers whose reduction has to be split over workgroups to fill the chip (small grids) stay on the f32 MFMA kernel
+        # small grids stay on the f32 kernel unless the reduction is long enough for the x6 kernel's own split-K (wsb6 > 0)
+        ws6 = torch.empty(wsb6, device=x.device, dtype=torch.uint8) if wsb6 else None
         rc = L.ts_conv3d_hw_x6_fwd(_lib.ptr(x), _lib.ptr(x6_weights(f)), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
                                    B, Cin, f.cout, D, H, W, dilation, f.act if act is None else act, float(act_param),
-                                   ib, ic, ob, oc, _lib.ptr(addend), addend.stride(0) if addend is not None else 0, _stream())
+                                   ib, ic, ob, oc, _lib.ptr(addend), addend.stride(0) if addend is not None else 0, _lib.ptr(ws6), wsb6,
+                                   _stream())
         _lib.check(rc, "ts_conv3d_hw_x6_fwd")
         return out
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None

@@ -578,12 +578,17 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
   unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   {
     const unsigned total = gridDim.x * gridDim.y * gridDim.z, per = total / 8;
-    if (!(p.kspan & 1) && lin < per * 8) lin = (lin % 8) * per + lin / 8;
+    if (p.xcd && lin < per * 8) lin = (lin % 8) * per + lin / 8;
   }
   const int tile = lin % gridDim.x;
   const int od = (lin / gridDim.x) % gridDim.y;
   const int bz = lin / (gridDim.x * gridDim.y);
-  const int cog = bz % p.co_groups, b = bz / p.co_groups;
+  const int cog = bz % p.co_groups;
+  // split-K (p.ksplit > 1): slice ks of the input channels, raw sums to the workspace, conv_splitk_finish adds the slices.  A grid of
+  // a few dozen workgroups runs ONE workgroup per CU, i.e. without the co-resident workgroup whose matrix phase hides this one's
+  // staging: every 16-channel chunk is then an exposed load -> split -> commit -> multiply sequence of 5-7 us.
+  const int ks = (bz / p.co_groups) % p.ksplit, b = bz / (p.co_groups * p.ksplit);
+  const int kbeg = ks * p.kspan, kend = min(p.Cin, kbeg + p.kspan);
   const int co0 = cog * COB;
   const int ty0 = (tile / p.tiles_x) * 8, tx0 = (tile % p.tiles_x) * 32;
   const unsigned HW = static_cast<unsigned>(p.H) * p.W;
@@ -667,12 +672,12 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
     for (int q = 0; q < RWN; ++q) w6s[wl[q]] = rw[q];
   };
 
-  fetch(0);
-  for (int c0 = 0; c0 < p.Cin; c0 += X6_NC) {
+  fetch(kbeg);
+  for (int c0 = kbeg; c0 < kend; c0 += X6_NC) {
     __syncthreads();
     commit();
     __syncthreads();
-    if (c0 + X6_NC < p.Cin) fetch(c0 + X6_NC);
+    if (c0 + X6_NC < kend) fetch(c0 + X6_NC);
     // Five steps of two half-steps (pixel blocks {0,1} and {2,3}).  The fragments of the NEXT half-step are read from LDS before
     // the 12 CB MFMAs of the current one issue (a wave otherwise alternates 18 ds_read_b128 and 48 MFMAs).  The kernel's duration
     // did not change with it -- what bounds it is the co-resident workgroups' staging, DESIGN.md section 4 -- but neither did the
@@ -728,9 +733,13 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
   }
 
   const size_t hw_o = static_cast<size_t>(p.Ho) * p.Wo;
-  const __amdgpu_buffer_rsrc_t yr = ig_rsrc(y + static_cast<long long>(b) * p.out_bstride, p.out_bytes);
-  const unsigned ocs = static_cast<unsigned>(p.out_cstride) * 4u;
-  const float* ab = p.addend ? p.addend + static_cast<size_t>(b) * p.add_bstride : nullptr;
+  const bool split = p.ksplit > 1;
+  const unsigned oplane = static_cast<unsigned>(p.Do) * static_cast<unsigned>(hw_o);
+  const __amdgpu_buffer_rsrc_t yr = split
+      ? ig_rsrc(p.partial + (static_cast<size_t>(ks) * p.B + b) * p.Cout * oplane, p.part_bytes)
+      : ig_rsrc(y + static_cast<long long>(b) * p.out_bstride, p.out_bytes);
+  const unsigned ocs = split ? oplane * 4u : static_cast<unsigned>(p.out_cstride) * 4u;
+  const float* ab = (p.addend && !split) ? p.addend + static_cast<size_t>(b) * p.add_bstride : nullptr;
   float outv[CB][4][4];
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
@@ -744,7 +753,7 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
         const int co = co0 + cb * 16 + kq * 4 + r;
         float v = acc[cb][pb][r];
         if (ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * hw_o + (inside ? ppix : 0u)];
-        outv[cb][pb][r] = apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param, co);
+        outv[cb][pb][r] = split ? v : apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param, co);
       }
   }
   __syncthreads();                                      // the last chunk's fragments are consumed: the tile buffers become the staging area
@@ -1270,6 +1279,37 @@ size_t x6_weight_bytes(int Cin, int Cout) {
 }
 }  // namespace
 
+namespace {
+// Split-K factor of the x6 kernel.  Measured layer by layer at config 2 (tools/exp/x6_splitk_bench.py, isolated launches): the split
+// pays where a LONG reduction meets a small grid -- 352 -> 32 on 12 x 34 x 60 (120 workgroups, 22 chunks): f32 kernel with its own
+// split-K 70 us, x6 unsplit 87 us, x6 in four slices 50 us; 256 -> 64 on 34 x 60 (20 workgroups): 22 / 64 / 19 us -- and costs 4-5 us
+// (the finishing launch) where the reduction is short: 32 -> 32 on 120-136 workgroups 16 -> 17.5-21 us, 64 -> 16 on 252: 17 -> 21 us.
+// So: only reductions of 16+ chunks (Cin >= 256), as many slices (2 | 4 | 8, two chunks each at least) as keep the grid within the
+// chip's 2 x 256 workgroup slots (+ 1/8).  TS_X6_KSPLIT=1 switches it off, =N forces N slices where the channel count allows.
+int x6_ksplit(int B, int Cin, int Cout, int D, int H, int W) {
+  static const long long forced = env_ll("TS_X6_KSPLIT", 0);
+  const int nchunk = (Cin + X6_NC - 1) / X6_NC;
+  const int need = (Cout + 15) / 16, cb = need >= 2 ? 2 : 1;
+  const long long wgs = static_cast<long long>((H + 7) / 8) * ((W + 31) / 32) * D * B * ((need + cb - 1) / cb);
+  int ks = 1;
+  if (forced > 0) {
+    while (ks * 2 <= forced && ks * 2 <= nchunk && ks < 8) ks *= 2;
+  } else if (nchunk >= 16) {
+    while (ks < 8 && wgs * ks * 2 <= 2 * ts::kNumCU + ts::kNumCU / 4 && nchunk >= ks * 4) ks *= 2;
+  }
+  // every slice must own at least one chunk
+  while (ks > 1 && ((nchunk + ks - 1) / ks) * (ks - 1) >= nchunk) ks /= 2;
+  return ks;
+}
+}  // namespace
+
+// bytes of the split-K workspace ts_conv3d_hw_x6_fwd wants for this shape (0: the layer runs unsplit)
+extern "C" size_t ts_conv3d_hw_x6_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  const int ks = x6_ksplit(B, Cin, Cout, D, H, W);
+  return ks > 1 ? static_cast<size_t>(ks) * B * Cout * D * H * W * sizeof(float) : 0;
+}
+
 extern "C" int ts_conv3d_hw_x6_supported(int Cin, int Cout, int W, int stride, int dilation, int transposed) {
   // Cout <= 8: the row-paired f32 kernel (both output rows of a wave in one 16-row MFMA) is as fast at batch 1 and faster at 4
   return Cin >= X6_NC && Cout > 8 && Cout <= 512 && W > 0 && W % 4 == 0 && stride == 1 && (dilation == 1 || dilation == 2) &&
@@ -1293,7 +1333,8 @@ extern "C" int ts_conv3d_hw_x6_weight_split(const float* w_t, void* w6, int Cin,
 extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* scale, const float* shift, float* y,
                                    int B, int Cin, int Cout, int D, int H, int W, int dilation, int act, float act_param,
                                    long long in_bstride, long long in_cstride, long long out_bstride,
-                                   long long out_cstride, const float* addend, long long addend_bstride, void* stream) {
+                                   long long out_cstride, const float* addend, long long addend_bstride,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw_x6: non-positive size");
   TS_REQUIRE(ts_conv3d_hw_x6_supported(Cin, Cout, W, 1, dilation, 0), TS_ERR_UNSUPPORTED,
              "conv3d_hw_x6: needs Cin >= 16, 8 < Cout <= 512, W %% 4 == 0, dilation 1 | 2 (Cin=%d Cout=%d W=%d dilation=%d)", Cin, Cout,
@@ -1307,7 +1348,7 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   static const int no_xcd = env_not_zero("TS_X6_XCD") ? 0 : 1;
-  p.ksplit = 1; p.kspan = no_xcd; p.partial = nullptr; p.B = B;
+  p.ksplit = 1; p.kspan = (Cin + X6_NC - 1) / X6_NC * X6_NC; p.partial = nullptr; p.B = B; p.xcd = !no_xcd;
   p.addend = addend; p.add_bstride = addend_bstride;
   TS_REQUIRE(ig_extent(p, 9), TS_ERR_UNSUPPORTED, "conv3d_hw_x6: a batch element of x spans 2 GiB or more");
   const size_t wb = x6_weight_bytes(Cin, Cout);
@@ -1324,10 +1365,32 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
   const int need = (Cout + 15) / 16;
   const int cb = need >= 2 ? 2 : 1;
   p.co_groups = (need + cb - 1) / cb;
-  const dim3 grid(tiles, D, B * p.co_groups);
+  // split-K only with a workspace of the size ts_conv3d_hw_x6_workspace_bytes names (none / too small: unsplit, same result up to
+  // the order of the fp32 additions)
+  const int ksplit = x6_ksplit(B, Cin, Cout, D, H, W);
+  const long long plane = static_cast<long long>(D) * H * W;
+  const size_t need_ws = static_cast<size_t>(ksplit) * B * Cout * plane * sizeof(float);
+  const bool split = ksplit > 1 && workspace != nullptr && workspace_bytes >= need_ws &&
+                     static_cast<unsigned long long>(Cout) * plane * 4ull < 0x7fffffffull && static_cast<long long>(B) * Cout <= 65535;
+  if (split) {
+    const int nchunk = (Cin + X6_NC - 1) / X6_NC;
+    p.ksplit = ksplit;
+    p.kspan = (nchunk + ksplit - 1) / ksplit * X6_NC;
+    p.partial = reinterpret_cast<float*>(workspace);
+    p.part_bytes = static_cast<unsigned>(static_cast<unsigned long long>(Cout) * plane * 4ull);
+  }
+  const dim3 grid(tiles, D, B * p.co_groups * p.ksplit);
   hipStream_t st = ts::as_stream(stream);
-  if (cb == 2) return dilation == 2 ? launch_x6<2, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<2, 1>(x, w6, scale, shift, y, p, grid, st);
-  return dilation == 2 ? launch_x6<1, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<1, 1>(x, w6, scale, shift, y, p, grid, st);
+  int rc;
+  if (cb == 2) rc = dilation == 2 ? launch_x6<2, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<2, 1>(x, w6, scale, shift, y, p, grid, st);
+  else rc = dilation == 2 ? launch_x6<1, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<1, 1>(x, w6, scale, shift, y, p, grid, st);
+  if (rc || !split) return rc;
+  long long blocks = (plane + 255) / 256;
+  const long long cap = (4096 + static_cast<long long>(B) * Cout - 1) / (static_cast<long long>(B) * Cout);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(conv_splitk_finish, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(B * Cout)), dim3(256), 0, st, p.partial, scale, shift, y,
+                     B, Cout, plane, ksplit, act, act_param, out_bstride, out_cstride, addend, addend_bstride, static_cast<long long>(H) * W);
+  return ts::launched("conv_splitk_finish");
 }
 
 extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,

@@ -8,7 +8,7 @@
 
 #include "../../include/ts_hip.h"
 
-#define TS_ABI_VERSION 4   // 4: train_ops (candidates, offset head, deconv2d training forms, clip+RMSprop); 3: bwd_weight workspace, bn_stats counter, x6 / weight-layout / bn_train
+#define TS_ABI_VERSION 5   // 5: split-K workspace of ts_conv3d_hw_x6_fwd; 4: train_ops (candidates, offset head, deconv2d training forms, clip+RMSprop); 3: bwd_weight workspace, bn_stats counter, x6 / weight-layout / bn_train
 
 namespace ts {
 

@@ -414,7 +414,6 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, a
     _require_gpu(x, weight)
     x = x.contiguous()
     B, Cin, D, H, W = x.shape
-    w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
     if transposed:                                   # weight [Cin, Cout, 1, 3, 3]
         Cout = weight.shape[1]
         w_t = _layout(weight, 0, 1)                                              # [ci][t][co]
@@ -448,7 +447,6 @@ def _hw_backward(x, weight, dy, geom, need_x, need_w):
     dy = dy.contiguous()
     L = _lib.lib()
     dx = dw = None
-    w9 = weight.reshape(weight.shape[0], weight.shape[1], 9)
     if need_x:
         if transposed:
             w_b = _layout(weight, 1, 0)                                          # [co][t][ci] = W_T[ci][co][t]
@@ -498,7 +496,6 @@ def _d_forward(x, weight, stride, dilation, padding, transposed, bias=None, fold
     x = x.contiguous()
     B, Cin, Din, H, W = x.shape
     k = weight.shape[2]
-    wk = weight.reshape(weight.shape[0], weight.shape[1], k)
     if transposed:
         Cout = weight.shape[1]
         w_t = _layout(weight, 0, 1)
@@ -521,7 +518,6 @@ def _d_backward(x, weight, dy, geom, need_x, need_w):
     dy = dy.contiguous()
     L = _lib.lib()
     dx = dw = None
-    wk = weight.reshape(weight.shape[0], weight.shape[1], k)
     if need_x:
         if transposed:
             w_b = _layout(weight, 1, 0)
@@ -784,7 +780,7 @@ class _ConvBNAct(torch.autograd.Function):
         else:
             x, y, cg = _d_forward(x, weight, geom[0], geom[1], geom[2], geom[3], bias)
         B, C = y.shape[0], y.shape[1]
-        N = y[0, 0].numel()
+        N = y.numel() // (B * C)
         L = _lib.lib()
         n_total = float(B * N)
         out = torch.empty_like(y)
@@ -839,7 +835,7 @@ class _ConvBNAct(torch.autograd.Function):
         family, cg, eps, act, training, group, n_total, has_bias = ctx.meta
         g = g.contiguous()
         B, C = y.shape[0], y.shape[1]
-        N = y[0, 0].numel()
+        N = y.numel() // (B * C)
         L = _lib.lib()
         s1 = torch.empty(C, device=y.device, dtype=torch.float32)
         s2 = torch.empty_like(s1)

@@ -119,3 +119,40 @@ def test_x6_fuzz_against_the_f32_kernel():
         scale = float(outs[False].abs().max())
         err = float((outs[True] - outs[False]).abs().max())
         assert err <= 4e-6 * max(scale, 1.0), (case, (B, Cin, Cout, D, H, W, dil), err, scale)
+
+
+@pytest.mark.parametrize("shape", [(1, 352, 32, 12, 34, 60, 1), (1, 256, 64, 1, 34, 60, 1), (2, 272, 16, 2, 9, 16, 1), (1, 512, 24, 3, 17, 32, 2)],
+                         ids=lambda s: "B%d_%dto%d_D%d_%dx%d_dil%d" % s)
+def test_x6_split_k_equals_the_unsplit_form(shape):
+    """Small grids with long reductions (Cin >= 256) cut the input channels into slices (raw sums to a workspace, summed in a fixed order by conv_splitk_finish);
+    without a workspace the same entry point runs unsplit: the two differ only in the order of a few fp32 additions -- and both
+    stay within the x6 bound of the fp64 result, with scale / shift / SiLU / addend applied by the finishing launch."""
+    from temporalstereo_amd import _lib
+    from temporalstereo_amd.aggregation import native as N
+    B, Cin, Cout, D, H, W, dil = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, D, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 1, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(dev)
+    f = N.Folded(w, torch.randn(Cout, generator=g).to(dev), None, N.ACT_SILU, False, "hw")
+    addend = torch.randn(B, Cout, 1, H, W, generator=g).to(dev)
+    L = _lib.lib()
+    wsb = int(L.ts_conv3d_hw_x6_workspace_bytes(B, Cin, Cout, D, H, W))
+    assert wsb > 0 and wsb % (B * Cout * D * H * W * 4) == 0, "these grids are small enough to be split"
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    outs = []
+    for buf, nbytes in ((None, 0), (ws, wsb)):
+        out = torch.full((B, Cout, D, H, W), float("nan"), device=dev)
+        rc = L.ts_conv3d_hw_x6_fwd(_lib.ptr(x), _lib.ptr(N.x6_weights(f)), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out), B, Cin, Cout,
+                                   D, H, W, dil, N.ACT_SILU, 0.0, x.stride(0), x.stride(1), out.stride(0), out.stride(1), _lib.ptr(addend),
+                                   addend.stride(0), _lib.ptr(buf), nbytes, N._stream())
+        _lib.check(rc, "ts_conv3d_hw_x6_fwd")
+        outs.append(out)
+    torch.cuda.synchronize()
+    ref = F.conv3d(x.double(), w.double(), padding=(0, dil, dil), dilation=(1, dil, dil)) + addend.double()
+    ref = F.silu(ref * f.scale[:Cout].double().view(1, -1, 1, 1, 1) + f.shift[:Cout].double().view(1, -1, 1, 1, 1))
+    scale = max(float(ref.abs().max()), 1.0)
+    for out in outs:
+        assert torch.isfinite(out).all()
+        assert float((out.double() - ref).abs().max()) <= 1e-6 * scale
+    assert float((outs[0] - outs[1]).abs().max()) <= 5e-7 * scale

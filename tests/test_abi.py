@@ -82,3 +82,22 @@ def test_ops_refuse_cpu_tensors():
     import temporalstereo_amd as ts
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ts.block_cost(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4), 3)
+
+
+def test_x6_split_k_choice_without_gpu(built_lib):
+    """ts_conv3d_hw_x6_workspace_bytes is host logic: which (1,3,3) layers of config 2 the x6 kernel cuts into slices of its input
+    channels (long reductions on small grids only: csrc/conv3d.hip x6_ksplit, measured in tools/exp/x6_splitk_bench.py)."""
+    from temporalstereo_amd import _lib
+    L = _lib.lib()
+    out = lambda B, Co, D, H, W: B * Co * D * H * W * 4
+    assert L.ts_conv3d_hw_x6_workspace_bytes(1, 352, 32, 12, 34, 60) == 4 * out(1, 32, 12, 34, 60)     # coarse first layer: four slices
+    assert L.ts_conv3d_hw_x6_workspace_bytes(1, 256, 64, 1, 34, 60) == 8 * out(1, 64, 1, 34, 60)       # 20 workgroups, 16 chunks
+    assert L.ts_conv3d_hw_x6_workspace_bytes(1, 32, 32, 12, 34, 60) == 0                               # short reductions never
+    assert L.ts_conv3d_hw_x6_workspace_bytes(1, 176, 16, 5, 68, 120) == 0
+    assert L.ts_conv3d_hw_x6_workspace_bytes(1, 128, 32, 14, 34, 60) == 0
+    assert L.ts_conv3d_hw_x6_workspace_bytes(4, 352, 32, 12, 34, 60) == 0                              # batch 4 fills the chip unsplit
+    assert L.ts_conv3d_hw_x6_workspace_bytes(1, 272, 16, 2, 9, 16) % out(1, 16, 2, 9, 16) == 0         # ragged chunk count: whole slices
+    assert L.ts_conv3d_hw_x6_workspace_bytes(0, 352, 32, 12, 34, 60) == 0
+    # without a workspace the entry point runs unsplit; its argument checks come first either way
+    rc = L.ts_conv3d_hw_x6_fwd(None, None, None, None, None, 1, 352, 32, 12, 34, 60, 1, 0, 0.0, 0, 0, 0, 0, None, 0, None, 0, None)
+    assert rc == -1 and b"NULL" in L.ts_last_error_string()

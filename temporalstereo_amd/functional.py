@@ -881,15 +881,20 @@ class _ConvBNAct(torch.autograd.Function):
 def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False):
     """Fused wrapper forward (see _ConvBNAct).  `bn`: an nn.BatchNorm*d / dist.SyncBatchNorm module; `activation`: None | 'SiLU' |
     'ReLU'; family 'hw' geom (stride, dilation, transposed) / family 'd' geom (stride, dilation, padding, transposed)."""
-    training = bn.training or bn.running_mean is None
+    # parameters / buffers straight from the module's dictionaries: nn.Module.__getattr__ (the fallback every `bn.weight`,
+    # `bn.running_mean` ... goes through) was ~10 lookups x 180 wrappers per frame
+    d, P, Bf = bn.__dict__, bn._parameters, bn._buffers
+    rmean = Bf.get("running_mean")
+    training = d["training"] or rmean is None
     group = None
-    if training and getattr(bn, "process_group", "absent") != "absent":
+    if training and "process_group" in d:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
-            group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-    momentum = bn.momentum if bn.momentum is not None else 0.1
-    counter = bn.num_batches_tracked if (training and bn.track_running_stats) else None     # incremented by the statistics launch
-    return _ConvBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, family, geom, bn.eps, momentum,
+        pg = d["process_group"]
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(pg) > 1:
+            group = pg if pg is not None else dist.group.WORLD
+    momentum = d["momentum"] if d["momentum"] is not None else 0.1
+    counter = Bf.get("num_batches_tracked") if (training and d["track_running_stats"]) else None     # incremented by the statistics launch
+    return _ConvBNAct.apply(x, weight, bias, P["weight"], P["bias"], rmean, Bf.get("running_var"), family, geom, d["eps"], momentum,
                             BN_ACT[activation], training, group, counter)
 
 

@@ -111,6 +111,20 @@ class _NormAct:
         return False
 
 
+def _static(m, make):
+    """Per-module memo of what depends only on the constructor arguments and on WHICH norm / activation modules are attached (not
+    on their state): the kernel family, its geometry tuple and the fused activation's name.  A training step walks ~180 wrappers per
+    frame; recomputing these (tuple building, isinstance chains, nn.Module.__getattr__ for every parameter and submodule) was ~1 ms
+    of its host time."""
+    d = m.__dict__
+    mods = d["_modules"]
+    key = (id(mods.get("norm")), id(mods.get("activation")))
+    memo = d.get("_ts_static")
+    if memo is None or memo[0] != key:
+        memo = d["_ts_static"] = (key, make())
+    return memo[1]
+
+
 class Conv2d(nn.Conv2d, _NormAct):
     def __init__(self, *args, **kwargs):
         norm, act, kwargs = _split_kwargs(kwargs)
@@ -120,12 +134,17 @@ class Conv2d(nn.Conv2d, _NormAct):
     def forward(self, x):
         if _hip_conv(x):
             from . import functional as TF
-            w5 = self.weight.unsqueeze(2)
-            st, pd, dl = (1,) + tuple(self.stride), (0,) + tuple(self.padding), (1,) + tuple(self.dilation)
-            if TF.conv3d_supported(tuple(w5.shape), st, pd, dl, self.groups) == "hw":      # a (1,3,3) convolution on one plane
-                act = self._fusable()
+
+            def make():
+                st, pd, dl = (1,) + tuple(self.stride), (0,) + tuple(self.padding), (1,) + tuple(self.dilation)
+                w5 = (self.weight.shape[0], self.weight.shape[1], 1) + tuple(self.weight.shape[2:])
+                return TF.conv3d_supported(w5, st, pd, dl, self.groups), self._fusable(), st, pd, dl
+            kind, act, st, pd, dl = _static(self, make)
+            if kind == "hw":      # a (1,3,3) convolution on one plane
+                w5 = self._parameters["weight"].unsqueeze(2)
                 if act is not False:
-                    return TF.conv_bn_act(x.unsqueeze(2), w5, self.bias, self.norm, act, "hw", (st[1], dl[1], False)).squeeze(2)
+                    return TF.conv_bn_act(x.unsqueeze(2), w5, self._parameters["bias"], self._modules["norm"], act, "hw",
+                                          (st[1], dl[1], False)).squeeze(2)
                 return self._finish(TF.conv3d(x.unsqueeze(2), w5, self.bias, st, pd, dl).squeeze(2))
         return self._finish(F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups))
 
@@ -139,13 +158,16 @@ class Conv3d(nn.Conv3d, _NormAct):
     def forward(self, x):
         if _hip_conv(x):
             from . import functional as TF
-            kind = TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups)
+
+            def make():
+                kind = TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups)
+                geom = (self.stride[1], self.dilation[1], False) if kind == "hw" else \
+                    (self.stride[0], self.dilation[0], self.padding[0], False)
+                return kind, self._fusable(), geom
+            kind, act, geom = _static(self, make)
             if kind:
-                act = self._fusable()
                 if act is not False:      # conv -> BatchNorm (train or eval statistics) -> activation as one autograd node
-                    geom = (self.stride[1], self.dilation[1], False) if kind == "hw" else \
-                        (self.stride[0], self.dilation[0], self.padding[0], False)
-                    return TF.conv_bn_act(x, self.weight, self.bias, self.norm, act, kind, geom)
+                    return TF.conv_bn_act(x, self._parameters["weight"], self._parameters["bias"], self._modules["norm"], act, kind, geom)
                 return self._finish(TF.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation))
         return self._finish(F.conv3d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups))
 

@@ -1188,7 +1188,9 @@ int conv_hw_ksplit(int B, int Cin, int Cout, int D, int Ho, int Wo) {
   const long long tiles = static_cast<long long>((Ho + 7) / 8) * ((Wo + 31) / 32) * D * B;
   const int groups = (Cout + 15) / 16;
   int ks = 1;
-  while (ks < 8 && tiles * groups * ks < 3 * ts::kNumCU && Cin / (ks * 2) >= 32) ks *= 2;
+  // up to 2 workgroups per CU (round 3, tools/exp/f32_splitk_bench.py: every split layer of config 2 gains 1-38 us from it except the
+  // row-paired 176 -> 8 on 5 x 136 x 240, whose 680 workgroups were cut in two under the former 3-per-CU bound: 68.7 vs 65.7 us unsplit)
+  while (ks < 8 && tiles * groups * ks < 2 * ts::kNumCU && Cin / (ks * 2) >= 32) ks *= 2;
   return ks;
 }
 

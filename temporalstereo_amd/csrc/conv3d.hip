@@ -186,11 +186,17 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   unsigned goff[RQ];
   int loff[RQ];
   if (MODE == MODE_D) {
+    // MODE_D stages 16 bytes per lane: the 256 pixels of a (channel, plane) row are 64 quads, so one instruction of the workgroup
+    // moves four rows -- wave w takes the channels c = w (mod 4) of the chunk, all NTR planes of each.  (Round 3: the kernel staged
+    // one dword per lane, NC * NTR loads per thread and chunk at ~29 cycles of the CU's address unit each -- 1.15 us per 8-channel
+    // chunk whatever the grid, and that, not the matrix work, was the duration of every (k,1,1) layer: 7 / 9.5 / 14 us at 16 / 32 /
+    // 64 channels, tools/exp/conv_d_bench.py.  The x6 kernel had learnt the same lesson in round 2.)  A quad that straddles the end
+    // of the plane carries foreign elements into pixels >= H W, which no output reads (the reduction is per pixel column).
 #pragma unroll
     for (int t = 0; t < NTR; ++t) {
-      const unsigned px = px0 + threadIdx.x;
+      const unsigned px = px0 + 4u * (threadIdx.x & 63u);
       goff[t] = (plane_id[t] >= 0 && px < HW) ? (static_cast<unsigned>(plane_id[t]) * HW + px) * 4u : kOOB;
-      loff[t] = t * 256 + threadIdx.x;
+      loff[t] = t * 256 + 4 * static_cast<int>(threadIdx.x & 63u);
     }
   } else {
 #pragma unroll
@@ -270,16 +276,29 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   // kernel is a chain of exposed latencies; the second register set costs occupancy, which such a grid does not use anyway
   // (on full grids it loses: 1113 -> 1085 pairs/s with three passes in flight).
   constexpr int NSET = PF ? 2 : 1;
-  float rin[NSET][NC][RQ];
+  constexpr bool VD = (MODE == MODE_D);                // 16-byte staging (see above)
+  constexpr int NCQ = VD ? NC / 4 : 1;
+  float rin[NSET][VD ? 1 : NC][VD ? 1 : RQ];
+  u32x4 rin4[NSET][NCQ][VD ? NTR : 1];
   u32x4 rw[NSET][RWN];
+  const int wave_u = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // uniform: the channel offsets stay scalar
   auto fetch = [&](auto set, int c0) {
     constexpr int S = decltype(set)::value;
+    if constexpr (VD) {
+#pragma unroll
+      for (int ic = 0; ic < NCQ; ++ic) {
+        const unsigned so = static_cast<unsigned>(min(c0 + wave_u + 4 * ic, p.Cin - 1)) * cstride_b;
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) rin4[S][ic][t] = __builtin_amdgcn_raw_buffer_load_b128(xr, goff[t], so, 0);
+      }
+    } else {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       // channels past the slice re-read the last real one; their weights are zero
       const unsigned so = static_cast<unsigned>(min(c0 + c, p.Cin - 1)) * cstride_b;
 #pragma unroll
       for (int i = 0; i < RQ; ++i) rin[S][c][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, goff[i], so, 0));
+    }
     }
     const unsigned wso = static_cast<unsigned>(c0) * wstride_b;
 #pragma unroll
@@ -288,10 +307,18 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   };
   auto commit = [&](auto set) {
     constexpr int S = decltype(set)::value;
+    if constexpr (VD) {
+#pragma unroll
+      for (int ic = 0; ic < NCQ; ++ic)
+#pragma unroll
+        for (int t = 0; t < NTR; ++t)
+          *reinterpret_cast<u32x4*>(in_tile + (wave_u + 4 * ic) * chan_elems + loff[t]) = rin4[S][ic][t];
+    } else {
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int i = 0; i < RQ; ++i) in_tile[c * chan_elems + loff[i]] = rin[S][c][i];
+    }
 #pragma unroll
     for (int q = 0; q < RWN; ++q) *reinterpret_cast<u32x4*>(w_tile + wl[q]) = rw[S][q];
   };
@@ -798,7 +825,7 @@ thread_local int g_chunk_cap = 32;
 // this file to the FIRST such lambda (a bool came out holding 192 -- the default of g_pf_max_wgs -- and tested false).
 long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
 bool env_not_zero(const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); }
-const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 512);     // measured 0 ... 512: 128-512 equal with three passes in flight, 512 best one pass at a time
+const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 1024);    // measured 0 ... 4096: 128-1024 equal with three passes in flight (4096: -0.7 %), one pass at a time 748 / 757 / 765 / 765 pairs/s at 128 / 512 / 1024 / 4096
 // TS_CONV_ROW_PAIRING=0 switches the Cout <= 8 row pairing off (A/B measurements)
 const bool g_row_pairing = env_not_zero("TS_CONV_ROW_PAIRING");
 

@@ -83,16 +83,18 @@ struct IG {
   int xcd;                      // XCD-banded workgroup order (ig_conv_kernel)
 };
 
-template <int MODE, int KT, int ST, int DL>
+// TP (MODE_D): pixels per workgroup, 256 or 64 (one 16-pixel block per wave: layers that run on a few dozen workgroups last as long as
+// ONE workgroup's K loop, so the tile is cut instead of the grid being filled)
+template <int MODE, int KT, int ST, int DL, int TP = 256>
 struct Geom {
   static constexpr int NTR = (MODE == MODE_D) ? KT : 1;                 // planes staged per channel (MODE_D)
   static constexpr int in_rows = (MODE == MODE_HW) ? 7 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 10 : 9) : 1);
-  static constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 34 : 33) : 256);
-  static constexpr int pitch = (MODE == MODE_D) ? 256 : (in_cols | 1);
+  static constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 34 : 33) : TP);
+  static constexpr int pitch = (MODE == MODE_D) ? TP : (in_cols | 1);
   // staged elements per thread and channel: the tile is dealt linearly to the 256 threads (a (row, column-of-64) deal
   // wasted over half of the load slots on a 10 x 34 tile)
   static constexpr int RQ_HW = (in_rows * in_cols + 255) / 256;
-  static constexpr int chan_raw = (MODE == MODE_D) ? NTR * 256 : in_rows * pitch;
+  static constexpr int chan_raw = (MODE == MODE_D) ? NTR * TP : in_rows * pitch;
   static constexpr int pad0 = (16 - (chan_raw & 31)) & 31;
   // == 16 (mod 32): the four k-slots of a B fragment sit on disjoint banks; >= 1 spare word (dump slot)
   static constexpr int chan_elems = chan_raw + (pad0 ? pad0 : 32);
@@ -110,18 +112,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ig_rsrc(const void* base, unsi
 // feeds both: per kx, input row R+rho*DL (rho = 0..3) is multiplied by [ W[ky=rho-1] | W[ky=rho] ] (zero where ky is
 // outside 0..2) -- 12 "virtual taps" with 18 useful (tap, row) products in 24 half-tiles instead of 18 in 36, i.e. a third
 // fewer MFMAs and a third fewer B-fragment reads.  The paired weight rows are assembled while the weights are staged.
-template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0, int PF = 0>
+template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0, int PF = 0, int TP = 256>
 __global__ void __launch_bounds__(256)
 ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                const float* __restrict__ shift, float* __restrict__ y, const IG p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!PR || (MODE == MODE_HW && KT == 9 && ST == 1 && CB == 1 && NC >= 8), "row pairing: stride-1 (1,3,3), Cout <= 8");
-  using G = Geom<MODE, KT, ST, DL>;
+  static_assert(TP == 256 || (TP == 64 && MODE == MODE_D), "64-pixel tiles: (k,1,1) layers");
+  using G = Geom<MODE, KT, ST, DL, TP>;
   constexpr int WP = (CB * 16) | 16;                  // weight row pitch (k-slots on disjoint banks)
   constexpr int NTR = G::NTR, RQ = (MODE == MODE_D) ? NTR : G::RQ_HW;
   constexpr int in_rows = G::in_rows, in_cols = G::in_cols, pitch = G::pitch, chan_elems = G::chan_elems;
   constexpr int KTW = PR ? 12 : KT;                   // taps as staged in LDS (virtual taps when pairing)
-  constexpr int NPB = PR ? 2 : 4;                     // 16-pixel blocks per wave
+  constexpr int NPB = PR ? 2 : TP / 64;               // 16-pixel blocks per wave
   constexpr int WV = KTW * NC * CB * 4;               // 16-byte weight vectors per chunk
   constexpr int RWN = (WV + 255) / 256;
 
@@ -179,7 +182,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       }
     }
   }
-  const int px0 = (MODE == MODE_D) ? bx * 256 : 0;
+  const int px0 = (MODE == MODE_D) ? bx * TP : 0;
 
   // ---- staging geometry of this thread: where each of its RQ elements of a channel comes from (byte
   // offset inside the batch element, kOOB = zero padding) and where it goes in the LDS channel tile ----
@@ -208,6 +211,25 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       const bool live = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       goff[q] = live ? (static_cast<unsigned>(od) * HW + static_cast<unsigned>(gy) * p.W + gx) * 4u : kOOB;
       loff[q] = slot ? cy * pitch + cx : G::chan_raw;                        // dump slot in the channel padding
+    }
+  }
+  // TP == 64: a (channel, plane) row is 16 quads, one instruction of the workgroup moves 16 rows; row r = c * NTR + t of the chunk
+  constexpr int NI64 = (MODE == MODE_D && TP == 64) ? (NC * NTR + 15) / 16 : 1;
+  unsigned go64[NI64];
+  int lo64[NI64], ch64[NI64];
+  if constexpr (MODE == MODE_D && TP == 64) {
+#pragma unroll
+    for (int i = 0; i < NI64; ++i) {
+      const int r = static_cast<int>(threadIdx.x >> 4) + 16 * i;
+      const bool ok = r < NC * NTR;
+      const int c = r / NTR, t = r - c * NTR;
+      int pid = -1;
+#pragma unroll
+      for (int u = 0; u < NTR; ++u) pid = (u == t) ? plane_id[u] : pid;
+      const unsigned px = px0 + 4u * (threadIdx.x & 15u);
+      go64[i] = (ok && pid >= 0 && px < HW) ? (static_cast<unsigned>(pid) * HW + px) * 4u : kOOB;
+      ch64[i] = ok ? c : 0;
+      lo64[i] = ok ? c * chan_elems + t * TP + 4 * static_cast<int>(threadIdx.x & 15u) : G::chan_raw;     // no row: the spare quad of channel 0
     }
   }
   // weights: vector v of a chunk = 4 consecutive output channels of (tap, ci)
@@ -239,7 +261,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   int boff[4];
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb) {
-    if (MODE == MODE_D) boff[pb] = kq * chan_elems + wave * 64 + pb * 16 + j;
+    if (MODE == MODE_D) boff[pb] = kq * chan_elems + wave * (TP / 4) + pb * 16 + j;
     else if (PR) {
       // output rows (base, base + DL) of the 8-row tile: DL 1 -> (2w, 2w+1); DL 2 -> (w&1) + 4(w>>1) + {0, 2}
       const int base = (DL == 1) ? wave * 2 : (wave & 1) + 4 * (wave >> 1);
@@ -279,12 +301,20 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   constexpr bool VD = (MODE == MODE_D);                // 16-byte staging (see above)
   constexpr int NCQ = VD ? NC / 4 : 1;
   float rin[NSET][VD ? 1 : NC][VD ? 1 : RQ];
-  u32x4 rin4[NSET][NCQ][VD ? NTR : 1];
+  constexpr bool VD64 = VD && TP == 64;
+  u32x4 rin4[NSET][VD64 ? 1 : NCQ][(VD && !VD64) ? NTR : 1];
+  u32x4 rin64[NSET][NI64];
   u32x4 rw[NSET][RWN];
   const int wave_u = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));   // uniform: the channel offsets stay scalar
   auto fetch = [&](auto set, int c0) {
     constexpr int S = decltype(set)::value;
-    if constexpr (VD) {
+    if constexpr (VD64) {
+#pragma unroll
+      for (int i = 0; i < NI64; ++i) {
+        const unsigned chb = static_cast<unsigned>(min(c0 + ch64[i], p.Cin - 1)) * cstride_b;
+        rin64[S][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, go64[i] == kOOB ? kOOB : go64[i] + chb, 0, 0);
+      }
+    } else if constexpr (VD) {
 #pragma unroll
       for (int ic = 0; ic < NCQ; ++ic) {
         const unsigned so = static_cast<unsigned>(min(c0 + wave_u + 4 * ic, p.Cin - 1)) * cstride_b;
@@ -307,7 +337,10 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   };
   auto commit = [&](auto set) {
     constexpr int S = decltype(set)::value;
-    if constexpr (VD) {
+    if constexpr (VD64) {
+#pragma unroll
+      for (int i = 0; i < NI64; ++i) *reinterpret_cast<u32x4*>(in_tile + lo64[i]) = rin64[S][i];
+    } else if constexpr (VD) {
 #pragma unroll
       for (int ic = 0; ic < NCQ; ++ic)
 #pragma unroll
@@ -393,11 +426,11 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
 #pragma unroll
-          for (int pb = 0; pb < 4; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + t * 256];
+          for (int pb = 0; pb < NPB; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + t * TP];
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb)
+            for (int pb = 0; pb < NPB; ++pb)
               acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
         }
       }
@@ -456,7 +489,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       ppix = static_cast<unsigned>(oy) * p.Wo + ox;
       opix = static_cast<unsigned>(od) * static_cast<unsigned>(hw_o) + ppix;
     } else if (MODE == MODE_D) {
-      const unsigned px = px0 + wave * 64 + pb * 16 + j;
+      const unsigned px = px0 + wave * (TP / 4) + pb * 16 + j;
       inside = px < HW;
       opix = static_cast<unsigned>(od) * HW + px;
     } else {
@@ -829,15 +862,15 @@ const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 1024);    // measure
 // TS_CONV_ROW_PAIRING=0 switches the Cout <= 8 row pairing off (A/B measurements)
 const bool g_row_pairing = env_not_zero("TS_CONV_ROW_PAIRING");
 
-template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0, int PF = 0>
+template <int CB, int MODE, int KT, int ST, int DL, int NC, int PR = 0, int PF = 0, int TP = 256>
 int launch_one(const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
                dim3 grid, hipStream_t st) {
-  using G = Geom<MODE, KT, ST, DL>;
+  using G = Geom<MODE, KT, ST, DL, TP>;
   constexpr int WP = (CB * 16) | 16;
   constexpr int KTW = PR ? 12 : KT;
   constexpr size_t lds = (static_cast<size_t>(NC) * G::chan_elems + static_cast<size_t>(KTW) * NC * WP + 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "ig_conv_kernel: tile does not fit the LDS");
-  auto kern = &ig_conv_kernel<CB, MODE, KT, ST, DL, NC, PR, PF>;
+  auto kern = &ig_conv_kernel<CB, MODE, KT, ST, DL, NC, PR, PF, TP>;
   if (lds > 64 * 1024) {
     static bool raised = false;      // per instantiation
     if (!raised) {
@@ -849,13 +882,13 @@ int launch_one(const float* x, const float* w, const float* scale, const float* 
   return ts::launched("ig_conv_kernel");
 }
 
-template <int CB, int MODE, int KT, int ST, int DL>
+template <int CB, int MODE, int KT, int ST, int DL, int TP = 256>
 int launch_nc(long long wgs, const float* x, const float* w, const float* scale, const float* shift, float* y, const IG& p,
               dim3 grid, hipStream_t st) {
   // K-chunk size.  A workgroup pays one global-memory round trip per chunk, so the chunk is made as
   // long as possible -- but only while every workgroup of the grid stays resident (LDS is what limits
   // that): co-resident workgroups hide each other's round trips, queued ones do not.
-  using G = Geom<MODE, KT, ST, DL>;
+  using G = Geom<MODE, KT, ST, DL, TP>;
   constexpr int WP = (CB * 16) | 16;
   constexpr size_t per_ch = (static_cast<size_t>(G::chan_elems) + static_cast<size_t>(KT) * WP) * sizeof(float);
   constexpr size_t lds_cu = 160 * 1024;
@@ -875,12 +908,12 @@ int launch_nc(long long wgs, const float* x, const float* w, const float* scale,
     }
   }
   auto fits = [&](int nc) { return nc <= max_nc && (nc * per_ch + 16) * per_cu <= lds_cu && p.kspan >= nc; };
-  if constexpr (32 * per_ch + 16 <= lds_cu) { if (fits(32)) return launch_one<CB, MODE, KT, ST, DL, 32>(x, w, scale, shift, y, p, grid, st); }
-  if constexpr (16 * per_ch + 16 <= lds_cu) { if (fits(16)) return launch_one<CB, MODE, KT, ST, DL, 16>(x, w, scale, shift, y, p, grid, st); }
+  if constexpr (32 * per_ch + 16 <= lds_cu) { if (fits(32)) return launch_one<CB, MODE, KT, ST, DL, 32, 0, 0, TP>(x, w, scale, shift, y, p, grid, st); }
+  if constexpr (16 * per_ch + 16 <= lds_cu) { if (fits(16)) return launch_one<CB, MODE, KT, ST, DL, 16, 0, 0, TP>(x, w, scale, shift, y, p, grid, st); }
   if constexpr (CB <= 2) {
-    if (wgs < g_pf_max_wgs && p.kspan > 8) return launch_one<CB, MODE, KT, ST, DL, 8, 0, 1>(x, w, scale, shift, y, p, grid, st);
+    if (wgs < g_pf_max_wgs && p.kspan > 8) return launch_one<CB, MODE, KT, ST, DL, 8, 0, 1, TP>(x, w, scale, shift, y, p, grid, st);
   }
-  return launch_one<CB, MODE, KT, ST, DL, 8>(x, w, scale, shift, y, p, grid, st);
+  return launch_one<CB, MODE, KT, ST, DL, 8, 0, 0, TP>(x, w, scale, shift, y, p, grid, st);
 }
 
 template <int MODE, int KT, int ST, int DL>
@@ -905,6 +938,15 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   static const int xcd = env_not_zero("TS_CONV_XCD") ? 1 : 0;
   p.xcd = xcd;
   const long long wgs = tiles * p.co_groups;
+  if constexpr (MODE == MODE_D) {
+    // few dozen workgroups: 64-pixel tiles (Geom, TP) -- four times the workgroups, a quarter of the K loop's matrix and staging work each
+    static const long long small = env_ll("TS_CONV_D_SMALL_WGS", 256);   // measured 0 / 64 / 128 / 256 / 512 / 1024: 1129 / 1156 / 1165 / 1165 / 1162 / 1153 pairs/s, one pass at a time 768 / 795 / 798 / 812 / 811 / 809
+    if (wgs <= small && cb == 1) {
+      const int gx64 = (p.H * p.W + 63) / 64;
+      const dim3 grid64(gx64, grid_y, B * p.co_groups * p.ksplit);
+      return launch_nc<1, MODE, KT, ST, DL, 64>(4 * wgs, x, w, scale, shift, y, p, grid64, st);
+    }
+  }
   const dim3 grid(grid_x, grid_y, B * p.co_groups * p.ksplit);
   if (cb == 4) return launch_nc<4, MODE, KT, ST, DL>(wgs, x, w, scale, shift, y, p, grid, st);
   if (cb == 2) return launch_nc<2, MODE, KT, ST, DL>(wgs, x, w, scale, shift, y, p, grid, st);

@@ -88,8 +88,9 @@ struct IG {
 template <int MODE, int KT, int ST, int DL, int TP = 256>
 struct Geom {
   static constexpr int NTR = (MODE == MODE_D) ? KT : 1;                 // planes staged per channel (MODE_D)
-  static constexpr int in_rows = (MODE == MODE_HW) ? 7 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 10 : 9) : 1);
-  static constexpr int in_cols = (MODE == MODE_HW) ? 31 * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? 34 : 33) : TP);
+  static constexpr int TRW = (TP == 64) ? 4 : 8, TCW = (TP == 64) ? 16 : 32;   // MODE_HW output tile (rows x columns)
+  static constexpr int in_rows = (MODE == MODE_HW) ? (TRW - 1) * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? TRW + 2 : TRW + 1) : 1);
+  static constexpr int in_cols = (MODE == MODE_HW) ? (TCW - 1) * ST + 2 * DL + 1 : ((MODE == MODE_HWT) ? ((KT == 16) ? TCW + 2 : TCW + 1) : TP);
   static constexpr int pitch = (MODE == MODE_D) ? TP : (in_cols | 1);
   // staged elements per thread and channel: the tile is dealt linearly to the 256 threads (a (row, column-of-64) deal
   // wasted over half of the load slots on a 10 x 34 tile)
@@ -118,7 +119,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
                const float* __restrict__ shift, float* __restrict__ y, const IG p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!PR || (MODE == MODE_HW && KT == 9 && ST == 1 && CB == 1 && NC >= 8), "row pairing: stride-1 (1,3,3), Cout <= 8");
-  static_assert(TP == 256 || (TP == 64 && MODE == MODE_D), "64-pixel tiles: (k,1,1) layers");
+  static_assert(TP == 256 || (TP == 64 && (MODE == MODE_D || MODE == MODE_HWT || (MODE == MODE_HW && !PR))), "64-pixel tiles: not the row-paired form");
   using G = Geom<MODE, KT, ST, DL, TP>;
   constexpr int WP = (CB * 16) | 16;                  // weight row pitch (k-slots on disjoint banks)
   constexpr int NTR = G::NTR, RQ = (MODE == MODE_D) ? NTR : G::RQ_HW;
@@ -150,11 +151,11 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
   if (MODE == MODE_HWT) { pa = (tile & 3) >> 1; pbit = tile & 1; tile >>= 2; }
   int iy0 = 0, ix0 = 0, ty0 = 0, tx0 = 0;
   if (MODE == MODE_HW) {
-    ty0 = (tile / p.tiles_x) * 8; tx0 = (tile % p.tiles_x) * 32;
+    ty0 = (tile / p.tiles_x) * G::TRW; tx0 = (tile % p.tiles_x) * G::TCW;
     iy0 = ty0 * ST - DL; ix0 = tx0 * ST - DL;                              // padding == dilation
   } else if (MODE == MODE_HWT) {
     // KT == 9 : k3 s2 p1 op1, taps reach rows/cols {0,+1};  KT == 16: k4 s2 p1, taps reach {-1,0,+1}
-    ty0 = (tile / p.tiles_x) * 8; tx0 = (tile % p.tiles_x) * 32;
+    ty0 = (tile / p.tiles_x) * G::TRW; tx0 = (tile % p.tiles_x) * G::TCW;
     iy0 = ty0 - ((KT == 16) ? 1 : 0); ix0 = tx0 - ((KT == 16) ? 1 : 0);
   }
   float* in_tile = lds;
@@ -267,7 +268,8 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       const int base = (DL == 1) ? wave * 2 : (wave & 1) + 4 * (wave >> 1);
       boff[pb] = kq * chan_elems + base * pitch + (pb & 1) * 16 + j;
     } else {
-      const int row = wave * 2 + (pb >> 1), col = (pb & 1) * 16 + j;
+      // 8 x 32 tile: a wave owns two rows as 2 x 2 blocks of 16 pixels; 4 x 16 tile (TP == 64): one row, one block
+      const int row = (TP == 64) ? wave : wave * 2 + (pb >> 1), col = (TP == 64) ? j : (pb & 1) * 16 + j;
       constexpr int st = (MODE == MODE_HW) ? ST : 1;
       boff[pb] = kq * chan_elems + row * st * pitch + col * st;
     }
@@ -406,11 +408,11 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) a[cb] = wt[cq * 4 * WP + cb * 16];
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
+            for (int pb = 0; pb < NPB; ++pb) bv[pb] = it[boff[pb] + cq * 4 * chan_elems + toff];
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-              for (int pb = 0; pb < 4; ++pb)
+              for (int pb = 0; pb < NPB; ++pb)
                 acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], bv[pb], acc[cb][pb], 0, 0, 0);
           }
         }
@@ -493,7 +495,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
       inside = px < HW;
       opix = static_cast<unsigned>(od) * HW + px;
     } else {
-      int oy = ty0 + wave * 2 + (pb >> 1), ox = tx0 + (pb & 1) * 16 + j;
+      int oy = (TP == 64) ? ty0 + wave : ty0 + wave * 2 + (pb >> 1), ox = (TP == 64) ? tx0 + j : tx0 + (pb & 1) * 16 + j;
       if (MODE == MODE_HWT) {
         inside = oy < p.H && ox < p.W;
         oy = 2 * oy + pa; ox = 2 * ox + pbit;
@@ -893,12 +895,12 @@ int launch_nc(long long wgs, const float* x, const float* w, const float* scale,
   constexpr size_t per_ch = (static_cast<size_t>(G::chan_elems) + static_cast<size_t>(KT) * WP) * sizeof(float);
   constexpr size_t lds_cu = 160 * 1024;
   const size_t per_cu = static_cast<size_t>((wgs + ts::kNumCU - 1) / ts::kNumCU);
-  if constexpr (MODE == MODE_HW) {
+  if constexpr (MODE == MODE_HW && TP == 256) {
     // 3-channel image layers: a 4-channel chunk (one k = 4 MFMA step per tap) instead of 8 with five zero channels
     if (p.Cin <= 4 && p.ksplit == 1) return launch_one<CB, MODE, KT, ST, DL, 4>(x, w, scale, shift, y, p, grid, st);
   }
   const int max_nc = g_chunk_cap;
-  if constexpr (MODE == MODE_HW && KT == 9 && ST == 1 && CB == 1) {
+  if constexpr (MODE == MODE_HW && KT == 9 && ST == 1 && CB == 1 && TP == 256) {
     if (p.Cout <= 8 && g_row_pairing) {           // both output rows of a wave in one 16-row MFMA (see ig_conv_kernel, PR)
       constexpr size_t per_ch2 = (static_cast<size_t>(G::chan_elems) + 12 * WP) * sizeof(float);
       auto fits2 = [&](int nc) { return nc <= max_nc && (nc * per_ch2 + 16) * per_cu <= lds_cu && p.kspan >= nc; };
@@ -943,6 +945,25 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
     static const long long small = env_ll("TS_CONV_D_SMALL_WGS", 256);   // measured 0 / 64 / 128 / 256 / 512 / 1024: 1129 / 1156 / 1165 / 1165 / 1162 / 1153 pairs/s, one pass at a time 768 / 795 / 798 / 812 / 811 / 809
     if (wgs <= small && cb == 1) {
       const int gx64 = (p.H * p.W + 63) / 64;
+      const dim3 grid64(gx64, grid_y, B * p.co_groups * p.ksplit);
+      return launch_nc<1, MODE, KT, ST, DL, 64>(4 * wgs, x, w, scale, shift, y, p, grid64, st);
+    }
+  }
+  if constexpr (MODE == MODE_HW) {
+    // the same for plain (1,3,3) layers: 4 x 16 pixel tiles instead of 8 x 32 (not the row-paired Cout <= 8 form, not the 3-channel image layer)
+    static const long long small_hw = env_ll("TS_CONV_HW_SMALL_WGS", 256);      // measured 0 / 64 / 128 / 256 / 512: 1163 / 1170 / 1174 / 1181 / 1181 pairs/s, one pass at a time 808 / 816 / 823 / 833 / 835
+    if (wgs <= small_hw && cb == 1 && p.Cin > 4 && !(p.Cout <= 8 && ST == 1 && g_row_pairing)) {
+      p.tiles_x = (p.Wo + 15) / 16;
+      const int gx64 = ((p.Ho + 3) / 4) * p.tiles_x;
+      const dim3 grid64(gx64, grid_y, B * p.co_groups * p.ksplit);
+      return launch_nc<1, MODE, KT, ST, DL, 64>(4 * wgs, x, w, scale, shift, y, p, grid64, st);
+    }
+  }
+  if constexpr (MODE == MODE_HWT) {
+    static const long long small_hwt = env_ll("TS_CONV_HW_SMALL_WGS", 256);
+    if (wgs <= small_hwt && cb == 1) {                   // transposed form: 4 x 16 INPUT pixels per tile, four parity classes each
+      p.tiles_x = (p.W + 15) / 16;
+      const int gx64 = ((p.H + 3) / 4) * p.tiles_x * 4;
       const dim3 grid64(gx64, grid_y, B * p.co_groups * p.ksplit);
       return launch_nc<1, MODE, KT, ST, DL, 64>(4 * wgs, x, w, scale, shift, y, p, grid64, st);
     }

@@ -860,7 +860,7 @@ thread_local int g_chunk_cap = 32;
 // this file to the FIRST such lambda (a bool came out holding 192 -- the default of g_pf_max_wgs -- and tested false).
 long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
 bool env_not_zero(const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); }
-const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 1024);    // measured 0 ... 4096: 128-1024 equal with three passes in flight (4096: -0.7 %), one pass at a time 748 / 757 / 765 / 765 pairs/s at 128 / 512 / 1024 / 4096
+const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 512);     // measured again with the 64-pixel tiles in place (their grids count four-fold): 256 / 512 / 1024 = 1191 / 1189 / 1176 pairs/s, one pass at a time 846 / 846 / 841
 // TS_CONV_ROW_PAIRING=0 switches the Cout <= 8 row pairing off (A/B measurements)
 const bool g_row_pairing = env_not_zero("TS_CONV_ROW_PAIRING");
 

@@ -299,6 +299,8 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
     x6_grid = ((H + 7) // 8) * ((W + 31) // 32) * D * B * ((f.cout + 31) // 32)
     x6_ok = X6 and L.ts_conv3d_hw_x6_supported(Cin, f.cout, W, stride, dilation, int(transposed))
     wsb6 = int(L.ts_conv3d_hw_x6_workspace_bytes(B, Cin, f.cout, D, H, W)) if x6_ok else 0
+    if x6_ok and Cin < 32 and x6_grid < 512:
+        x6_ok = False        # one K chunk on a small grid: the f32 kernel on 64-pixel tiles is the shorter launch (16 -> 16 on 5 x 68 x 120: 7.1 vs 8.7 us)
     if x6_ok and (not wsb or x6_grid >= _X6_MIN_GRID or wsb6):
         # fp32 products from bf16 pieces on the bf16 matrix pipe (max error below the f32 kernel's: DESIGN.md section 4; 3/8 of the matrix time);
         # small grids stay on the f32 kernel unless the reduction is long enough for the x6 kernel's own split-K (wsb6 > 0)

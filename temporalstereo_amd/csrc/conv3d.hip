@@ -861,6 +861,8 @@ thread_local int g_chunk_cap = 32;
 long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
 bool env_not_zero(const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); }
 const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 512);     // measured again with the 64-pixel tiles in place (their grids count four-fold): 256 / 512 / 1024 = 1191 / 1189 / 1176 pairs/s, one pass at a time 846 / 846 / 841
+// grids of at most this many 8 x 32 workgroups run the plain (1,3,3) forms on 4 x 16 pixel tiles (launch_ig); measured 0 / 64 / 128 / 256 / 512: 1163 / 1170 / 1174 / 1181 / 1181 pairs/s, one pass at a time 808 / 816 / 823 / 833 / 835
+const long long g_small_hw = env_ll("TS_CONV_HW_SMALL_WGS", 256);
 // TS_CONV_ROW_PAIRING=0 switches the Cout <= 8 row pairing off (A/B measurements)
 const bool g_row_pairing = env_not_zero("TS_CONV_ROW_PAIRING");
 
@@ -951,8 +953,7 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   }
   if constexpr (MODE == MODE_HW) {
     // the same for plain (1,3,3) layers: 4 x 16 pixel tiles instead of 8 x 32 (not the row-paired Cout <= 8 form, not the 3-channel image layer)
-    static const long long small_hw = env_ll("TS_CONV_HW_SMALL_WGS", 256);      // measured 0 / 64 / 128 / 256 / 512: 1163 / 1170 / 1174 / 1181 / 1181 pairs/s, one pass at a time 808 / 816 / 823 / 833 / 835
-    if (wgs <= small_hw && cb == 1 && p.Cin > 4 && !(p.Cout <= 8 && ST == 1 && g_row_pairing)) {
+    if (wgs <= g_small_hw && cb == 1 && p.Cin > 4 && !(p.Cout <= 8 && ST == 1 && g_row_pairing)) {
       p.tiles_x = (p.Wo + 15) / 16;
       const int gx64 = ((p.Ho + 3) / 4) * p.tiles_x;
       const dim3 grid64(gx64, grid_y, B * p.co_groups * p.ksplit);
@@ -960,8 +961,7 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
     }
   }
   if constexpr (MODE == MODE_HWT) {
-    static const long long small_hwt = env_ll("TS_CONV_HW_SMALL_WGS", 256);
-    if (wgs <= small_hwt && cb == 1) {                   // transposed form: 4 x 16 INPUT pixels per tile, four parity classes each
+    if (wgs <= g_small_hw && cb == 1) {                   // transposed form: 4 x 16 INPUT pixels per tile, four parity classes each
       p.tiles_x = (p.W + 15) / 16;
       const int gx64 = ((p.H + 3) / 4) * p.tiles_x * 4;
       const dim3 grid64(gx64, grid_y, B * p.co_groups * p.ksplit);
@@ -1274,16 +1274,24 @@ int cout_bucket(int cout) {
 
 // Split-K factor of a (1,3,3) convolution: long reductions on grids too small to fill the chip are cut
 // into slices handled by separate workgroups (partials summed in a fixed order afterwards).
-int conv_hw_ksplit(int B, int Cin, int Cout, int D, int Ho, int Wo) {
+int conv_hw_ksplit(int B, int Cin, int Cout, int D, int Ho, int Wo, int stride) {
   const long long tiles = static_cast<long long>((Ho + 7) / 8) * ((Wo + 31) / 32) * D * B;
   const int groups = (Cout + 15) / 16;
   int ks = 1;
+  // layers that will run on 4 x 16 pixel tiles (launch_ig) have four times the workgroups already: with those, slices pay only while
+  // the grid stays below one workgroup per CU (tools/exp/f32_splitk_bench.py with the small tiles in place: 64 -> 64 on 6 x 17 x 30 in
+  // two slices 10.6 us, unsplit 8.8; 128 -> 64 on 68 x 120 in four 28.6, unsplit 24.7; 128 -> 16 on 68 x 120 12.6 vs 13.1)
+  const bool small_form = Cin > 4 && !(Cout <= 8 && stride == 1 && g_row_pairing) && tiles * groups <= g_small_hw;
+  if (small_form) {
+    const long long tiles64 = static_cast<long long>((Ho + 3) / 4) * ((Wo + 15) / 16) * D * B;
+    while (ks < 8 && tiles64 * groups * ks < ts::kNumCU && Cin / (ks * 2) >= 32) ks *= 2;
+    return ks;
+  }
   // up to 2 workgroups per CU (round 3, tools/exp/f32_splitk_bench.py: every split layer of config 2 gains 1-38 us from it except the
   // row-paired 176 -> 8 on 5 x 136 x 240, whose 680 workgroups were cut in two under the former 3-per-CU bound: 68.7 vs 65.7 us unsplit)
   while (ks < 8 && tiles * groups * ks < 2 * ts::kNumCU && Cin / (ks * 2) >= 32) ks *= 2;
   return ks;
 }
-
 }  // namespace
 
 // x [B,Cin,D,H,W] -> y [B,Cout,D,Ho,Wo]; w_t is [Cin][3][3][CoutPad] with CoutPad = ts_conv_cout_pad(Cout)
@@ -1328,7 +1336,7 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
   p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
   p.tiles_x = (p.Wo + 31) / 32;
   const int tiles = ((p.Ho + 7) / 8) * p.tiles_x;
-  const int ksplit = conv_hw_ksplit(B, Cin, Cout, D, p.Ho, p.Wo);
+  const int ksplit = conv_hw_ksplit(B, Cin, Cout, D, p.Ho, p.Wo, stride);
   const size_t need = static_cast<size_t>(ksplit) * B * Cout * D * p.Ho * p.Wo * sizeof(float);
   const bool split = ksplit > 1 && workspace != nullptr && workspace_bytes >= need;
   if (split) {
@@ -1681,7 +1689,7 @@ extern "C" int ts_conv_set_chunk_cap(int cap) {
 extern "C" size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride, int transposed) {
   if (transposed || B <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const int ks = conv_hw_ksplit(B, Cin, Cout, D, Ho, Wo);
+  const int ks = conv_hw_ksplit(B, Cin, Cout, D, Ho, Wo, stride);
   return ks > 1 ? static_cast<size_t>(ks) * B * Cout * D * Ho * Wo * sizeof(float) : 0;
 }
 

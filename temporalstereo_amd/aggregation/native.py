@@ -249,6 +249,8 @@ X6 = os.environ.get("TS_CONV_X6", "1") != "0"
 # (round 3: long reductions on small grids, ts_conv3d_hw_x6_workspace_bytes > 0).  Measured 32 ... 384: 128 best at batch 1, flat at 4;
 # layer by layer: tools/exp/x6_splitk_bench.py.
 _X6_MIN_GRID = int(os.environ.get("TS_CONV_X6_MIN_GRID", "128"))
+# ... and where the f32 kernel would not split its reduction (Cin < 64), from this many x6 workgroups
+_X6_MIN_GRID_UNSPLIT = int(os.environ.get("TS_CONV_X6_MIN_GRID_UNSPLIT", "64"))
 
 
 def x6_weights(f):
@@ -301,9 +303,10 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
     wsb6 = int(L.ts_conv3d_hw_x6_workspace_bytes(B, Cin, f.cout, D, H, W)) if x6_ok else 0
     if x6_ok and Cin < 32 and x6_grid < 512:
         x6_ok = False        # one K chunk on a small grid: the f32 kernel on 64-pixel tiles is the shorter launch (16 -> 16 on 5 x 68 x 120: 7.1 vs 8.7 us)
-    if x6_ok and (not wsb or x6_grid >= _X6_MIN_GRID or wsb6):
+    if x6_ok and (x6_grid >= _X6_MIN_GRID or wsb6 or (not wsb and x6_grid >= _X6_MIN_GRID_UNSPLIT)):
         # fp32 products from bf16 pieces on the bf16 matrix pipe (max error below the f32 kernel's: DESIGN.md section 4; 3/8 of the matrix time);
-        # small grids stay on the f32 kernel unless the reduction is long enough for the x6 kernel's own split-K (wsb6 > 0)
+        # small grids stay on the f32 kernel (64-pixel tiles, its own split-K) unless the reduction is long enough for the x6 kernel's
+        # split-K (wsb6 > 0) -- also where the f32 kernel would not split: 32 -> 32 on 3 x 34 x 60 is 6.2 us there against 15.7 us on x6
         ws6 = torch.empty(wsb6, device=x.device, dtype=torch.uint8) if wsb6 else None
         rc = L.ts_conv3d_hw_x6_fwd(_lib.ptr(x), _lib.ptr(x6_weights(f)), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
                                    B, Cin, f.cout, D, H, W, dilation, f.act if act is None else act, float(act_param),

@@ -863,6 +863,10 @@ bool env_not_zero(const char* name) { const char* e = getenv(name); return !(e &
 const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 512);     // measured again with the 64-pixel tiles in place (their grids count four-fold): 256 / 512 / 1024 = 1191 / 1189 / 1176 pairs/s, one pass at a time 846 / 846 / 841
 // grids of at most this many 8 x 32 workgroups run the plain (1,3,3) forms on 4 x 16 pixel tiles (launch_ig); measured 0 / 64 / 128 / 256 / 512: 1163 / 1170 / 1174 / 1181 / 1181 pairs/s, one pass at a time 808 / 816 / 823 / 833 / 835
 const long long g_small_hw = env_ll("TS_CONV_HW_SMALL_WGS", 256);
+// small grids of Cout <= 8 layers with 64+ input channels: 4 x 16 tiles (plain form, half of each MFMA idle, no split-K) instead of the
+// row-paired 8 x 32 form -- 64 -> 2 on 14 x 34 x 60 (the coarse prediction heads) 14.1 -> 10.1 us, 128 -> 8 on 136 x 240 20.1 -> 16.5;
+// 32 -> 2 on 7 x 68 x 120 would lose (9.4 -> 10.4)
+const bool g_small_over_pairing = env_ll("TS_CONV_SMALL_OVER_PAIRING", 1) != 0;
 // TS_CONV_ROW_PAIRING=0 switches the Cout <= 8 row pairing off (A/B measurements)
 const bool g_row_pairing = env_not_zero("TS_CONV_ROW_PAIRING");
 
@@ -953,7 +957,7 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
   }
   if constexpr (MODE == MODE_HW) {
     // the same for plain (1,3,3) layers: 4 x 16 pixel tiles instead of 8 x 32 (not the row-paired Cout <= 8 form, not the 3-channel image layer)
-    if (wgs <= g_small_hw && cb == 1 && p.Cin > 4 && !(p.Cout <= 8 && ST == 1 && g_row_pairing)) {
+    if (wgs <= g_small_hw && cb == 1 && p.Cin > 4 && !(p.Cout <= 8 && ST == 1 && g_row_pairing && !(g_small_over_pairing && p.Cin >= 64))) {
       p.tiles_x = (p.Wo + 15) / 16;
       const int gx64 = ((p.Ho + 3) / 4) * p.tiles_x;
       const dim3 grid64(gx64, grid_y, B * p.co_groups * p.ksplit);
@@ -1281,7 +1285,7 @@ int conv_hw_ksplit(int B, int Cin, int Cout, int D, int Ho, int Wo, int stride) 
   // layers that will run on 4 x 16 pixel tiles (launch_ig) have four times the workgroups already: with those, slices pay only while
   // the grid stays below one workgroup per CU (tools/exp/f32_splitk_bench.py with the small tiles in place: 64 -> 64 on 6 x 17 x 30 in
   // two slices 10.6 us, unsplit 8.8; 128 -> 64 on 68 x 120 in four 28.6, unsplit 24.7; 128 -> 16 on 68 x 120 12.6 vs 13.1)
-  const bool small_form = Cin > 4 && !(Cout <= 8 && stride == 1 && g_row_pairing) && tiles * groups <= g_small_hw;
+  const bool small_form = Cin > 4 && !(Cout <= 8 && stride == 1 && g_row_pairing && !(g_small_over_pairing && Cin >= 64)) && tiles * groups <= g_small_hw;
   if (small_form) {
     const long long tiles64 = static_cast<long long>((Ho + 3) / 4) * ((Wo + 15) / 16) * D * B;
     while (ks < 8 && tiles64 * groups * ks < ts::kNumCU && Cin / (ks * 2) >= 32) ks *= 2;

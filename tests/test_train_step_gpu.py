@@ -13,23 +13,22 @@ H, W, NS = 128, 256, 8
 
 
 def _setup(dev, seed=5):
+    """The committed trained checkpoint on a planted-disparity two-frame scene with its own poses.  (Rounds 1-2 ran this file on random
+    weights and independent noise features: such a network amplifies the last-bit differences that the fp32 atomics of the splat and of a
+    few backward kernels leave between ANY two runs -- first-step gradients of two runs differed by 1 % of their norm once in eight
+    runs, second-step losses by 3 % -- which made a comparison of two runs a coin toss in the full suite.)"""
     import bench
-    net = bench.build_model(dev, seed, NS)
+    net = bench.load_trained(bench.build_model(dev, seed, NS)).train()
+    sc = synth.stereo_sequence(synth.SEED0 + seed, 1, H, W, frames=2, max_disp=16 * NS)
+    to = lambda a: torch.from_numpy(a).to(dev)
     frames = []
-    for t in range(2):
-        lf, rf, il, ir = bench.make_inputs(dev, seed + 1000 * t, 1, (H, W))
+    for t, (lf, rf, il, ir) in enumerate(sc["frames"]):
+        lf, rf = [to(x) for x in lf], [to(x) for x in rf]
         if t == 1:
             lf, rf = [x.requires_grad_(True) for x in lf], [x.requires_grad_(True) for x in rf]
-        frames.append((lf, rf, il, ir))
-    bench.calibrate_batchnorm(net, frames[0])
-    gt = torch.from_numpy(synth.smooth(synth.normal(seed, "gt", (1, 1, H, W))) * 8.0 + 30.0).to(dev)
-    K = np.eye(4, dtype=np.float32)
-    K[0, 0] = K[1, 1] = 300.0
-    K[0, 2], K[1, 2] = W / 2 - 0.5, H / 2 - 0.5
-    K = torch.from_numpy(K[None]).to(dev)
-    T = torch.from_numpy(synth.small_motion(seed, 1)).to(dev)
+        frames.append((lf, rf, to(il), to(ir)))
     eye = torch.eye(4, device=dev).expand(1, 4, 4).contiguous()
-    return net, frames, gt, K, [(eye, eye), (T, eye)]
+    return net, frames, to(sc["gt"][1]), to(sc["K"]), [(eye, eye), (to(sc["T"][1]), eye)]
 
 
 def _run(graph, steps=4):
@@ -54,15 +53,21 @@ def test_eager_step_learns():
 
 
 def test_graph_replay_follows_the_eager_trajectory():
-    """Same initial weights, inputs and optimizer: the replayed step must stay on the eager step's loss curve (the fp32
-    atomics of a few backward kernels make the two runs differ in the last bits; the warm-up passes of the capture leave
-    no trace in BatchNorm's running statistics)."""
-    eager, ge, _ = _run(False)
-    graph, gg, net = _run(True)
+    """Same initial weights, inputs and optimizer: the replayed step computes the eager step's loss and gradients and stays on its loss
+    curve (the warm-up passes of the capture leave no trace in BatchNorm's running statistics).  Measured spread between any two runs on
+    this checkpoint and scene (fp32 atomics in the splat and a few backward kernels): first-step gradients 2-5e-6 of their norm, losses
+    1e-7 for two steps and 1.3e-5 at the third; the bounds below are 20x that."""
+    e1, ge1, _ = _run(False, steps=1)
+    g1, gg1, _ = _run(True, steps=1)
+    np.testing.assert_allclose(g1[0], e1[0], rtol=1e-5)
+    assert set(gg1) == set(ge1) and len(gg1) > 200
+    num = sum(float(((gg1[n].double() - ge1[n].double()) ** 2).sum()) for n in ge1)
+    den = sum(float((ge1[n].double() ** 2).sum()) for n in ge1)
+    assert (num / den) ** 0.5 < 1e-4, (num, den)
+    eager, ge, _ = _run(False, steps=3)
+    graph, gg, net = _run(True, steps=3)
     assert all(np.isfinite(graph)), graph
-    # identical first step; afterwards the last-bit differences of the atomics grow through the updates of a random-weight
-    # network (the eager run against itself behaves the same), so the curve is compared while that growth is small
-    for i, rtol in enumerate((1e-4, 1e-2)):               # (two eager runs differ by 10 % at the third step)
+    for i, rtol in enumerate((1e-5, 1e-4, 1e-3)):
         np.testing.assert_allclose(graph[i], eager[i], rtol=rtol, err_msg="step %d: %s vs %s" % (i, graph, eager))
     assert all(bool(torch.isfinite(g).all()) for g in gg.values())
     assert all(bool(torch.isfinite(p).all()) for p in net.parameters())

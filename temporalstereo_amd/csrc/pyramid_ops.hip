@@ -164,7 +164,7 @@ struct Merge {
 // Appendix B.2), write the sorted disparities, and move each candidate's C-channel column of the
 // volume to its sorted slot.  Memory candidates get their volume from past_conv:
 // Conv3d(1->C, 1x1x1, no bias) + BatchNorm + SiLU of the remembered cost (coarse.py:42,98).
-constexpr int MERGE_CPB = 4;    // channels moved per workgroup row (grid.y walks channel groups)
+constexpr int MERGE_CPB = 2;    // channels moved per workgroup row (grid.y walks channel groups); 4 / 2 / 1: 11.5 / 9.3 / 8.5 us at the coarse level, 22.3 / 18.4 / 18.8 at batch 4
 
 // DM: compile-time bound on the candidate count.  Every load is unconditional (indices clamped, results
 // selected afterwards) and issued before anything waits, so a lane pays ONE memory round trip for its

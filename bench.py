@@ -57,6 +57,8 @@ def k1_algorithmic_bytes(B, C, H, W, D, sampled):
     form that leaves out the D-fold repeat of the left features (ts_block_cost_sampled_warped_fwd)."""
     if sampled == "warped":
         return 4 * B * H * W * (2 * C + D + (C + 3 * C // 8) * D)
+    if sampled == "corr":           # the correlation blocks alone (ts_block_cost_sampled_corr_fwd)
+        return 4 * B * H * W * (2 * C + D + (3 * C // 8) * D)
     if sampled:
         return 4 * B * H * W * (2 * C + D + (2 * C + 3 * C // 8) * D)
     return 4 * B * H * W * (2 * C + (C + 3 * C // 8) * D)
@@ -133,7 +135,8 @@ class K1Probe:
 
     def __enter__(self):
         self.TF._k1_probe = self._probe
-        self._orig = {"block_cost": self.TF.block_cost, "block_cost_warped": self.TF.block_cost_warped}
+        self._orig = {"block_cost": self.TF.block_cost, "block_cost_warped": self.TF.block_cost_warped,
+                      "block_cost_corr": self.TF.block_cost_corr}
 
         def remember(name):
             orig = self._orig[name]
@@ -141,7 +144,7 @@ class K1Probe:
             def f(reference_fm, target_fm, disp_sample, block_cost_scale=3):
                 B, C, H, W = reference_fm.shape
                 sampled = not isinstance(disp_sample, int)
-                kind = "warped" if name == "block_cost_warped" else sampled
+                kind = "warped" if name == "block_cost_warped" else ("corr" if name == "block_cost_corr" else sampled)
                 key = (B, C, H, W, disp_sample.shape[1] if sampled else disp_sample, kind)
                 if key not in self.calls:
                     self.calls[key] = (orig, reference_fm.detach(), target_fm.detach(),
@@ -177,13 +180,15 @@ class K1Probe:
         st = torch.cuda.current_stream().cuda_stream
         calls = dict(self.calls)
         for key, (fn, l, r, d, sc) in self.calls.items():
-            if key[5] == "warped":     # also time the complete op on the same tensors: SURVEY.md section 8(d)'s
+            if key[5] in ("warped", "corr"):     # also time the complete op on the same tensors: SURVEY.md section 8(d)'s
                 calls.setdefault(key[:5] + (True,), (None, l, r, d, sc))            # unfused-boundary figure
+            if key[5] == "corr":                 # ... and the variant of rounds 1-3 (volume without its reference half)
+                calls.setdefault(key[:5] + ("warped",), (None, l, r, d, sc))
         out_t = {}
         for key, (_, l, r, d, sc) in calls.items():
             B, C, H, W, D, kind = key
             l, r = l.contiguous(), r.contiguous()
-            ctot = {True: 2 * C, "warped": C, False: C}[kind] + sc * (C // 8)
+            ctot = {True: 2 * C, "warped": C, False: C, "corr": 0}[kind] + sc * (C // 8)
             out = torch.empty((B, ctot, D, H, W), device=l.device, dtype=torch.float32)
             ws = torch.empty(max(int(L.ts_block_cost_workspace_bytes(B, C, H, W, D, sc)), 256), device=l.device, dtype=torch.uint8)
             if kind is False:
@@ -191,6 +196,9 @@ class K1Probe:
             elif kind is True:
                 dd = d.contiguous()
                 launch = lambda: L.ts_block_cost_sampled_fwd(l.data_ptr(), r.data_ptr(), dd.data_ptr(), out.data_ptr(), ws.data_ptr(), B, C, H, W, D, sc, st)
+            elif kind == "corr":
+                dd = d.contiguous()
+                launch = lambda: L.ts_block_cost_sampled_corr_fwd(l.data_ptr(), r.data_ptr(), dd.data_ptr(), out.data_ptr(), ws.data_ptr(), B, C, H, W, D, sc, st)
             else:
                 dd = d.contiguous()
                 launch = lambda: L.ts_block_cost_sampled_warped_fwd(l.data_ptr(), r.data_ptr(), dd.data_ptr(), out.data_ptr(), ws.data_ptr(), B, C, H, W, D, sc, st)
@@ -463,12 +471,15 @@ def main():
             step()
         out = step()
         torch.cuda.synchronize()
+        k1_launched = list(k1.calls)                 # what the pipeline itself launched (before the extra measurements below add keys)
         k1_times = k1.measure(max(a.steps, 200)) if rank == 0 else {}
         k1_b4 = None
         if rank == 0 and mode.startswith("native"):
             # the same launch on four pairs: 930 MB per launch, beyond the 256 MiB Infinity Cache (SURVEY.md section 8(d) hygiene)
             from temporalstereo_amd import functional as TF
             key1 = (a.batch, 2 * DIMS['precise']['in_planes'], RUN_H // 4, RUN_W // 4, 5, "warped")
+            if key1 not in k1.calls:
+                key1 = key1[:5] + ("corr",)
             if key1 in k1.calls:
                 _, l1, r1, d1, sc1 = k1.calls[key1]
                 rep = max(1, 4 // a.batch)
@@ -488,6 +499,51 @@ def main():
                              note="same launch on 4 pairs (930 MB per launch: beyond the 256 MiB Infinity Cache); this box's plain fill of that "
                                   "size runs at 4.6-5.4 TB/s, i.e. 0.58-0.68 of the spec figure is the write ceiling")
                 del l4, r4, d4
+        # cost volume + first (1,3,3) layer of the 1/4 level on the pipeline's own tensors, two ways --
+        # materialised (rounds 1-3: volume without its reference half, convolved) and contracted (correlation blocks + the warped half
+        # contracted over channels before the warp: the volume's 2C main channels are never written).  `fused` = the UNFUSED op's
+        # algorithmic bytes over the time of what replaces it.
+        fused = None
+        if rank == 0 and mode.startswith("native"):
+            ckey = (a.batch, 2 * DIMS['precise']['in_planes'], RUN_H // 4, RUN_W // 4, 5, "corr")
+            if ckey not in k1.calls:
+                ckey = ckey[:5] + ("warped",)
+            agg_n = getattr(runner, "net", None)
+            if ckey in k1.calls and hasattr(agg_n, "precise"):
+                from temporalstereo_amd import functional as TF
+                from temporalstereo_amd.aggregation import native as _N
+                _, lq, rq, dq, scq = k1.calls[ckey]
+                pr = agg_n.precise
+                lq, rq, dq = lq.contiguous(), rq.contiguous(), dq.contiguous()
+
+                def timed_us(fn, n=100):
+                    with torch.no_grad():
+                        for _ in range(10):
+                            fn()
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(n):
+                            fn()
+                        e1.record()
+                        torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / n * 1e3
+                with torch.no_grad():
+                    lt, rt = pr.left_term(lq), pr.right_term(rq)
+                t_mat = timed_us(lambda: _N.conv_hw(TF.block_cost_warped(lq, rq, dq, scq), pr.init0.f0, 1, pr.init0.dil, addend=lt))
+                t_con = timed_us(lambda: _N.conv_hw_warp(TF.block_cost_corr(lq, rq, dq, scq), pr.init0_corr, rt, dq, lt.squeeze(2), pr.init0.dil))
+                t_q = timed_us(lambda: pr.right_term(rq))
+                nbf = k1_algorithmic_bytes(*ckey[:5], True)
+                fused = dict(kernels="ts_block_cost_sampled_corr_fwd + ts_conv3d_hw_warp_fwd (gather + (1,3,3) convolution over the correlation "
+                                     "blocks) + the 1x1 pre-contraction right -> Q (ts_conv3d_d_fwd, k = 1; a function of the features only, "
+                                     "issued at the start of a pass)",
+                             replaces="ts_block_cost_sampled_warped_fwd + ts_conv3d_hw_fwd over [warped | corr] (rounds 1-3)",
+                             mean_us=t_con + t_q, on_the_level_chain_us=t_con, precontraction_us=t_q, replaced_mean_us=t_mat,
+                             unfused_algorithmic_bytes=nbf, equivalent=nbf / ((t_con + t_q) * 1e-6) / 1e9, unit="GB/s",
+                             frac=nbf / ((t_con + t_q) * 1e-6) / HBM_PEAK, in_use=bool(_N.FUSED_K1),
+                             note="algorithmic bytes of the UNFUSED cost-volume op (SURVEY 8(d)) over the time of cost volume + first layer "
+                                  "in the contracted form; both forms include the first layer's convolution, so compare mean_us with "
+                                  "replaced_mean_us, and `equivalent` with the unfused op's `achieved` only as a bytes-never-moved figure")
         if a.calibrate and rank == 0:
             from temporalstereo_amd import _lib
             nbytes = 1 << 30
@@ -611,9 +667,14 @@ def main():
         if pkey in k1_times:
             nbytes = k1_algorithmic_bytes(*pkey)
             ach = nbytes / k1_times[pkey]
-            used = [k for k in k1_times if not (k[5] is True and k[:5] + ("warped",) in k1_times)]   # what the pipeline launched
+            # all three levels, each as the COMPLETE op at its unfused boundary (329.3 MB per pair at batch 1)
+            used = [k for k in k1_times if k[5] is True or k[5] is False]
             all_b = sum(k1_algorithmic_bytes(*k) for k in used)
             all_t = sum(k1_times[k] for k in used)
+            # ... and what the pipeline itself launches at each level (round 4: the correlation blocks alone at the sampled levels)
+            launched = [k for k in k1_launched if k in k1_times]
+            lau_b = sum(k1_algorithmic_bytes(*k) for k in launched)
+            lau_t = sum(k1_times[k] for k in launched)
             traffic, traffic_file = None, None
             for cand in ("r03_k1_hbm_traffic_pmc.json", "r02_k1_hbm_traffic_pmc.json"):
                 try:    # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected in-process)
@@ -624,6 +685,8 @@ def main():
                         break
                 except (OSError, ValueError, KeyError):
                     pass
+            ckey_p = pkey[:5] + ("corr",)
+            vkey = ckey_p if ckey_p in k1.calls else wkey
             roofline = dict(bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
                             traffic=traffic,
                             measured="HIP events on the launch stream around %d back-to-back C-ABI launches on the pipeline's "
@@ -632,14 +695,24 @@ def main():
                                    "[%d,%d,%d,%d] x %d candidates" % pkey[:5],
                             algorithmic_bytes=nbytes, mean_us=k1_times[pkey] * 1e6,
                             frac_of_measured_copy_ceiling=ach / 6.29e12,
-                            pipeline_variant=(dict(kernel="ts_block_cost_sampled_warped_fwd (volume without the D-fold repeat of "
-                                                          "the left features; what the native pipeline launches)",
-                                                   algorithmic_bytes=k1_algorithmic_bytes(*wkey), mean_us=k1_times[wkey] * 1e6,
-                                                   achieved=k1_algorithmic_bytes(*wkey) / k1_times[wkey] / 1e9,
-                                                   frac=k1_algorithmic_bytes(*wkey) / k1_times[wkey] / HBM_PEAK)
-                                              if wkey in k1_times else None),
+                            pipeline_variant=(dict(kernel=("ts_block_cost_sampled_corr_fwd (the correlation blocks alone: the first layer takes the "
+                                                           "warped half in pre-contracted form, see `fused`)" if vkey[5] == "corr" else
+                                                           "ts_block_cost_sampled_warped_fwd (volume without the D-fold repeat of "
+                                                           "the left features)") + "; what the native pipeline launches",
+                                                   algorithmic_bytes=k1_algorithmic_bytes(*vkey), mean_us=k1_times[vkey] * 1e6,
+                                                   achieved=k1_algorithmic_bytes(*vkey) / k1_times[vkey] / 1e9,
+                                                   frac=k1_algorithmic_bytes(*vkey) / k1_times[vkey] / HBM_PEAK)
+                                              if vkey in k1_times else None),
+                            warped_variant=(dict(kernel="ts_block_cost_sampled_warped_fwd (rounds 1-3: volume without the D-fold repeat of the left features)",
+                                                 algorithmic_bytes=k1_algorithmic_bytes(*wkey), mean_us=k1_times[wkey] * 1e6,
+                                                 frac=k1_algorithmic_bytes(*wkey) / k1_times[wkey] / HBM_PEAK) if wkey in k1_times else None),
                             all_levels=dict(algorithmic_bytes=all_b, mean_us=all_t * 1e6,
-                                            achieved=all_b / all_t / 1e9, frac=all_b / all_t / HBM_PEAK),
+                                            achieved=all_b / all_t / 1e9, frac=all_b / all_t / HBM_PEAK,
+                                            note="coarse (int) + fine + precise (sampled), each the complete op at its unfused boundary"),
+                            all_levels_as_launched=dict(algorithmic_bytes=lau_b, mean_us=lau_t * 1e6, achieved=lau_b / lau_t / 1e9,
+                                                        frac=lau_b / lau_t / HBM_PEAK,
+                                                        note="the variants the pipeline launches, with THEIR algorithmic bytes (rounds 1-3 reported this as all_levels)"),
+                            fused=fused,
                             beyond_infinity_cache=k1_b4,
                             traffic_source="profiles/%s: FETCH_SIZE / WRITE_SIZE passes of this command under rocprofv3 (tools/k1_traffic.py, "
                                            "tools/prof_r03.sh); a PMC pass cannot run inside the timed process" % traffic_file)

@@ -60,6 +60,12 @@ int ts_block_cost_sampled_warped_fwd(const float* left, const float* right, cons
                                      void* workspace, int B, int C, int H, int W, int D, int scales,
                                      void* stream);
 
+/* Correlation blocks only (ABI 6): out [B, scales*C/8, D, H, W] = channels [2C:] of ts_block_cost_sampled_fwd.  The consumer is
+ * ts_conv3d_hw_warp_fwd, which needs neither half of the 2C main channels as a volume. */
+int ts_block_cost_sampled_corr_fwd(const float* left, const float* right, const float* disp, float* out,
+                                   void* workspace, int B, int C, int H, int W, int D, int scales,
+                                   void* stream);
+
 /* Dense siblings of block_cost (forward only): any number of candidates D >= 2, C % 8 == 0.
  *   cat_fms  aggregation/utils/cat_fms.py:5-36   out [B,2C,D,H,W] = cat[left repeated over D, warped right]
  *   dif_fms  aggregation/utils/dif_fms.py:5-44   out [B, C,D,H,W] = |left - warped right|, elements whose warped
@@ -284,6 +290,24 @@ int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* scale, const
 /* addend (may be NULL): [B, Cout, Ho, Wo] (batch stride addend_bstride elements), added to the raw sum of
  * EVERY depth plane before scale / shift / activation -- the D-invariant part of a convolution over a
  * volume whose leading channels are a broadcast (see ts_block_cost_sampled_warped_fwd). */
+/* ABI 6 -- the first (1,3,3) layer of a sampled level without its warped input volume (reference
+ * precise.py:88-91, fine.py:96-103 over block_cost.py:47-81).  The warp of block_cost's sampled path is a two-tap interpolation along
+ * x whose weights do not depend on the channel, and the convolution contracts over channels, so the two commute:
+ *     sum_c W[co][c][t] warp(right)[c][d][p]  ==  lerp(Q[t*Cout + co][row of p], x_p - disp[d][p]),
+ *     Q[t*Cout + co] = sum_c W[co][C + c][t] right[c]      (a 1x1 convolution, [B, 9*Cout, H, W], made with ts_conv3d_d_fwd, k = 1)
+ * i.e. layer(cat[left x D | warp | corr]) = act(scale * (conv_{W[:, 2C:]}(corr) + T) + shift),
+ *     T[co][d][y][x] = base[co][y][x] + sum_{t=(ky,kx)} lerp(Q[t*Cout+co][y+(ky-1)dil], x+(kx-1)dil - disp[d][y+(ky-1)dil][x+(kx-1)dil])
+ * with zero for tap pixels outside the image (the convolution's padding) and for columns outside the row (the warp's padding).
+ *   corr [B,Cc,D,H,W] (ts_block_cost_sampled_corr_fwd), w_t [Cc][9][CoutPad], scale/shift [CoutPad], q [B,9*Cout,H,W] dense,
+ *   disp [B,D,H,W] dense, base [B,Cout,H,W] (the left term conv_{W[:, :C]}(left), or NULL), y [B,Cout,D,H,W].
+ *   workspace: ts_conv3d_hw_warp_workspace_bytes(B, Cout, D, H, W) bytes (T).  Strides in elements as for ts_conv3d_hw_fwd. */
+size_t ts_conv3d_hw_warp_workspace_bytes(int B, int Cout, int D, int H, int W);
+int ts_conv3d_hw_warp_fwd(const float* corr, const float* w_t, const float* scale, const float* shift, float* y,
+                          const float* q, const float* disp, const float* base,
+                          int B, int Cc, int Cout, int D, int H, int W, int dilation, int act, float act_param,
+                          long long in_bstride, long long in_cstride, long long out_bstride, long long out_cstride,
+                          long long base_bstride, void* workspace, size_t workspace_bytes, void* stream);
+
 /* scratch ts_conv3d_hw_fwd can use to split a long reduction over more workgroups (0 = never splits at
  * this shape; passing NULL / too little simply disables the split) */
 size_t ts_conv3d_hw_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W, int stride, int transposed);

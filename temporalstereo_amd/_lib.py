@@ -27,6 +27,9 @@ SIGNATURES = {
     "ts_block_cost_int_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_warped_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
+    "ts_block_cost_sampled_corr_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr] + [c_int] * 6 + [c_ptr]),
+    "ts_conv3d_hw_warp_workspace_bytes": (c_size, [c_int] * 5),
+    "ts_conv3d_hw_warp_fwd": (c_int, [c_f32p] * 8 + [c_int] * 8 + [c_float] + [ctypes.c_longlong] * 5 + [c_ptr, c_size, c_ptr]),
     "ts_cat_fms_fwd": (c_int, [c_f32p] * 4 + [c_int] * 5 + [c_ptr]),
     "ts_dif_fms_workspace_bytes": (c_size, []),
     "ts_dif_fms_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 5 + [c_ptr]),

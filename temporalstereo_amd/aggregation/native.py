@@ -339,6 +339,34 @@ def conv_d(x, f, k, stride=1, dilation=1, padding=0, transposed=False, out=None,
     return out
 
 
+# TS_FUSED_K1=0: the sampled levels build the warped half of their volume and convolve it (rounds 1-3) instead of the
+# pre-contracted form below (A/B measurements; both are held to the same fixtures)
+FUSED_K1 = os.environ.get("TS_FUSED_K1", "1") != "0"
+
+
+def block_cost_corr(left, right, disp, scales):
+    """The correlation blocks of the sampled block_cost alone (functional.block_cost_corr; reached as TF.<name> so that bench.py's
+    K1 probe sees the call)."""
+    return TF.block_cost_corr(left, right, disp, scales)
+
+
+def conv_hw_warp(corr, f, q, disp, base, dilation=1):
+    """First layer of a sampled level from the correlation blocks, the pre-contracted right map `q` and the candidates
+    (ts_conv3d_hw_warp_fwd): [B, Cout, D, H, W]."""
+    B, Cc, D, H, W = corr.shape
+    assert Cc == f.cin, (Cc, f.cin)
+    out = torch.empty((B, f.cout, D, H, W), device=corr.device, dtype=torch.float32)
+    ib, ic = _strides5(corr)
+    ob, oc = _strides5(out)
+    wsb = TF._q("ts_conv3d_hw_warp_workspace_bytes", B, f.cout, D, H, W)
+    ws = torch.empty(wsb, device=corr.device, dtype=torch.uint8)
+    rc = _lib.lib().ts_conv3d_hw_warp_fwd(_lib.ptr(corr), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
+                                          _lib.ptr(q), _lib.ptr(disp), _lib.ptr(base), B, Cc, f.cout, D, H, W, dilation, f.act, 0.0,
+                                          ib, ic, ob, oc, base.stride(0) if base is not None else 0, _lib.ptr(ws), wsb, _stream())
+    _lib.check(rc, "ts_conv3d_hw_warp_fwd")
+    return out
+
+
 def resize_add_act(a, add, size, act=ACT_SILU):
     B, C, Da, Ha, Wa = a.shape
     D, H, W = size
@@ -406,6 +434,29 @@ def range_candidates(disp, rng, extra_front=0):
                                             float(rng), extra_front, extra_front + 5, _stream())
     _lib.check(rc, "ts_range_candidates_fwd")
     return low, high, cand
+
+
+def split_sampled_first_layer(f0, scales):
+    """The (1,3,3) layer over a sampled level's volume [left x D | warped right | corr] (precise.py:88-91, fine.py:96-103) in
+    the pieces the native pipeline runs -> (left, rest, corr, q):
+      left  the raw convolution over the first C channels: they are the left features repeated over D (block_cost.py:51), so this
+            part is computed once per pixel and handed on as a D-invariant addend;
+      rest  the layer over [warped | corr] with the original epilogue (the form of rounds 1-3: ts_block_cost_sampled_warped_fwd);
+      corr  the layer over the correlation blocks alone, and
+      q     the 1x1 convolution right -> Q [9*Cout planes, plane = tap * Cout + co]: the warp is a two-tap interpolation whose
+            weights do not depend on the channel, so it commutes with the layer's channel contraction (ts_conv3d_hw_warp_fwd)."""
+    C = f0.cin * 8 // (16 + scales)                  # cin == 2C + scales * C/8
+    if 2 * C + scales * (C // 8) != f0.cin or f0.kshape != (1, 3, 3):
+        raise NotImplementedError("first aggregation layer is not a (1,3,3) conv over [left | warped | corr]")
+    left, rest = fold_split_input(f0, C)
+    _, corr = fold_split_input(rest, C)
+    q = object.__new__(Folded)
+    q.cin, q.cout, q.kind, q.act, q.kshape = C, 9 * rest.cout, "d", ACT_NONE, (1, 1, 1)
+    pad = int(_lib.lib().ts_conv_cout_pad(q.cout))
+    q.w = torch.zeros(C, 1, pad, device=rest.w.device, dtype=torch.float32)
+    q.w[:, 0, :q.cout] = rest.w[:C, :, :rest.cout].reshape(C, 9 * rest.cout)         # [c][tap][co] -> plane tap * Cout + co
+    q.scale, q.shift = torch.ones(pad, device=q.w.device), torch.zeros(pad, device=q.w.device)
+    return left, rest, corr, q
 
 
 # ------------------------------------------------------------------------------------------- blocks
@@ -534,18 +585,32 @@ class _LevelBase:
         return self.init2(self.hg(self.init0(raw, addend=addend)))
 
     def split_reference_half(self):
-        """Sampled levels: the first C channels of the volume are the left features repeated over D
-        (block_cost.py:51) and init3d starts with a (1,3,3) convolution, so that part of the first
-        layer is computed once per pixel (`left_term`) instead of once per candidate, and the volume
-        is built without it (ts_block_cost_sampled_warped_fwd)."""
-        f0 = self.init0.f0
-        C = f0.cin * 8 // (16 + self.scales)             # cin == 2C + scales * C/8
-        if 2 * C + self.scales * (C // 8) != f0.cin or self.init0.stride != 1 or self.init0.transposed:
+        """Sampled levels: see split_sampled_first_layer."""
+        if self.init0.stride != 1 or self.init0.transposed:
             raise NotImplementedError("first aggregation layer is not a stride-1 conv over [left | warped | corr]")
-        self.init0_left, self.init0.f0 = fold_split_input(f0, C)
+        self.init0_left, self.init0.f0, self.init0_corr, self.init0_q = split_sampled_first_layer(self.init0.f0, self.scales)
 
     def left_term(self, left):
         return conv_hw(left.unsqueeze(2), self.init0_left, 1, self.init0.dil)
+
+    def right_term(self, right):
+        """Q [B, 9*Cout, H, W]: the warped half of the first layer contracted over its channels BEFORE the warp (a function of
+        the right map only: issued with the other feature-only work at the start of a pass)."""
+        return conv_d(right.unsqueeze(2), self.init0_q, 1).squeeze(2)
+
+    def first_layer_fused(self, left, right, ds, lterm, rterm):
+        """init3d[0]'s (1,3,3) half on [corr | Q] instead of on the [warped | corr] volume, then its (k,1,1) half."""
+        corr = block_cost_corr(left, right, ds, self.scales)
+        i0 = self.init0
+        y = conv_hw_warp(corr, self.init0_corr, rterm, ds, lterm.squeeze(2) if lterm.dim() == 5 else lterm, i0.dil)
+        return conv_d(y, i0.f1, i0.k, i0.stride, i0.dil, i0.pad_d, i0.transposed)
+
+    def init3d_from(self, first):
+        return self.init2(self.hg(first))
+
+    def feature_terms(self, left, right):
+        """(left term, right term) of the first layer: functions of the feature maps only."""
+        return self.left_term(left), (self.right_term(right) if FUSED_K1 else None)
 
 
 class _MergingLevel(_LevelBase):
@@ -625,10 +690,14 @@ class NativeFine(_MergingLevel):
         super().__init__(mod)
         self.split_reference_half()
 
-    def __call__(self, left, right, ds, prev_info, mask=None, left_term=None, next_range=None):
-        raw = TF.block_cost_warped(left, right, ds, self.scales)
-        lt = left_term() if callable(left_term) else (left_term if left_term is not None else self.left_term(left))
-        return self.merge_fuse_predict(self.init3d(raw, lt), ds, prev_info, left, resize_memory=False, mask=mask, next_range=next_range)
+    def __call__(self, left, right, ds, prev_info, mask=None, terms=None, next_range=None):
+        """terms: feature_terms(left, right), or a callable returning it (produced on another stream: the callable joins it)."""
+        lt, rt = terms() if callable(terms) else (terms if terms is not None else self.feature_terms(left, right))
+        if rt is not None:
+            vol = self.init3d_from(self.first_layer_fused(left, right, ds, lt, rt))
+        else:
+            vol = self.init3d(TF.block_cost_warped(left, right, ds, self.scales), lt)
+        return self.merge_fuse_predict(vol, ds, prev_info, left, resize_memory=False, mask=mask, next_range=next_range)
 
 
 class NativePrecise(_LevelBase):
@@ -692,7 +761,7 @@ class NativePrecise(_LevelBase):
         C32, C2 = self.deconv4.cout, self.enc[1].cout
         cat2 = torch.empty((B, C32 + C2, 2 * H, 2 * W), device=left.device, dtype=torch.float32)      # [deconv4 | s2 of the left view]
         self.encode(left_image, right_image, both, cat2[:, C32:].unsqueeze(2))
-        lterm = self.left_term(lcat)
+        lterm = self.feature_terms(lcat, rcat)
         f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)
         self._deconv(_lib.contiguous(f), self.deconv4, cat2, cat2.stride(0))
         g = _lib.contiguous(self._c2d(cat2.unsqueeze(2), self.concat, 1).squeeze(2))
@@ -705,8 +774,12 @@ class NativePrecise(_LevelBase):
         H, W = both.shape[-2:]
         mask, lterm = mask_lterm
         lcat, rcat = both[:B], both[B:]
-        raw = TF.block_cost_warped(lcat, rcat, ds, self.scales)
-        cost, off = self.heads(self.init3d(raw, lterm))
+        lt, rt = lterm
+        if rt is not None:
+            vol = self.init3d_from(self.first_layer_fused(lcat, rcat, ds, lt, rt))
+        else:
+            vol = self.init3d(TF.block_cost_warped(lcat, rcat, ds, self.scales), lt)
+        cost, off = self.heads(vol)
         disp, mem_s, mem_c = TF.topk_softargmax(cost, ds, off, k=self.topk)
         full = torch.empty((B, 1, 4 * H, 4 * W), device=both.device, dtype=torch.float32)
         rc = _lib.lib().ts_unet_upsample_fwd(_lib.ptr(mask), _lib.ptr(disp), _lib.ptr(full), B, H, W, 4 * H, 4 * W, _stream())
@@ -753,10 +826,10 @@ class NativeAggregator:
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
 
-    def _fine_level(self, l8, r8, ds, prev_info, out, mask=None, left_term=None):
+    def _fine_level(self, l8, r8, ds, prev_info, out, mask=None, terms=None):
         rng = 4
         disps, costs, offs, samples, ranges = out
-        (d, low, high, ds), c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, mask, left_term, (rng, 0))
+        (d, low, high, ds), c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, mask, terms, (rng, 0))
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
 
@@ -778,7 +851,7 @@ class NativeAggregator:
             _chunk_cap(8)
             with torch.cuda.stream(self.fast):
                 mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
-                ltf = self.fine.left_term(_lib.contiguous(l8))
+                ltf = self.fine.feature_terms(_lib.contiguous(l8), _lib.contiguous(r8))
                 ds = self._coarse_level(l16, r16, prev_info, out, lambda: mc)
             both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
             _edge(self.fast, self.aux)
@@ -814,7 +887,7 @@ class NativeAggregator:
                 _chunk_cap(8)
                 with torch.cuda.stream(self.aux):
                     mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
-                    ltf = self.fine.left_term(_lib.contiguous(l8))
+                    ltf = self.fine.feature_terms(_lib.contiguous(l8), _lib.contiguous(r8))
                     _lib.check(L.ts_event_record(slots[1], P(self.aux)), "ts_event_record")
                 with torch.cuda.stream(self.fast):
                     vol = self.coarse.early(_lib.contiguous(l16), _lib.contiguous(r16))
@@ -881,7 +954,7 @@ class NativeAggregator:
                 # convex-upsampling logits of the coarse and fine levels depend on the features only
                 with torch.cuda.stream(aux):
                     mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
-                    ltf = self.fine.left_term(_lib.contiguous(l8))
+                    ltf = self.fine.feature_terms(_lib.contiguous(l8), _lib.contiguous(r8))
 
                 waited = []
 

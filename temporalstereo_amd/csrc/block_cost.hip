@@ -32,7 +32,8 @@ struct Shape {
   int G;          // C / 8
   int mainC;      // C (int path) or 2C (sampled path; C when the reference half is omitted)
   int Ctot;       // mainC + scales * G
-  int omit_ref;   // sampled path: do not write the D-fold broadcast of `left` (see ts_block_cost_sampled_warped_fwd)
+  int omit_ref;   // sampled path: 1 = do not write the D-fold broadcast of `left` (ts_block_cost_sampled_warped_fwd);
+                  // 2 = correlation blocks only, neither half of the main channels (ts_block_cost_sampled_corr_fwd)
   int tch;        // sampled path: first channel of the warped half (C, or 0 when the reference half is omitted)
   int H1, W1, H2, W2;
   int nbx, nby;   // 4x4 pixel blocks
@@ -279,7 +280,7 @@ block_cost_main(const float* __restrict__ L, const float* __restrict__ R,
           float* pl = plane0 + static_cast<size_t>(g * GRP + c) * cstride + rowoff;
           if constexpr (SAMPLED) {
             if (!s.omit_ref) st4<VEC>(pl, x4, W, lv4);                             // reference half
-            st4<VEC>(pl + static_cast<size_t>(s.tch) * cstride, x4, W, pack(tv));  // warped half
+            if (s.omit_ref < 2) st4<VEC>(pl + static_cast<size_t>(s.tch) * cstride, x4, W, pack(tv));  // warped half
           } else {
             st4<VEC>(pl, x4, W, make_float4(-ev[0] * ev[0], -ev[1] * ev[1], -ev[2] * ev[2], -ev[3] * ev[3]));
           }
@@ -411,7 +412,7 @@ __device__ __forceinline__ float comp(const float4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-template <bool SAMPLED, bool VEC, int NP, bool REF>   // REF: write the reference (left-repeat) half
+template <bool SAMPLED, bool VEC, int NP, bool REF, bool MAIN = true>   // REF: write the reference (left-repeat) half; MAIN: write the warped half / the int path's main channels
 // VEC: <= 128 VGPRs, three 5-wave workgroups per CU; ragged widths (scalar loads / stores with their own masks) get 168
 // registers instead of spilling
 __global__ void __launch_bounds__(512, VEC ? 4 : 3)
@@ -590,7 +591,7 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
           if constexpr (SAMPLED) {
             if constexpr (REF) {   // the reference half left with the staging threads (prologue)
               bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));    // warped half
-            } else {
+            } else if constexpr (MAIN) {
               bst4<VEC>(orsrc, loff, plane, x4, W, pack(tv));                                     // warped half only
             }
           } else {
@@ -997,7 +998,7 @@ block_cost_upsample_rows(const float* __restrict__ P1, const float* __restrict__
   }
 }
 
-int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales, bool omit_ref = false, int min_hw = 4) {
+int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int scales, int omit_ref = 0, int min_hw = 4) {
   TS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0, TS_ERR_SHAPE, "block_cost: non-positive size");
   TS_REQUIRE(C % GRP == 0, TS_ERR_SHAPE, "block_cost: C=%d is not a multiple of 8 (block_cost.py:9)", C);
   TS_REQUIRE(scales >= 1 && scales <= 3, TS_ERR_UNSUPPORTED, "block_cost: scales=%d outside 1..3", scales);
@@ -1007,9 +1008,9 @@ int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int sc
   TS_REQUIRE(B <= 65535 && C / GRP <= 65535, TS_ERR_UNSUPPORTED, "block_cost: grid too large");
   s.B = B; s.C = C; s.H = H; s.W = W; s.D = D; s.scales = scales;
   s.G = C / GRP;
-  s.omit_ref = (sampled && omit_ref) ? 1 : 0;
+  s.omit_ref = sampled ? omit_ref : 0;
   s.tch = s.omit_ref ? 0 : C;
-  s.mainC = (sampled && !omit_ref) ? 2 * C : C;
+  s.mainC = (sampled && !omit_ref) ? 2 * C : (s.omit_ref == 2 ? 0 : C);
   s.Ctot = s.mainC + scales * s.G;
   s.H1 = H / 2; s.W1 = W / 2; s.H2 = H / 4; s.W2 = W / 4;
   s.nbx = (W + 3) / 4; s.nby = (H + 3) / 4;
@@ -1036,7 +1037,7 @@ size_t pooled_bytes(const Shape& s, int lvl) {
 
 template <bool SAMPLED>
 int launch_fwd(const float* left, const float* right, const float* disp, float* out, void* workspace,
-               int B, int C, int H, int W, int D, int scales, void* stream, bool omit_ref = false) {
+               int B, int C, int H, int W, int D, int scales, void* stream, int omit_ref = 0) {
   Shape s;
   if (int rc = make_shape(s, SAMPLED, B, C, H, W, D, scales, omit_ref)) return rc;
   TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(out);
@@ -1063,7 +1064,10 @@ int launch_fwd(const float* left, const float* right, const float* disp, float* 
 
 #define TS_LAUNCH_FAST(V, N)                                                                        \
   do {                                                                                               \
-    if (SAMPLED && omit_ref)                                                                         \
+    if (SAMPLED && omit_ref == 2)                                                                    \
+      hipLaunchKernelGGL((block_cost_fast<SAMPLED, V, N, false, false>), grid, dim3(threads), lds_bytes, st, \
+                         left, right, disp, out, P1, P2, s);                                         \
+    else if (SAMPLED && omit_ref)                                                                    \
       hipLaunchKernelGGL((block_cost_fast<SAMPLED, V, N, false>), grid, dim3(threads), lds_bytes, st, \
                          left, right, disp, out, P1, P2, s);                                         \
     else                                                                                             \
@@ -1621,7 +1625,13 @@ extern "C" int ts_block_cost_sampled_fwd(const float* left, const float* right, 
 extern "C" int ts_block_cost_sampled_warped_fwd(const float* left, const float* right, const float* disp, float* out,
                                                 void* workspace, int B, int C, int H, int W, int D, int scales,
                                                 void* stream) {
-  return launch_fwd<true>(left, right, disp, out, workspace, B, C, H, W, D, scales, stream, true);
+  return launch_fwd<true>(left, right, disp, out, workspace, B, C, H, W, D, scales, stream, 1);
+}
+
+extern "C" int ts_block_cost_sampled_corr_fwd(const float* left, const float* right, const float* disp, float* out,
+                                              void* workspace, int B, int C, int H, int W, int D, int scales,
+                                              void* stream) {
+  return launch_fwd<true>(left, right, disp, out, workspace, B, C, H, W, D, scales, stream, 2);
 }
 
 namespace {
@@ -1629,7 +1639,7 @@ template <int MODE>
 int launch_dense(const float* left, const float* right, const float* disp, float* out, unsigned* maxbits,
                  int B, int C, int H, int W, int D, void* stream) {
   Shape s;
-  if (int rc = make_shape(s, true, B, C, H, W, D, 1, false, 1)) return rc;       // no pooling here: any H, W
+  if (int rc = make_shape(s, true, B, C, H, W, D, 1, 0, 1)) return rc;       // no pooling here: any H, W
   TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(disp);
   if (MODE != 1) TS_REQUIRE_PTR(out);
   if (MODE != 0) TS_REQUIRE_PTR(maxbits);

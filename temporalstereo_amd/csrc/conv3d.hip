@@ -78,8 +78,9 @@ struct IG {
   int ksplit, kspan;            // split-K: this many slices of `kspan` input channels each (partials -> workspace)
   float* partial;               // [ksplit][B][Cout][Do*Ho*Wo] raw sums when ksplit > 1
   int B;
-  const float* addend;          // [B][Cout][Ho*Wo] added to every depth plane's sum before scale/shift (or null)
-  long long add_bstride;
+  const float* addend;          // [B][Cout][Ho*Wo] added to every depth plane's sum before scale/shift (or null);
+  long long add_bstride;        // add_dstride != 0: one term per depth plane, [B][Cout][D][Ho*Wo] (ts_conv3d_hw_warp_fwd)
+  long long add_cstride, add_dstride;
   int xcd;                      // XCD-banded workgroup order (ig_conv_kernel)
 };
 
@@ -512,7 +513,7 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
         const unsigned off = (inside && co < p.Cout) ? opix * 4u + static_cast<unsigned>(co) * ocs : kOOB;   // per lane: VGPR
         float v = acc[cb][pb][r];
         if (!split) {
-          if (MODE == MODE_HW && ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * hw_o + (inside ? ppix : 0u)];
+          if (MODE == MODE_HW && ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * p.add_cstride + static_cast<size_t>(od) * p.add_dstride + (inside ? ppix : 0u)];
           v = apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param, co);
         }
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, off, 0, 0);
@@ -814,7 +815,7 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + cb * 16 + kq * 4 + r;
         float v = acc[cb][pb][r];
-        if (ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * hw_o + (inside ? ppix : 0u)];
+        if (ab) v += ab[static_cast<size_t>(min(co, p.Cout - 1)) * p.add_cstride + static_cast<size_t>(od) * p.add_dstride + (inside ? ppix : 0u)];
         outv[cb][pb][r] = split ? v : apply_act(v * esc[cb][r] + esh[cb][r], p.act, p.act_param, co);
       }
   }
@@ -1309,7 +1310,8 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
                  int transposed, int act, float act_param,
                  long long in_bstride, long long in_cstride, long long out_bstride,
                  long long out_cstride, const float* addend, long long addend_bstride,
-                 void* workspace, size_t workspace_bytes, int out_h, int out_w, void* stream) {
+                 void* workspace, size_t workspace_bytes, int out_h, int out_w, void* stream,
+                 long long addend_cstride = 0, long long addend_dstride = 0) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "conv3d_hw: non-positive size");
   TS_REQUIRE(stride == 1 || stride == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: stride must be 1 or 2");
   TS_REQUIRE(dilation == 1 || dilation == 2, TS_ERR_UNSUPPORTED, "conv3d_hw: dilation must be 1 or 2");
@@ -1327,6 +1329,8 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
   p.addend = addend; p.add_bstride = addend_bstride;
+  p.add_cstride = addend_dstride ? addend_cstride : static_cast<long long>((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+  p.add_dstride = addend_dstride;
   TS_REQUIRE(!(addend && transposed), TS_ERR_UNSUPPORTED, "conv3d_hw: no addend in the transposed form");
   TS_REQUIRE(ig_extent(p, 9), TS_ERR_UNSUPPORTED, "conv3d_hw: a batch element of x spans 2 GiB or more");
   if (transposed) {
@@ -1340,7 +1344,7 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
   p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
   p.tiles_x = (p.Wo + 31) / 32;
   const int tiles = ((p.Ho + 7) / 8) * p.tiles_x;
-  const int ksplit = conv_hw_ksplit(B, Cin, Cout, D, p.Ho, p.Wo, stride);
+  const int ksplit = addend_dstride ? 1 : conv_hw_ksplit(B, Cin, Cout, D, p.Ho, p.Wo, stride);      // the finishing pass adds a D-invariant term only
   const size_t need = static_cast<size_t>(ksplit) * B * Cout * D * p.Ho * p.Wo * sizeof(float);
   const bool split = ksplit > 1 && workspace != nullptr && workspace_bytes >= need;
   if (split) {
@@ -1362,6 +1366,100 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
                      B, Cout, plane, ksplit, act, act_param, out_bstride, out_cstride, addend, addend_bstride,
                      static_cast<long long>(p.Ho) * p.Wo);
   return ts::launched("conv_splitk_finish");
+}
+
+// ------------------------------------------------------------------------------------------------
+// The first (1,3,3) layer of a sampled level WITHOUT its warped input volume.
+//
+// Reference: cost = cat[left (repeated over D), warp(right, disp_d), corr] -> Conv3d(1,3,3) + BN + SiLU
+// (architecture/modeling/aggregation/TemporalStereo/precise.py:88-91, fine.py:96-103, utils/block_cost.py:47-81).
+// The warp is a two-tap linear interpolation along x with per-pixel weights that do not depend on the channel
+// (inverse_warp_3d.py:41-56), and the convolution contracts over channels -- the two commute:
+//     sum_c W[co][c][t] ((1-f) R[c][x0] + f R[c][x0+1])  ==  (1-f) Q[t][co][x0] + f Q[t][co][x0+1],
+//     Q[t][co] = sum_c W[co][c][t] R[c]          (a 1x1 convolution of the right map: ONCE per pixel, not once per candidate)
+// so the warped half of the volume (C channels x D candidates: 84 of the 149 MB the 1/4 level wrote and read back per pair) is
+// never built, and its share of the layer's multiply-adds drops by the factor D.  What is left per output (co, d, y, x) is a gather:
+//     T = left term + sum_{t=(ky,kx)} lerp(Q[t][co][y+ky-1], (x+kx-1) - disp[d][y+ky-1][x+kx-1])        (zero where the tap's pixel
+// is outside the image: the convolution's zero padding; zero for columns outside the row: the warp's zeros padding), added to
+// the convolution over the correlation channels as a per-depth-plane addend of ig_conv_kernel.
+// The tap arithmetic is block_cost.hip's (the reference's normalise / un-normalise float sequence), so tap positions round identically.
+// One lane per output pixel of one candidate; the two columns of a tap are one 8-byte load (dword-aligned buffer load).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int DL>
+__global__ void __launch_bounds__(256)
+warp_gather_kernel(const float* __restrict__ q, const float* __restrict__ disp, const float* __restrict__ base,
+                   float* __restrict__ out, int Cout, int D, int H, int W, long long base_bstride) {
+  const int cogs = (Cout + 7) / 8;
+  // Workgroup order: (batch item, channel group, pixel block, candidate) with the candidate fastest, dealt to the eight XCDs in
+  // contiguous bands (consecutive workgroup ids go round the XCDs, each with its own 4 MB L2): an XCD then gathers from ONE band of
+  // rows of Q for all candidates (1/8 of the 9.4 MB at the 1/4 level) instead of from all of it.
+  unsigned lin = blockIdx.x;
+  {
+    const unsigned per = gridDim.x / 8;
+    if (lin < per * 8) lin = (lin % 8) * per + lin / 8;
+  }
+  const int d = static_cast<int>(lin % D);
+  const unsigned nblk = (static_cast<unsigned>(H) * W + 255u) / 256u;
+  const unsigned blk = (lin / D) % nblk;
+  const int bc = static_cast<int>(lin / (static_cast<unsigned>(D) * nblk));
+  const int cog = bc % cogs, b = bc / cogs;
+  const unsigned HW = static_cast<unsigned>(H) * W;
+  const unsigned pix = blk * 256u + threadIdx.x;
+  const bool live = pix < HW;
+  const int y = live ? static_cast<int>(pix / W) : 0, x = live ? static_cast<int>(pix - (pix / W) * W) : 0;
+  const __amdgpu_buffer_rsrc_t qrs = ig_rsrc(q + static_cast<size_t>(b) * 9 * Cout * HW, static_cast<unsigned>(9 * Cout) * HW * 4u);
+  const __amdgpu_buffer_rsrc_t drs = ig_rsrc(disp + (static_cast<size_t>(b) * D + d) * HW, HW * 4u);
+  const float Wm1 = static_cast<float>(W - 1);
+  // the candidates of the nine tap pixels, requested together (outside the image: out of range -> 0, and the tap's weights are 0)
+  float dv[9];
+  bool in[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int qy = y + (t / 3 - 1) * DL, qx = x + (t % 3 - 1) * DL;
+    in[t] = live && qy >= 0 && qy < H && qx >= 0 && qx < W;
+    dv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(drs, in[t] ? (static_cast<unsigned>(qy) * W + qx) * 4u : kOOB, 0, 0));
+  }
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int co = min(cog * 8 + c, Cout - 1);
+    acc[c] = (base && live) ? base[static_cast<size_t>(b) * base_bstride + static_cast<size_t>(co) * HW + pix] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int qy = y + (t / 3 - 1) * DL, qx = x + (t % 3 - 1) * DL;
+    // same float sequence as block_cost.hip tap4<true> (inverse_warp_3d.py:41-47 and grid_sample's un-normalisation)
+    const float xs = static_cast<float>(qx) + (-dv[t]);
+    const float gx = (xs / Wm1 * 2.f) - 1.f;
+    float ix = ((gx + 1.f) / 2.f) * Wm1;
+    ix = fminf(fmaxf(ix, -2.f), static_cast<float>(W) + 1.f);
+    const float fl = floorf(ix);
+    const float f = ix - fl;
+    const int xi = static_cast<int>(fl);
+    // the pair (xb, xb + 1) that covers the taps inside the row; a tap outside it has weight 0
+    const int xb = min(max(xi, 0), W - 2);
+    float wa = 0.f, wb = 0.f;
+    if (xi >= 0 && xi <= W - 2) { wa = 1.f - f; wb = f; }
+    else if (xi == -1) wa = f;                       // only the right tap (column 0) is inside
+    else if (xi == W - 1) wb = 1.f - f;              // only the left tap (column W-1) is inside
+    if (!in[t]) { wa = 0.f; wb = 0.f; }
+    const unsigned voff = in[t] ? (static_cast<unsigned>(qy) * W + xb) * 4u : 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned plane = static_cast<unsigned>(t * Cout + min(cog * 8 + c, Cout - 1));      // uniform
+      const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(qrs, voff, plane * HW * 4u, 0));
+      acc[c] += wa * __uint_as_float(v.x) + wb * __uint_as_float(v.y);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int co = cog * 8 + c;
+      if (co < Cout) out[((static_cast<size_t>(b) * Cout + co) * D + d) * HW + pix] = acc[c];
+    }
+  }
 }
 
 // ---- x6 (bf16-split) form of the stride-1 (1,3,3) convolution ------------------------------------------------------
@@ -1453,7 +1551,7 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   static const int no_xcd = env_not_zero("TS_X6_XCD") ? 0 : 1;
   p.ksplit = 1; p.kspan = (Cin + X6_NC - 1) / X6_NC * X6_NC; p.partial = nullptr; p.B = B; p.xcd = !no_xcd;
-  p.addend = addend; p.add_bstride = addend_bstride;
+  p.addend = addend; p.add_bstride = addend_bstride; p.add_cstride = static_cast<long long>(H) * W; p.add_dstride = 0;
   TS_REQUIRE(ig_extent(p, 9), TS_ERR_UNSUPPORTED, "conv3d_hw_x6: a batch element of x spans 2 GiB or more");
   const size_t wb = x6_weight_bytes(Cin, Cout);
   TS_REQUIRE(wb < 0x7fffffffull, TS_ERR_UNSUPPORTED, "conv3d_hw_x6: weight array too large");
@@ -1506,6 +1604,37 @@ extern "C" int ts_conv3d_hw_fwd(const float* x, const float* w_t, const float* s
   return conv_hw_impl(x, w_t, scale, shift, y, B, Cin, Cout, D, H, W, stride, dilation, transposed, act, act_param,
                       in_bstride, in_cstride, out_bstride, out_cstride, addend, addend_bstride, workspace, workspace_bytes,
                       0, 0, stream);
+}
+
+// ---- first layer of a sampled level from [corr | Q] (see warp_gather_kernel) ----------------------------------------------
+extern "C" size_t ts_conv3d_hw_warp_workspace_bytes(int B, int Cout, int D, int H, int W) {
+  if (B <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  return ts::round_up(static_cast<size_t>(B) * Cout * D * H * W * sizeof(float), 256);
+}
+
+extern "C" int ts_conv3d_hw_warp_fwd(const float* corr, const float* w_t, const float* scale, const float* shift, float* y,
+                                     const float* q, const float* disp, const float* base,
+                                     int B, int Cc, int Cout, int D, int H, int W, int dilation, int act, float act_param,
+                                     long long in_bstride, long long in_cstride, long long out_bstride, long long out_cstride,
+                                     long long base_bstride, void* workspace, size_t workspace_bytes, void* stream) {
+  TS_REQUIRE(B > 0 && Cc > 0 && Cout > 0 && D > 0 && H > 0 && W >= 2, TS_ERR_SHAPE, "conv3d_hw_warp: bad size");
+  TS_REQUIRE(dilation == 1 || dilation == 2, TS_ERR_UNSUPPORTED, "conv3d_hw_warp: dilation must be 1 or 2");
+  TS_REQUIRE(D <= 65535 && static_cast<long long>(B) * ((Cout + 7) / 8) <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw_warp: grid too large");
+  TS_REQUIRE_PTR(corr); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(y); TS_REQUIRE_PTR(q); TS_REQUIRE_PTR(disp); TS_REQUIRE_PTR(workspace);
+  TS_REQUIRE(workspace_bytes >= ts_conv3d_hw_warp_workspace_bytes(B, Cout, D, H, W), TS_ERR_SHAPE, "conv3d_hw_warp: workspace too small");
+  TS_REQUIRE(9ull * Cout * H * W * 4ull < 0x7fffffffull, TS_ERR_UNSUPPORTED, "conv3d_hw_warp: a batch element of q spans 2 GiB or more");
+  hipStream_t st = ts::as_stream(stream);
+  float* T = reinterpret_cast<float*>(workspace);
+  const long long HW = static_cast<long long>(H) * W;
+  const long long wgs = ((HW + 255) / 256) * D * B * ((Cout + 7) / 8);
+  TS_REQUIRE(wgs < (1ll << 31), TS_ERR_UNSUPPORTED, "conv3d_hw_warp: grid too large");
+  const dim3 grid(static_cast<unsigned>(wgs));
+  if (dilation == 1) hipLaunchKernelGGL(warp_gather_kernel<1>, grid, dim3(256), 0, st, q, disp, base, T, Cout, D, H, W, base_bstride);
+  else hipLaunchKernelGGL(warp_gather_kernel<2>, grid, dim3(256), 0, st, q, disp, base, T, Cout, D, H, W, base_bstride);
+  if (int rc = ts::launched("warp_gather_kernel")) return rc;
+  return conv_hw_impl(corr, w_t, scale, shift, y, B, Cc, Cout, D, H, W, 1, dilation, 0, act, act_param, in_bstride, in_cstride,
+                      out_bstride, out_cstride, T, static_cast<long long>(Cout) * D * HW, nullptr, 0, 0, 0, stream,
+                      static_cast<long long>(D) * HW, HW);
 }
 
 // Gradient w.r.t. the input of ts_conv3d_hw_fwd (no scale / shift / activation: the raw convolution).
@@ -1590,7 +1719,7 @@ int conv_d_impl(const float* x, const float* w_t, const float* scale, const floa
   p.act = act; p.act_param = act_param;
   p.in_bstride = in_bstride; p.in_cstride = in_cstride; p.out_bstride = out_bstride; p.out_cstride = out_cstride;
   p.tiles_x = 1; p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
-  p.addend = nullptr; p.add_bstride = 0;
+  p.addend = nullptr; p.add_bstride = 0; p.add_cstride = 0; p.add_dstride = 0;
   TS_REQUIRE(ig_extent(p, k), TS_ERR_UNSUPPORTED, "conv3d_d: a batch element of x spans 2 GiB or more");
   const int tiles = (H * W + 255) / 256;
   if (k == 1) return launch_ig<MODE_D, 1, 1, 1>(x, w_t, scale, shift, y, p, B, tiles, Dout, st);
@@ -1671,7 +1800,7 @@ extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const floa
   p.in_bstride = static_cast<long long>(Cin) * H * W; p.in_cstride = static_cast<long long>(H) * W;
   p.out_bstride = out_bstride; p.out_cstride = 4ll * H * W;
   p.tiles_x = (W + 31) / 32; p.co_groups = 1; p.ksplit = 1; p.kspan = Cin; p.partial = nullptr;
-  p.addend = nullptr; p.add_bstride = 0;
+  p.addend = nullptr; p.add_bstride = 0; p.add_cstride = 0; p.add_dstride = 0;
   TS_REQUIRE(ig_extent(p, 16), TS_ERR_UNSUPPORTED, "deconv2d: a batch element of x spans 2 GiB or more");
   const int tiles = ((H + 7) / 8) * p.tiles_x;
   return launch_ig<MODE_HWT, 16, 1, 1>(x, w_t, scale, shift, y, p, B, tiles * 4, 1, ts::as_stream(stream));

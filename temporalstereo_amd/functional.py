@@ -1155,6 +1155,28 @@ def block_cost_warped(reference_fm, target_fm, disp_sample, block_cost_scale=3):
     return out
 
 
+def block_cost_corr(reference_fm, target_fm, disp_sample, block_cost_scale=3):
+    """Inference form of the sampled block_cost WITHOUT its 2C main channels: the correlation blocks alone,
+    [B, scales*C/8, D, H, W] = block_cost(...)[:, 2C:].  No autograd.  The consumer is ts_conv3d_hw_warp_fwd, which takes the
+    warped half of the volume in pre-contracted form (include/ts_hip.h)."""
+    _require_gpu(reference_fm, target_fm, disp_sample)
+    left, right, disp = _lib.contiguous(reference_fm), _lib.contiguous(target_fm), _lib.contiguous(disp_sample)
+    B, C, H, W = left.shape
+    D = disp.shape[1]
+    if C % 8 != 0:
+        raise ValueError("channel count must be a multiple of 8 (block_cost.py:9)")
+    L = _lib.lib()
+    out = torch.empty((B, block_cost_scale * (C // 8), D, H, W), device=left.device, dtype=torch.float32)
+    ws = torch.empty(max(_q("ts_block_cost_workspace_bytes", B, C, H, W, D, block_cost_scale), 256), device=left.device, dtype=torch.uint8)
+
+    def launch():
+        return L.ts_block_cost_sampled_corr_fwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(disp), _lib.ptr(out),
+                                                _lib.ptr(ws), B, C, H, W, D, block_cost_scale, _stream())
+    rc = launch() if _k1_probe is None else _k1_probe((B, C, H, W, D, "corr"), launch)
+    _lib.check(rc, "ts_block_cost_sampled_corr_fwd")
+    return out
+
+
 def block_cost(reference_fm, target_fm, disp_sample, block_cost_scale=3):
     """Cost volume of `block_cost` (block_cost.py:16-83), same arguments and output layout.
 

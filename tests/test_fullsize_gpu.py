@@ -105,6 +105,10 @@ def _frame_checks(case, agg, t, trace, out_o, prev_o, rep, name):
     _cmp(rep, "fine K1 block_cost(sampled)", TF.block_cost(l8, r8, ds0, 3), trace["fine_raw"], 1e-4, 2e-5, **ctx)
     _cmp(rep, "fine K1 warped variant", TF.block_cost_warped(l8, r8, ds0, 3), trace["fine_raw"][:, Cf:], 1e-4, 2e-5, **ctx)
     _cmp(rep, "fine init3d", fi.init3d(g("fine_raw")[:, Cf:].contiguous(), fi.left_term(l8)), trace["fine_init"], 1e-4, 1e-4, **ctx)
+    # the pre-contracted first layer (ts_conv3d_hw_warp_fwd): correlation blocks alone, then init3d from [corr | Q | left term]
+    _cmp(rep, "fine K1 correlation blocks only", N.block_cost_corr(l8, r8, ds0, 3), trace["fine_raw"][:, 2 * Cf:], 1e-4, 2e-5, **ctx)
+    _cmp(rep, "fine init3d, warped half pre-contracted", fi.init3d_from(fi.first_layer_fused(l8, r8, ds0, fi.left_term(l8), fi.right_term(r8))),
+         trace["fine_init"], 1e-4, 1e-4, **ctx)
     cat4, samp = fi.merge(g("fine_init"), ds0, prev, False)
     _cmp(rep, "fine merged candidates", samp, trace["fine_ds"], 0.0, **ctx)                      # keys are the oracle's bits: exact
     _cmp(rep, "fine merged volume", cat4[:, :fi.C], trace["fine_merged"], 1e-5, 1e-5, **ctx)
@@ -137,6 +141,10 @@ def _frame_checks(case, agg, t, trace, out_o, prev_o, rep, name):
     assert SOFT or e_ours <= 1.25 * e_ref + 1e-5, "precise K1: %.3g from exact, the fp32 reference %.3g" % (e_ours, e_ref)
     _cmp(rep, "precise K1 warped variant", TF.block_cost_warped(both_o[:B], both_o[B:], dsp, 3), trace["precise_raw"][:, Cp:], 1e-4, 2e-5, **ctx)
     _cmp(rep, "precise init3d", pr.init3d(g("precise_raw")[:, Cp:].contiguous(), pr.left_term(both_o[:B])), trace["precise_init"], 1e-4, 1e-4, **ctx)
+    _cmp(rep, "precise K1 correlation blocks only", N.block_cost_corr(both_o[:B], both_o[B:], dsp, 3), trace["precise_raw"][:, 2 * Cp:], 1e-4, 2e-5, **ctx)
+    _cmp(rep, "precise init3d, warped half pre-contracted",
+         pr.init3d_from(pr.first_layer_fused(both_o[:B], both_o[B:], dsp, pr.left_term(both_o[:B]), pr.right_term(both_o[B:]))),
+         trace["precise_init"], 1e-4, 1e-4, **ctx)
     cost, off = pr.heads(g("precise_init"))
     _cmp(rep, "precise head cost", cost, trace["precise_cost"], 1e-4, 1e-4, **ctx)
     _cmp(rep, "precise head offset", off, trace["precise_off"], 1e-5, 1e-4, **ctx)

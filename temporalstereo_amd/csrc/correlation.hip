@@ -263,6 +263,14 @@ extern "C" int ts_correlation_fwd(const float* left, const float* right, float* 
     while ((pitchR & 31) != 16) ++pitchR;
     const size_t in_b = static_cast<size_t>(CKC) * (CPL + pitchR) * 4, out_b = static_cast<size_t>(keep) * CPO * 4;
     const size_t shm = in_b > out_b ? in_b : out_b;
+    // keep >= 238 needs more than 64 KB of dynamic LDS: allowed up to the device's per-workgroup limit (160 KB on gfx950) once the
+    // kernel's attribute is raised; a device that cannot hold the tile takes the lane-per-output kernel below instead of failing
+    static const size_t lds_limit = [] {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return size_t(64 * 1024);
+      return static_cast<size_t>(v);
+    }();
+    if (shm <= lds_limit) {
     // rows per workgroup (the next row's loads fly under this row's matrix work and stores): 2 where that still leaves four rounds of
     // workgroups, else 1 -- measured at [4,32,272,480] D=192: 1 row 222 us, 2 rows 221, 4 rows 233, 8 rows 264 (longer chains of
     // fewer, fatter workgroups lose more to the tail than the prefetch wins)
@@ -274,8 +282,13 @@ extern "C" int ts_correlation_fwd(const float* left, const float* right, float* 
     hipStream_t st = ts::as_stream(stream);
     if (T <= 4) hipLaunchKernelGGL(corr_row_mfma_kernel<4>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR, rpw);
     else if (T <= 8) hipLaunchKernelGGL(corr_row_mfma_kernel<8>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR, rpw);
-    else hipLaunchKernelGGL(corr_row_mfma_kernel<16>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR, rpw);
+    else {
+      if (shm > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_row_mfma_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shm));
+      hipLaunchKernelGGL(corr_row_mfma_kernel<16>, grid, dim3(256), shm, st, left, right, out, p, T, pitchR, rpw);
+    }
     return ts::launched("corr_row_mfma_kernel");
+    }
   }
   const long long n = static_cast<long long>(B) * keep * H * ((W + 3) / 4);
   hipLaunchKernelGGL(correlation_fwd_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ts::as_stream(stream),

@@ -182,6 +182,7 @@ class GradientBuckets:
             self._ready.append(0)
         self._handles = [None] * len(self.buckets)
         self._fired = set()
+        self._accumulated = set()             # parameters that received gradient under paused() since the last finish()
         self._next = 0                        # buckets are all-reduced strictly in index order (the same order on every rank)
 
     def paused(self):
@@ -198,7 +199,10 @@ class GradientBuckets:
         return _P()
 
     def _on_grad(self, p):
-        if self.world == 1 or self._paused:
+        if self.world == 1:
+            return
+        if self._paused:
+            self._accumulated.add(id(p))      # its .grad holds a contribution that finish() must not drop if it does not fire again
             return
         if id(p) in self._fired:
             raise RuntimeError("GradientBuckets: a second backward() before finish() -- accumulate under gb.paused()")
@@ -211,7 +215,9 @@ class GradientBuckets:
         # Launch order must not depend on the rank: a data-dependent branch can make a parameter fire on one rank and not on another,
         # and collectives issued in different orders on different ranks hang (or sum the wrong buffers).  So buckets go out strictly
         # by index; a full bucket behind one that is not full yet waits for it (or for finish()).
-        while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
+        # ... and not at all on the first step: the ranks first agree on the participating parameters (finish(): one all-reduce of the
+        # "fired" flags), and that collective must be the first one on every rank whatever fired where.
+        while self._unused_known and self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
             nb = self._next
             self._handles[nb] = dist.all_reduce(self._flat[nb], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.launched_in_backward += 1
@@ -224,16 +230,19 @@ class GradientBuckets:
         first = not self._unused_known
         if first:
             # which parameters take part: agreed across ranks (a parameter used on any rank is reduced on all)
-            flags = torch.tensor([1.0 if id(p) in self._fired else 0.0 for p in self.params], device=self.params[0].device)
+            flags = torch.tensor([1.0 if (id(p) in self._fired or id(p) in self._accumulated) else 0.0 for p in self.params], device=self.params[0].device)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             used = [p for p, f in zip(self.params, flags.tolist()) if f > 0]
             used_ids = {id(p) for p in used}
         for bi, bucket in enumerate(self.buckets):            # the rest, in index order again
             if self._handles[bi] is None:
                 for p in bucket:
-                    if id(p) not in self._fired:              # no gradient on this rank in this step: contributes zero (a .grad left
-                        _, off = self._where[id(p)]           # over from an earlier step is stale and must not be averaged in)
-                        self._flat[bi][off:off + p.numel()].zero_()
+                    if id(p) not in self._fired:              # no gradient on this rank in the last backward: contributes zero (a .grad
+                        _, off = self._where[id(p)]           # left over from an earlier step is stale and must not be averaged in) --
+                        if id(p) in self._accumulated and p.grad is not None:      # unless a paused() pass of THIS step accumulated into it
+                            self._flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
+                        else:
+                            self._flat[bi][off:off + p.numel()].zero_()
                 self._handles[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for bi, bucket in enumerate(self.buckets):
             self._handles[bi].wait()
@@ -250,6 +259,7 @@ class GradientBuckets:
             self._handles[bi] = None
             self._ready[bi] = 0
         self._fired = set()
+        self._accumulated = set()
         self._next = 0
         if first:
             self._unused_known = True

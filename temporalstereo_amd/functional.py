@@ -764,8 +764,10 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, family, geom, eps, momentum, act, training, group,
-                counter=None):
-        if _FOLDS is not None and not training and not torch.is_grad_enabled() and running_mean is not None:
+                counter=None, may_fold=False):
+        # may_fold is decided by conv_bn_act in the CALLER's grad mode (inside Function.forward grad mode is always off): the folded
+        # path keeps nothing for backward, so it is for calls through which no gradient can flow
+        if _FOLDS is not None and not training and may_fold and running_mean is not None:
             fold = _FOLDS.get(gamma, beta, running_mean, running_var, bias, eps, weight.shape[1] if (family == "dc" or geom[-1]) else weight.shape[0])
             if fold is not None:        # eval frame of a training step: conv -> BatchNorm -> activation in the convolution's epilogue
                 if family == "hw":
@@ -875,7 +877,7 @@ class _ConvBNAct(torch.autograd.Function):
         gbias = None
         if has_bias and ctx.needs_input_grad[2]:
             gbias = dy.sum(dim=[0] + list(range(2, dy.dim())))     # == 0 up to rounding in train mode (BatchNorm removes the mean)
-        return dx, dw, gbias, gaffine[0], gaffine[1], None, None, None, None, None, None, None, None, None, None
+        return dx, dw, gbias, gaffine[0], gaffine[1], None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False):
@@ -894,8 +896,11 @@ def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False)
             group = pg if pg is not None else dist.group.WORLD
     momentum = d["momentum"] if d["momentum"] is not None else 0.1
     counter = Bf.get("num_batches_tracked") if (training and d["track_running_stats"]) else None     # incremented by the statistics launch
-    return _ConvBNAct.apply(x, weight, bias, P["weight"], P["bias"], rmean, Bf.get("running_var"), family, geom, d["eps"], momentum,
-                            BN_ACT[activation], training, group, counter)
+    gamma, beta = P["weight"], P["bias"]
+    may_fold = (not training) and (not torch.is_grad_enabled() or not any(
+        t is not None and t.requires_grad for t in (x, weight, bias, gamma, beta)))
+    return _ConvBNAct.apply(x, weight, bias, gamma, beta, rmean, Bf.get("running_var"), family, geom, d["eps"], momentum,
+                            BN_ACT[activation], training, group, counter, may_fold)
 
 
 def conv3d_supported(weight_shape, stride, padding, dilation, groups, transposed=False, output_padding=(0, 0, 0)):

@@ -87,9 +87,27 @@ class ClipRMSprop:
         self._host = [torch.empty(n * 32, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(n * 32, dtype=torch.uint8)
                       for _ in range(2)]
         self._turn = 0
+        self._copied = [None, None]          # event behind the last non-blocking upload from each pinned table
         self._table = self._ws = None
         self._static_grads = None
         self.steps = 0
+
+    def state_dict(self):
+        """square_avg per parameter (in parameter order), hyper-parameters and the step count: what a checkpoint needs to resume
+        (the reference's Lightning checkpoints carry the optimizer state)."""
+        return dict(square_avg=[t.detach().clone() for t in self.square_avg], lr=float(self.param_groups[0]["lr"]), alpha=self.alpha,
+                    eps=self.eps, max_norm=self.max_norm, steps=self.steps)
+
+    def load_state_dict(self, state):
+        sq = state["square_avg"]
+        if len(sq) != len(self.square_avg) or any(a.shape != b.shape for a, b in zip(sq, self.square_avg)):
+            raise ValueError("ClipRMSprop.load_state_dict: state does not match the parameters")
+        with torch.no_grad():
+            for dst, src in zip(self.square_avg, sq):
+                dst.copy_(src)
+        self.param_groups[0]["lr"] = self.lr = float(state.get("lr", self.lr))
+        self.alpha, self.eps = float(state.get("alpha", self.alpha)), float(state.get("eps", self.eps))
+        self.max_norm, self.steps = float(state.get("max_norm", self.max_norm)), int(state.get("steps", 0))
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -121,7 +139,8 @@ class ClipRMSprop:
         grads = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in ps)
         if grads != self._static_grads:                      # eager steps: fresh gradient tensors every backward; graph replays: static
             host = self._host[self._turn]
-            self._turn ^= 1
+            if self._copied[self._turn] is not None:
+                self._copied[self._turn].synchronize()     # the upload that last read this pinned table has completed
             rec = host.numpy().view(self._dtype)
             for i, p in enumerate(ps):
                 g = p.grad
@@ -129,10 +148,19 @@ class ClipRMSprop:
                     raise RuntimeError("ClipRMSprop: gradients must be dense fp32")
                 rec[i] = (p.data_ptr(), grads[i], self.square_avg[i].data_ptr(), p.numel())
             self._table.copy_(host, non_blocking=True)
+            if dev.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record()
+                self._copied[self._turn] = ev
+            self._turn ^= 1
             self._static_grads = grads
         lr = float(self.param_groups[0]["lr"])
         _lib.check(L.ts_clip_rmsprop_step(_lib.ptr(self._table), n, self.max_norm, lr, self.alpha, self.eps, _lib.ptr(self._ws),
                                           self._ws.numel(), _stream()), "ts_clip_rmsprop_step")
+        # the kernel writes through raw pointers: tell autograd (and everything that stamps (storage, version), e.g. the
+        # InferenceEngine's stale-weights check) that the parameters changed, as torch.optim.RMSprop's in-place ops would.
+        # Note: p.grad is left UNclipped (clip_grad_norm_ scales it in place); the clipped step is applied inside the kernel.
+        torch.autograd.graph.increment_version(ps)
         self.steps += 1
 
 
@@ -176,6 +204,7 @@ class TrainStep:
         self._g = self._static = self._loss = None
         self.timings = {}
         self._modules = list(net.modules())
+        self._stat_buffers = [b for b in net.buffers() if b.is_cuda]
         # Kernel layouts of all convolution weights in one launch per step instead of ~280: 5 ms of host time in the eager step
         # (28 -> 22.7 ms).  NOT in the replayed step, measured again in round 3 (ms per replay): a layout launch in front of every
         # convolution call 13.4; one launch per step 14.0-14.3; one launch per 16 / 32 / 64 consecutive requests, issued just ahead of
@@ -307,6 +336,10 @@ class TrainStep:
             if self.clip:
                 torch.nn.utils.clip_grad_norm_(self.params, self.clip)
             self.opt.step()
+        if self._stat_buffers:
+            # BatchNorm running statistics are updated inside the statistics kernels (raw pointers; under graph replay no host code
+            # runs at all): bump their versions like the in-place framework update would, for everything that stamps (storage, version)
+            torch.autograd.graph.increment_version(self._stat_buffers)
         t3 = time.perf_counter()
         # host-side issue times (the device runs behind them); the exchange entry includes waiting for the reduced buckets
         self.timings = dict(forward_backward_issue_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3, clip_step_issue_ms=(t3 - t2) * 1e3)

@@ -108,6 +108,44 @@ def test_buckets_drop_unused_parameters_and_overlap_from_the_second_step(tmp_pat
     assert "phi" not in torch.load(out)
 
 
+def _paused_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from temporalstereo_amd import dist as tsd
+    tsd.init_distributed("gloo")
+    model = _model()
+    model.side = nn.Parameter(torch.ones(1))          # receives gradient ONLY in the paused() micro-batch
+    model[0].norm.eval()
+    tsd.broadcast_parameters(model)
+    x, y = _data(8)
+    mine = tsd.shard_units(8, rank, world)
+    a, b = mine[:2], mine[2:]
+    gb = tsd.GradientBuckets(model.parameters(), bucket_bytes=64)
+    for step in range(2):                             # the first step (participation agreed) and a steady-state one
+        model.zero_grad(set_to_none=True)
+        with gb.paused():
+            (((model(x[a]) - y[a]) ** 2).mean() * 0.5 + (model.side * (rank + 1.0)).sum()).backward()
+        (((model(x[b]) - y[b]) ** 2).mean() * 0.5).backward()
+        gb.finish()
+    if rank == 0:
+        torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulated_under_paused_is_kept(tmp_path):
+    """A parameter whose only gradient of the step arrived under gb.paused() (accumulation micro-batch) is averaged, not zeroed."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_paused_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    model = _model()
+    model[0].norm.eval()
+    x, y = _data(8)
+    ((model(x) - y) ** 2).mean().backward()            # == mean over ranks of (0.5 mean(a) + 0.5 mean(b))
+    for k, p in model.named_parameters():
+        torch.testing.assert_close(got[k], p.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got["side"], torch.tensor([1.5]))      # mean of d/d side = rank + 1 over the two ranks
+
+
 # ------------------------------------------------------------------------------------------------ the real aggregator, ws 2
 def _tiny_aggregator(setattr_=setattr):
     """The registered TEMPORALSTEREO module at the tiny fixture dimensions, fp64, with the two GPU-only ops of its forward bound

@@ -78,3 +78,55 @@ def test_graph_mode_refuses_an_unsafe_runtime(monkeypatch):
     monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")
     with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
         TrainStep(torch.nn.Linear(2, 2), graph=True)
+
+
+def test_inference_engine_sees_the_fused_optimizer_step():
+    """An engine built BEFORE training steps must not keep running on its stale folded weights: ClipRMSprop and the BatchNorm
+    statistics kernels update through raw pointers, so TrainStep bumps the tensors' versions, which is what the engine stamps
+    (validation during training, projects/TemporalStereo/TemporalStereo.py:170-200)."""
+    from temporalstereo_amd.train import TrainStep
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    dev = torch.device("cuda:0")
+    net, frames, gt, K, poses = _setup(dev)
+    lf, rf, il, ir = frames[0]
+    net.eval()
+    early = InferenceEngine(net, backend="native", replay="plan")
+    before = early(lf, rf, il, ir, {})[0][0].clone()
+    step = TrainStep(net.train(), max_disp=16 * NS, local_map_size=1, lr=1e-3)
+    versions = [p._version for p in step.params]
+    for _ in range(2):
+        step(frames, gt, K, poses)
+    assert all(p._version > v for p, v in zip(step.params, versions) if p.grad is not None)
+    net.eval()
+    after = early(lf, rf, il, ir, {})[0][0].clone()
+    fresh = InferenceEngine(net, backend="native", replay="plan")(lf, rf, il, ir, {})[0][0]
+    torch.cuda.synchronize()
+    assert float((after - before).abs().max()) > 1e-4, "two optimizer steps left the output unchanged: the engine did not re-fold"
+    assert float((after - fresh).abs().max()) < 1e-5, "an engine built before the steps differs from one built after them"
+
+
+def test_fused_optimizer_state_round_trip():
+    from temporalstereo_amd.train import ClipRMSprop
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(5, 7, generator=g).to(dev)), torch.nn.Parameter(torch.randn(11, generator=g).to(dev))]
+    ref = [p.detach().clone() for p in ps]
+    a = ClipRMSprop(ps, lr=1e-2, max_norm=0.5)
+    grads = [torch.randn(p.shape, generator=g).to(dev) for p in ps]
+    for p, gr in zip(ps, grads):
+        p.grad = gr.clone()
+    a.step()
+    state = a.state_dict()
+    mid = [p.detach().clone() for p in ps]
+    a.step()
+    want = [p.detach().clone() for p in ps]
+    # resume from the state on fresh parameters holding the mid-point values
+    qs = [torch.nn.Parameter(m.clone()) for m in mid]
+    b = ClipRMSprop(qs, lr=1.0, max_norm=0.5)
+    b.load_state_dict(state)
+    for q, gr in zip(qs, grads):
+        q.grad = gr.clone()
+    b.step()
+    torch.cuda.synchronize()
+    assert b.steps == 2 and all(float((q - w).abs().max()) == 0.0 for q, w in zip(qs, want))
+    assert all(float((m - r).abs().max()) > 0 for m, r in zip(mid, ref))

@@ -331,6 +331,20 @@ int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* scale, cons
                         int B, int Cin, int Cout, int D, int H, int W, int dilation, int act, float act_param,
                         long long in_bstride, long long in_cstride, long long out_bstride, long long out_cstride,
                         const float* addend, long long addend_bstride, void* workspace, size_t workspace_bytes, void* stream);
+/* The same bf16-split arithmetic for the STRIDED and TRANSPOSED forms (ABI 7; csrc/conv_x6s.hip), which ts_conv3d_hw_fwd /
+ * ts_deconv2d_k4s2_fwd run on the f32-input MFMA.  mode 0: Conv3d (1,3,3) stride 2, padding 1 (Ho = (H-1)/2+1);  mode 1:
+ * ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1 (Ho = 2H);  mode 2: ConvTranspose2d 4x4 stride 2, padding 1
+ * (D = 1, Ho = 2H) -- reference: aggregation/TemporalStereo/module.py:111-184,453-457.  K chunks of 8 input channels, four taps per MFMA.
+ *   ts_conv3d_hw_x6s_supported     1 when the layer can take this path (Cin >= 16, Cout <= 512, W % 4 == 0, Wo % 4 == 0)
+ *   ts_conv3d_hw_x6s_weight_split  w_t [Cin][9 | 16][w_pad] (the array of ts_conv3d_hw_fwd / ts_deconv2d_k4s2_fwd) -> w6,
+ *                                  ts_conv3d_hw_x6s_weight_bytes bytes: [Cin/8][part 3][tap slot 12 | 16][Cout up to 16][8] bf16
+ *   ts_conv3d_hw_x6s_fwd           scale / shift [>= Cout] or NULL; strides in elements (x / y may be channel slices) */
+int ts_conv3d_hw_x6s_supported(int Cin, int Cout, int H, int W, int mode);
+size_t ts_conv3d_hw_x6s_weight_bytes(int Cin, int Cout, int mode);
+int ts_conv3d_hw_x6s_weight_split(const float* w_t, void* w6, int Cin, int Cout, int w_pad, int mode, void* stream);
+int ts_conv3d_hw_x6s_fwd(const float* x, const void* w6, const float* scale, const float* shift, float* y,
+                         int B, int Cin, int Cout, int D, int H, int W, int mode, int act, float act_param,
+                         long long in_bstride, long long in_cstride, long long out_bstride, long long out_cstride, void* stream);
 int ts_conv3d_d_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
                     int B, int Cin, int Cout, int Din, int H, int W, int k, int stride, int dilation,
                     int padding, int transposed, int act, float act_param,

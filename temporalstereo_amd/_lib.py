@@ -84,6 +84,10 @@ SIGNATURES = {
     "ts_conv3d_hw_x6_weight_bytes": (ctypes.c_size_t, [c_int] * 2),
     "ts_conv3d_hw_x6_weight_split": (c_int, [c_f32p, c_ptr, c_int, c_int, c_ptr]),
     "ts_conv3d_hw_x6_workspace_bytes": (c_size, [c_int] * 6),
+    "ts_conv3d_hw_x6s_supported": (c_int, [c_int] * 5),
+    "ts_conv3d_hw_x6s_weight_bytes": (c_size, [c_int] * 3),
+    "ts_conv3d_hw_x6s_weight_split": (c_int, [c_f32p, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "ts_conv3d_hw_x6s_fwd": (c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p] + [c_int] * 8 + [c_float] + [ctypes.c_longlong] * 4 + [c_ptr]),
     "ts_conv3d_hw_x6_fwd": (c_int, [c_f32p, c_ptr, c_f32p, c_f32p, c_f32p] + [c_int] * 8 + [c_float] + [ctypes.c_longlong] * 4 +
                             [c_f32p, ctypes.c_longlong, c_ptr, c_size, c_ptr]),
     "ts_conv3d_hw_fwd": (c_int, [c_f32p] * 5 + [c_int] * 10 + [c_float] + [ctypes.c_longlong] * 4 +
@@ -128,7 +132,7 @@ SIGNATURES = {
 
 # entry points that only answer a question (nothing is enqueued): never part of a recorded plan
 _QUERIES = frozenset(n for n in SIGNATURES if n.endswith("_bytes") or n.startswith("ts_plan_") or
-                     n in ("ts_version", "ts_last_error_string", "ts_conv_cout_pad", "ts_conv3d_hw_x6_supported"))
+                     n in ("ts_version", "ts_last_error_string", "ts_conv_cout_pad", "ts_conv3d_hw_x6_supported", "ts_conv3d_hw_x6s_supported"))
 
 
 def lib():

@@ -265,6 +265,36 @@ def x6_weights(f):
     return w6
 
 
+# TS_CONV_X6S=0: stride-2 / transposed convolutions and the UNet deconvolutions stay on the f32-input MFMA kernels (A/B measurements)
+X6S = os.environ.get("TS_CONV_X6S", "1") != "0"      # (in effect only with X6)
+# grids below this many x6s workgroups stay on the f32 kernel's 64-pixel tiles (the small layers of the hourglasses: launch-bound)
+# (tools/x6s_bench.py, x6s / f32: 32 -> 64 stride 2 on 2 x 272 x 480 38 / 53 us, 16 -> 32 on 5 x 136 x 240 11.6 / 13.8, 32 -> 64 on 12 x 32 x 64 -- 96 workgroups
+# -- 12.7 / 11.9; deconvolutions 32 -> 32 on 136 x 240 21.4 / 23.1, 32 -> 9 on 272 x 480 23.3 / 33.5; batch 4: 1.16 - 1.41 x)
+_X6S_MIN_GRID = int(os.environ.get("TS_CONV_X6S_MIN_GRID", "256"))
+# the (1,3,3)^T layers are the hourglasses' small ones: 16 -> 8 on 3 x 68 x 120 (108 workgroups) 15.5 vs 11.7 us, batch 4 (432) 19.9 vs 21.9
+_X6S_MIN_GRID_T3 = int(os.environ.get("TS_CONV_X6S_MIN_GRID_T3", "400"))
+X6S_S2, X6S_T3, X6S_T4 = 0, 1, 2
+
+
+def x6s_weights(f, mode):
+    """bf16-split weights of a strided / transposed layer in the 8-channel-chunk layout of csrc/conv_x6s.hip, made on first use
+    (outside any plan recording, like x6_weights)."""
+    w6 = getattr(f, "w6s", None)
+    if w6 is None:
+        L = _lib._real_lib()
+        w6 = torch.empty(int(L.ts_conv3d_hw_x6s_weight_bytes(f.cin, f.cout, mode)), device=f.w.device, dtype=torch.uint8)
+        _lib.check(L.ts_conv3d_hw_x6s_weight_split(f.w.data_ptr(), w6.data_ptr(), f.cin, f.cout, f.w.shape[2], mode, _stream()),
+                   "ts_conv3d_hw_x6s_weight_split")
+        f.w6s = w6
+    return w6
+
+
+def x6s_grid(B, cout, D, H, W, mode):
+    if mode == X6S_S2:
+        return ((((H - 1) // 2 + 1) + 3) // 4) * ((((W - 1) // 2 + 1) + 31) // 32) * D * B * ((cout + 31) // 32)
+    return ((H + 7) // 8) * ((W + 31) // 32) * D * B * ((cout + 15) // 16)
+
+
 def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, act_param=0.0, addend=None, second=None,
             out_second=None):
     """x [B,Cin,D,H,W] -> [B,Cout,D,Ho,Wo].  addend [B,Cout,1,Ho,Wo]: added to every depth plane's raw sum.
@@ -297,6 +327,14 @@ def conv_hw(x, f, stride=1, dilation=1, transposed=False, out=None, act=None, ac
         ob = (out_second.data_ptr() - out.data_ptr()) // 4
         _lib.ptr(out_second)
     L = _lib.lib()
+    if X6 and X6S and addend is None and (stride == 2 or transposed) and dilation == 1:
+        mode = X6S_T3 if transposed else X6S_S2
+        if L.ts_conv3d_hw_x6s_supported(Cin, f.cout, H, W, mode) and x6s_grid(B, f.cout, D, H, W, mode) >= (_X6S_MIN_GRID_T3 if transposed else _X6S_MIN_GRID):
+            rc = L.ts_conv3d_hw_x6s_fwd(_lib.ptr(x), _lib.ptr(x6s_weights(f, mode)), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
+                                        B, Cin, f.cout, D, H, W, mode, f.act if act is None else act, float(act_param),
+                                        ib, ic, ob, oc, _stream())
+            _lib.check(rc, "ts_conv3d_hw_x6s_fwd")
+            return out
     wsb = int(L.ts_conv3d_hw_workspace_bytes(B, Cin, f.cout, D, H, W, stride, int(transposed)))
     x6_grid = ((H + 7) // 8) * ((W + 31) // 32) * D * B * ((f.cout + 31) // 32)
     x6_ok = X6 and L.ts_conv3d_hw_x6_supported(Cin, f.cout, W, stride, dilation, int(transposed))
@@ -745,6 +783,12 @@ class NativePrecise(_LevelBase):
 
     def _deconv(self, x, f, out, out_bstride):
         B, Cin, H, W = x.shape
+        L = _lib.lib()
+        if X6 and X6S and L.ts_conv3d_hw_x6s_supported(Cin, f.cout, H, W, X6S_T4) and x6s_grid(B, f.cout, 1, H, W, X6S_T4) >= _X6S_MIN_GRID:
+            rc = L.ts_conv3d_hw_x6s_fwd(_lib.ptr(x), _lib.ptr(x6s_weights(f, X6S_T4)), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
+                                        B, Cin, f.cout, 1, H, W, X6S_T4, f.act, 0.0, Cin * H * W, H * W, out_bstride, 4 * H * W, _stream())
+            _lib.check(rc, "ts_conv3d_hw_x6s_fwd")
+            return
         rc = _lib.lib().ts_deconv2d_k4s2_fwd(_lib.ptr(x), _lib.ptr(f.w), _lib.ptr(f.scale), _lib.ptr(f.shift), _lib.ptr(out),
                                              B, Cin, f.cout, H, W, f.act, out_bstride, _stream())
         _lib.check(rc, "ts_deconv2d_k4s2_fwd")

@@ -20,24 +20,10 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "ts_common.hpp"
+#include "conv_common.hpp"
 
 namespace {
 
-enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_TANH_OFFSET = 3, ACT_HEAD_PAIR = 4 };
-
-// co: output channel (only ACT_HEAD_PAIR looks at it: channel 0 = the cost head, no activation; channel 1 =
-// the offset head -- both prediction heads as one block-diagonal convolution)
-__device__ __forceinline__ float apply_act(float v, int act, float p, int co = 0) {
-  if (act == ACT_HEAD_PAIR) act = co == 0 ? ACT_NONE : ACT_TANH_OFFSET;
-  switch (act) {
-    case ACT_SILU: return v / (1.f + expf(-v));
-    case ACT_RELU: return fmaxf(v, 0.f);
-    // PredictionHeads.regress_offset (module.py:384-390): tanh(x/100).clamp(-1,1) * delta
-    case ACT_TANH_OFFSET: return fminf(fmaxf(tanhf(v / 100.f), -1.f), 1.f) * p;
-    default: return v;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the matrix cores, all four conv families in one kernel:
@@ -59,30 +45,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float p, int co = 0
 //   MODE_D  : (k,1,1) taps, k = 1|3|5, stride/dilation along D, or its stride-2 transposed form.
 //             Tile = 256 consecutive pixels of one output depth.
 // ------------------------------------------------------------------------------------------------
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-enum { MODE_HW = 0, MODE_HWT = 1, MODE_D = 2 };
-constexpr unsigned kOOB = 0x80000000u;   // buffer offset past every num_records we allow: the load returns 0
 
-struct IG {
-  int Cin, Cout, coutp;         // coutp: padded channel count of the weight / scale / shift arrays
-  int D, H, W;                  // input: planes per channel, plane geometry
-  int Do, Ho, Wo;               // output
-  int stride, dil, pad, k, transposed;
-  int act;
-  float act_param;
-  long long in_bstride, in_cstride, out_bstride, out_cstride;
-  unsigned in_bytes, w_bytes;   // extent of one batch element of x / of the weight array (buffer range checks)
-  unsigned out_bytes, part_bytes;   // ... of one batch element of y / of one (slice, batch) block of the partials
-  int tiles_x, co_groups;
-  int ksplit, kspan;            // split-K: this many slices of `kspan` input channels each (partials -> workspace)
-  float* partial;               // [ksplit][B][Cout][Do*Ho*Wo] raw sums when ksplit > 1
-  int B;
-  const float* addend;          // [B][Cout][Ho*Wo] added to every depth plane's sum before scale/shift (or null);
-  long long add_bstride;        // add_dstride != 0: one term per depth plane, [B][Cout][D][Ho*Wo] (ts_conv3d_hw_warp_fwd)
-  long long add_cstride, add_dstride;
-  int xcd;                      // XCD-banded workgroup order (ig_conv_kernel)
-};
 
 // TP (MODE_D): pixels per workgroup, 256 or 64 (one 16-pixel block per wave: layers that run on a few dozen workgroups last as long as
 // ONE workgroup's K loop, so the tile is cut instead of the grid being filled)
@@ -102,9 +65,6 @@ struct Geom {
   static constexpr int chan_elems = chan_raw + (pad0 ? pad0 : 32);
 };
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ig_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
 
 // ST / DL: stride and dilation of MODE_HW as compile-time constants, so that every LDS fragment read is
 // `base register + immediate` (no address arithmetic between MFMAs).  NC: input channels per K chunk.
@@ -539,21 +499,6 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 //   pre-split from the host pass (weight_split6_kernel) as [chunk][part][tap slot][group][co][8]: an A fragment is one
 //   ds_read_b128 as well.
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
-}
-// (a, b) -> packed (hi, mid, lo) parts
-__device__ __forceinline__ void split6(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = pack_bf16(a, b);
-  a -= __uint_as_float(hi << 16); b -= __uint_as_float(hi & 0xffff0000u);
-  mid = pack_bf16(a, b);
-  a -= __uint_as_float(mid << 16); b -= __uint_as_float(mid & 0xffff0000u);
-  lo = pack_bf16(a, b);
-}
 
 
 // Epilogue through LDS: the accumulator layout (lane = pixel j of a 16-pixel block, registers = 4 channels) stores 64-byte
@@ -859,8 +804,6 @@ thread_local int g_chunk_cap = 32;
 // grids below this many workgroups take the two-chunks-in-flight form of the NC = 8 kernel (TS_CONV_PF_MAX_WGS, 0 = never)
 // Environment switches are read by NAMED functions: hipcc 7.2 resolved a third namespace-scope `= [] { ... }()` initialiser of
 // this file to the FIRST such lambda (a bool came out holding 192 -- the default of g_pf_max_wgs -- and tested false).
-long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
-bool env_not_zero(const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); }
 const long long g_pf_max_wgs = env_ll("TS_CONV_PF_MAX_WGS", 512);     // measured again with the 64-pixel tiles in place (their grids count four-fold): 256 / 512 / 1024 = 1191 / 1189 / 1176 pairs/s, one pass at a time 846 / 846 / 841
 // grids of at most this many 8 x 32 workgroups run the plain (1,3,3) forms on 4 x 16 pixel tiles (launch_ig); measured 0 / 64 / 128 / 256 / 512: 1163 / 1170 / 1174 / 1181 / 1181 pairs/s, one pass at a time 808 / 816 / 823 / 833 / 835
 const long long g_small_hw = env_ll("TS_CONV_HW_SMALL_WGS", 256);

@@ -48,6 +48,13 @@ def macs_of(name, a):
     if name == "ts_conv3d_hw_x6_fwd":
         B, Cin, Cout, D, H, W, dil = a[5:12]
         return B * Cin * Cout * D * H * W * 9, "x6 (1,3,3) d%d %d->%d  %dx%dx%d B%d" % (dil, Cin, Cout, D, H, W, B)
+    if name == "ts_conv3d_hw_x6s_fwd":
+        B, Cin, Cout, D, H, W, mode = a[5:12]
+        if mode == 0:
+            return B * Cin * Cout * D * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1) * 9, "x6s (1,3,3) s2 %d->%d  %dx%dx%d B%d" % (Cin, Cout, D, H, W, B)
+        if mode == 1:
+            return B * Cin * Cout * D * H * W * 9, "x6s (1,3,3)^T %d->%d  %dx%dx%d B%d" % (Cin, Cout, D, H, W, B)
+        return B * Cin * Cout * H * W * 16, "x6s deconv 4x4 s2 %d->%d  %dx%d B%d" % (Cin, Cout, H, W, B)
     if name == "ts_conv3d_hw_warp_fwd":
         B, Cc, Cout, D, H, W = a[8:14]
         return B * Cc * Cout * D * H * W * 9, "warp (1,3,3) %d->%d  %dx%dx%d B%d (+ gather)" % (Cc, Cout, D, H, W, B)

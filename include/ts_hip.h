@@ -331,6 +331,29 @@ int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* scale, cons
                         int B, int Cin, int Cout, int D, int H, int W, int dilation, int act, float act_param,
                         long long in_bstride, long long in_cstride, long long out_bstride, long long out_cstride,
                         const float* addend, long long addend_bstride, void* workspace, size_t workspace_bytes, void* stream);
+/* Small-message exchange between the ranks of one node as kernels over peer-mapped (hipIpc, xGMI) memory (ABI 8; csrc/peer.hip):
+ * the statistics exchanges of SyncBatchNorm (reference: Lightning's sync_batchnorm=True, projects/TemporalStereo/dist_train.py:94)
+ * without a communicator launch per layer, and capturable in a hipGraph.  Set-up: every rank ts_peer_alloc()s its mailbox, the
+ * 64-byte handles travel through any out-of-band channel (torch.distributed all_gather), every rank ts_peer_open()s the others and
+ * fills a ts_peer_ctx.  All ranks must issue the same sequence of exchanges.  At most ts_peer_max_floats() floats per exchange. */
+typedef struct ts_peer_ctx {
+  void* region[8];        /* mailbox of rank r as mapped in this process (region[rank]: the local allocation) */
+  int rank, world;
+} ts_peer_ctx;
+size_t ts_peer_region_bytes(void);
+int ts_peer_max_floats(void);
+int ts_peer_max_ranks(void);
+int ts_peer_alloc(void** region, void* handle64);
+int ts_peer_open(const void* handle64, void** region);
+int ts_peer_close(void* region);
+int ts_peer_free(void* region);
+/* status: 0, or 1 + r when rank r did not answer an exchange within ~2 s (that exchange's results are undefined) */
+int ts_peer_status(const void* ctx, int* status, void* stream);
+/* dst [world][n] <- every rank's src [n] */
+int ts_peer_all_gather(const void* ctx, const float* src, float* dst, int n, void* stream);
+/* buf [n] <- (sum over the ranks in rank order: bit-identical everywhere) * (*scale, a device scalar, if not NULL) */
+int ts_peer_all_reduce_sum(const void* ctx, float* buf, int n, const float* scale, void* stream);
+
 /* The same bf16-split arithmetic for the STRIDED and TRANSPOSED forms (ABI 7; csrc/conv_x6s.hip), which ts_conv3d_hw_fwd /
  * ts_deconv2d_k4s2_fwd run on the f32-input MFMA.  mode 0: Conv3d (1,3,3) stride 2, padding 1 (Ho = (H-1)/2+1);  mode 1:
  * ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1 (Ho = 2H);  mode 2: ConvTranspose2d 4x4 stride 2, padding 1

@@ -77,6 +77,16 @@ SIGNATURES = {
     "ts_softsplat_softmax_workspace_bytes": (c_size, [c_int] * 4),
     "ts_softsplat_softmax_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 4 + [c_ptr]),
     "ts_conv_cout_pad": (c_int, [c_int]),
+    "ts_peer_region_bytes": (c_size, []),
+    "ts_peer_max_floats": (c_int, []),
+    "ts_peer_max_ranks": (c_int, []),
+    "ts_peer_alloc": (c_int, [ctypes.POINTER(c_ptr), c_ptr]),
+    "ts_peer_open": (c_int, [c_ptr, ctypes.POINTER(c_ptr)]),
+    "ts_peer_close": (c_int, [c_ptr]),
+    "ts_peer_free": (c_int, [c_ptr]),
+    "ts_peer_status": (c_int, [c_ptr, ctypes.POINTER(c_int), c_ptr]),
+    "ts_peer_all_gather": (c_int, [c_ptr, c_f32p, c_f32p, c_int, c_ptr]),
+    "ts_peer_all_reduce_sum": (c_int, [c_ptr, c_f32p, c_int, c_f32p, c_ptr]),
     "ts_conv_weight_layout": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_longlong] * 3 + [c_int, c_ptr]),
     "ts_conv_weight_layout_many": (c_int, [c_ptr, c_int, c_int, c_ptr]),
     "ts_conv_set_chunk_cap": (c_int, [c_int]),
@@ -132,7 +142,8 @@ SIGNATURES = {
 
 # entry points that only answer a question (nothing is enqueued): never part of a recorded plan
 _QUERIES = frozenset(n for n in SIGNATURES if n.endswith("_bytes") or n.startswith("ts_plan_") or
-                     n in ("ts_version", "ts_last_error_string", "ts_conv_cout_pad", "ts_conv3d_hw_x6_supported", "ts_conv3d_hw_x6s_supported"))
+                     n in ("ts_version", "ts_last_error_string", "ts_conv_cout_pad", "ts_conv3d_hw_x6_supported", "ts_conv3d_hw_x6s_supported", "ts_peer_max_floats", "ts_peer_max_ranks",
+                           "ts_peer_alloc", "ts_peer_open", "ts_peer_close", "ts_peer_free", "ts_peer_status"))
 
 
 def lib():

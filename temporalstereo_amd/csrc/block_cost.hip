@@ -763,6 +763,83 @@ dense_warp_kernel(const float* __restrict__ L, const float* __restrict__ R, cons
   const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(disp + static_cast<size_t>(b) * dHW, dHW * 4u);
   const float fillv = (MODE == 2) ? __uint_as_float(maxbits[0]) : 0.f;
   float vmax = 0.f;
+  // one (candidate, 4-pixel block) item: taps, the 8 channels, stores
+  auto do_item = [&](int r, int d, int x4, unsigned loff, const float4 dq) {
+    float dv[4];
+    unpack(dq, dv);
+    unsigned op[4];
+    float fr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tap4<true>(x4 + k, d, dv[k], W, Wm1, Wq, Wqp, op[k], fr[k]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4* rrow = ldsR4 + (h * TRD + r) * 4 * Wqp;
+      float4 ta[4], tb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ta[k] = rrow[op[k] & 0xffffu]; tb[k] = rrow[op[k] >> 16]; }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = h * 4 + cc;
+        const float4 lv4 = *reinterpret_cast<const float4*>(ldsL + (c * TRD + r) * Wl + x4);
+        float lv[4], tv[4];
+        unpack(lv4, lv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tv[k] = (1.f - fr[k]) * comp(ta[k], cc) + fr[k] * comp(tb[k], cc);
+        const unsigned plane = static_cast<unsigned>(g * GRP + c) * dHW;        // uniform (SGPR)
+        if constexpr (MODE == 0) {
+          bst4<VEC>(orsrc, loff, plane, x4, W, lv4);
+          bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (VEC || x4 + k < W) vmax = fmaxf(vmax, fabsf(lv[k] - tv[k]));
+        } else {
+          float o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = (tv[k] > 0.f) ? fabsf(lv[k] - tv[k]) : fillv;   // dif_fms.py:40-42
+          bst4<VEC>(orsrc, loff, plane, x4, W, pack(o));
+        }
+      }
+    }
+  };
+  if constexpr (VEC) {
+    // Run order (round 4).  The rows y0, y0 + 1 of one (plane, candidate) are ONE contiguous run of 2 W floats, and with W = 240 a row is 7.5
+    // cache lines: walking row by row (below) writes the shared line of every run twice, at different times -- stores alone in that
+    // order reach 3.9-4.3 TB/s on 1.66 GB where the same bytes written run by run reach 5.9 (tools/exp/dense_store_patterns.py).  So an
+    // item is (candidate, float4 of the RUN), consecutive lanes = consecutive float4 of a run.  The candidates' disparities come through LDS
+    // in chunks of DC candidates, the next chunk's loads issued BEFORE this chunk's stores: vmcnt counts loads and stores in order, and a
+    // load requested per item (the row-order loop) makes every iteration wait for the previous iteration's stores to complete (-25 %:
+    // the row-order kernel with its taps and LDS reads removed ran exactly as long as with them).
+    const int rows = min(TRD, H - y0), run4 = rows * s.nbx;
+    const int DC = max(1, min(8, (4 * 256) / run4));
+    float4* ldsD = reinterpret_cast<float4*>(ldsL + GRP * TRD * Wl);          // [DC * run4 <= 1024]
+    const unsigned runbase = static_cast<unsigned>(y0) * W;
+    float4 dreg[4];
+    auto fetch = [&](int d0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + 256 * q;
+        const int dd = i / run4, e = i - dd * run4;
+        const bool ok = dd < DC && d0 + dd < D;
+        dreg[q] = bld4<true>(drsrc, ok ? static_cast<unsigned>(d0 + dd) * HW + runbase + 4u * e : 0x3ffffff0u, 0, W);
+      }
+    };
+    fetch(0);
+    for (int d0 = 0; d0 < D; d0 += DC) {
+      __syncthreads();                       // the previous chunk's candidates are consumed
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ldsD[tid + 256 * q] = dreg[q];
+      __syncthreads();
+      if (d0 + DC < D) fetch(d0 + DC);
+      const int nd = min(DC, D - d0);
+      for (int i = tid; i < nd * run4; i += 256) {
+        const int dd = i / run4, e = i - dd * run4;
+        const int r = e / s.nbx, x4 = (e - r * s.nbx) * 4;
+        const int d = d0 + dd;
+        do_item(r, d, x4, static_cast<unsigned>(d) * HW + runbase + 4u * e, ldsD[i]);
+      }
+    }
+  } else {
   const int nitems = s.nbx * D;
   for (int r = 0; r < TRD; ++r) {
     const int y = y0 + r;
@@ -780,47 +857,14 @@ dense_warp_kernel(const float* __restrict__ L, const float* __restrict__ R, cons
     for (int item = tid; item < nitems; item += nthr) {
       const int d = dn, x4 = xn;
       const unsigned loff = offn;
-      float dv[4];
-      unpack(dnext, dv);
+      const float4 dq = dnext;
       if (item + nthr < nitems) {
         offn = item_off(item + nthr, dn, xn);
         dnext = bld4<VEC>(drsrc, offn, xn, W);
       }
-      unsigned op[4];
-      float fr[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) tap4<true>(x4 + k, d, dv[k], W, Wm1, Wq, Wqp, op[k], fr[k]);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float4* rrow = ldsR4 + (h * TRD + r) * 4 * Wqp;
-        float4 ta[4], tb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { ta[k] = rrow[op[k] & 0xffffu]; tb[k] = rrow[op[k] >> 16]; }
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int c = h * 4 + cc;
-          const float4 lv4 = *reinterpret_cast<const float4*>(ldsL + (c * TRD + r) * Wl + x4);
-          float lv[4], tv[4];
-          unpack(lv4, lv);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) tv[k] = (1.f - fr[k]) * comp(ta[k], cc) + fr[k] * comp(tb[k], cc);
-          const unsigned plane = static_cast<unsigned>(g * GRP + c) * dHW;        // uniform (SGPR)
-          if constexpr (MODE == 0) {
-            bst4<VEC>(orsrc, loff, plane, x4, W, lv4);
-            bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));
-          } else if constexpr (MODE == 1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (VEC || x4 + k < W) vmax = fmaxf(vmax, fabsf(lv[k] - tv[k]));
-          } else {
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (tv[k] > 0.f) ? fabsf(lv[k] - tv[k]) : fillv;   // dif_fms.py:40-42
-            bst4<VEC>(orsrc, loff, plane, x4, W, pack(o));
-          }
-        }
-      }
+      do_item(r, d, x4, loff, dq);
     }
+  }
   }
   if constexpr (MODE == 1) {
 #pragma unroll
@@ -1643,12 +1687,12 @@ int launch_dense(const float* left, const float* right, const float* disp, float
   TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(disp);
   if (MODE != 1) TS_REQUIRE_PTR(out);
   if (MODE != 0) TS_REQUIRE_PTR(maxbits);
-  const size_t lds_bytes = (static_cast<size_t>(2) * TRD * 4 * s.Wqp * 4 + static_cast<size_t>(GRP) * TRD * 4 * s.Wq) * sizeof(float);
+  const bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(disp) && (MODE == 1 || ts::aligned16(out));
+  const size_t lds_bytes = (static_cast<size_t>(2) * TRD * 4 * s.Wqp * 4 + static_cast<size_t>(GRP) * TRD * 4 * s.Wq) * sizeof(float) + (vec ? 1024 * 16 : 0);
   TS_REQUIRE(lds_bytes <= 64 * 1024, TS_ERR_UNSUPPORTED, "cat/dif_fms: W=%d too wide for the row staging", W);
   const int CO = (MODE == 0) ? 2 * C : C;
   TS_REQUIRE(static_cast<unsigned long long>(CO) * D * H * W * 4ull < (1ull << 32), TS_ERR_UNSUPPORTED,
              "cat/dif_fms: one batch element of the volume spans 4 GiB or more");
-  const bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(disp) && (MODE == 1 || ts::aligned16(out));
   const dim3 grid((H + TRD - 1) / TRD, s.G, B);
   hipStream_t st = ts::as_stream(stream);
   if (vec) hipLaunchKernelGGL((dense_warp_kernel<MODE, true>), grid, dim3(256), lds_bytes, st, left, right, disp, out, maxbits, s);

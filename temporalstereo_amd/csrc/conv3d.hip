@@ -568,7 +568,12 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
   // the image or outside it, never across its border).  One dwordx4 per (row, quad, channel): the first version staged single
   // pixels -- 32 dword gathers per thread and chunk, ~29 cycles of the texture addresser each, 60 % of the kernel's time.
   constexpr int in_rows = 8 + 2 * DL, QPR = 10, LCOLS = 4 * QPR, NPIX = in_rows * LCOLS;
-  constexpr int NPIXP = NPIX + 1;
+  // pitch of a (part, group) block: a multiple of 16 entries, so that the 8 + 8 lanes of one ds_read_b128 bank group (lanes of channel group 0
+  // and of group 1, same pixels) land on disjoint banks; round 3's NPIX + 1 made EVERY fragment read a 2-way conflict (8 LDS cycles for 4:
+  // SQ_LDS_BANK_CONFLICT 47 % of SQ_LDS_IDX_ACTIVE).  Conflict-free reads change nothing measurable (1276 vs 1275 pairs/s) -- the LDS is 37 %
+  // busy either way -- and neither does pinning the issue order of reads and MFMAs with sched_group_barrier (1243: worse), DESIGN.md section 4.
+  constexpr int NPIXP = NPIX;
+  static_assert(NPIXP % 16 == 0, "block pitch");
   constexpr int SLOTS = in_rows * QPR;                  // (row, quad) pairs; threads [0, SLOTS) stage channels 0-7, [SLOTS, 2 SLOTS) 8-15
   static_assert(2 * SLOTS <= 256, "staging slots");
   constexpr int COB = CB * 16;
@@ -1408,7 +1413,7 @@ warp_gather_kernel(const float* __restrict__ q, const float* __restrict__ disp, 
 // ---- x6 (bf16-split) form of the stride-1 (1,3,3) convolution ------------------------------------------------------
 template <int CB, int DL>
 int launch_x6(const float* x, const void* w6, const float* scale, const float* shift, float* y, const IG& p, dim3 grid, hipStream_t st) {
-  constexpr int NPIXP = (8 + 2 * DL) * 40 + 1;
+  constexpr int NPIXP = (8 + 2 * DL) * 40;
   constexpr size_t lds = (static_cast<size_t>(3) * 2 * NPIXP + 3 * X6_SLOTS * 2 * CB * 16 + 1) * 16;
   static_assert(lds <= 80 * 1024, "ig_conv_x6_kernel: two workgroups per CU");
   auto kern = &ig_conv_x6_kernel<CB, DL>;

@@ -86,6 +86,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_conv_weight_layout),      TS_PLAN_OP(ts_conv_weight_layout_many),
     TS_PLAN_OP(ts_conv3d_hw_x6_fwd),        TS_PLAN_OP(ts_conv3d_hw_x6_weight_split),
     TS_PLAN_OP(ts_conv3d_hw_x6s_fwd),       TS_PLAN_OP(ts_conv3d_hw_x6s_weight_split),
+    TS_PLAN_OP(ts_peer_all_gather),         TS_PLAN_OP(ts_peer_all_reduce_sum),
     TS_PLAN_OP(ts_bn_train_fwd),            TS_PLAN_OP(ts_bn_train_bwd),
     TS_PLAN_OP(ts_channel_splice_fwd),
     TS_PLAN_OP(ts_candidates_in_range_fwd), TS_PLAN_OP(ts_candidates_in_range_bwd),

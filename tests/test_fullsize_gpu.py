@@ -218,7 +218,8 @@ def _native_sequence(case):
     return outs, info
 
 
-_PLANTED = ("planted_c1_s0", "planted_c1_s1", "planted_c1_s2", "planted_c2_s0", "planted_c3_s0", "planted_c4_s0")
+_PLANTED = ("planted_c1_s0", "planted_c1_s1", "planted_c1_s2", "planted_c2_s0", "planted_c3_s0", "planted_c4_s0",
+            "planted_c2_s1", "planted_c3_s1", "planted_c4_s1")
 
 
 @pytest.mark.parametrize("fixture", _PLANTED)

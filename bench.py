@@ -251,7 +251,7 @@ def cpu_baseline(sd, inputs_cpu, budget_s=20.0, all_cores=False):
                        "(torch %s CPU kernels, %d threads; first pass %.2fs excluded)" % (n, lf[0].shape[0], torch.__version__, cores, first)), out
 
 
-def training_leg(dev, rank, world, steps, warmup, batch, seed, graph=False):
+def training_leg(dev, rank, world, steps, warmup, batch, seed, graph=False, sync_bn=True):
     """Data-parallel TRAINING steps of the same path (temporalstereo_amd.train.TrainStep: T=2 frame loop with the previous frame
     in eval()/no_grad, update_map, train-mode forward, fused smooth-L1 + Wasserstein losses, backward through the HIP kernels,
     bucketed gradient all-reduce over RCCL + SyncBatchNorm, clip 0.1, RMSprop), FlyingThings3D 544x960 D=192, `batch` pairs per GPU.
@@ -271,8 +271,12 @@ def training_leg(dev, rank, world, steps, warmup, batch, seed, graph=False):
     T = torch.from_numpy(synth.small_motion(seed + rank, batch)).to(dev)
     eye = torch.eye(4, device=dev).expand(batch, 4, 4).contiguous()
     poses = [(eye, eye), (T, eye)]
-    step = TrainStep(net, max_disp=MAX_DISP, local_map_size=1, graph=graph)
-    for _ in range(warmup):
+    from temporalstereo_amd import functional as TF
+    step = TrainStep(net, max_disp=MAX_DISP, local_map_size=1, graph=graph, sync_bn=sync_bn)
+    ex0 = TF._EXCHANGES[0]
+    loss = step(frames, gt, K, poses)             # (graph: capture -- its two warm-up passes and the capture itself issue the exchanges three times)
+    per_step = (TF._EXCHANGES[0] - ex0) // (3 if graph else 1)
+    for _ in range(max(warmup - 1, 0)):
         loss = step(frames, gt, K, poses)
     torch.cuda.synchronize()
     if world > 1:
@@ -292,8 +296,15 @@ def training_leg(dev, rank, world, steps, warmup, batch, seed, graph=False):
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    if step.peer is not None:
+        step.peer.check()                         # raises if an exchange timed out waiting for a peer (the numbers would mean nothing)
     nparam = sum(p.numel() for p in step.params)
-    return dict(value=world * batch * steps / el, unit="pairs/s", ms_per_step=el / steps * 1e3, steps=steps, batch_per_gpu=batch,
+    collectives = dict(syncbn_exchanges_per_step=per_step if step.sync_bn else 0,
+                       syncbn_transport=("peer mailboxes over hipIpc/xGMI: one kernel per exchange, no communicator launch (csrc/peer.hip)"
+                                         if step.peer is not None else ("torch.distributed all_gather / all_reduce per layer" if step.sync_bn else "none")),
+                       communicator_launches_per_step=(0 if (step.peer is not None or not step.sync_bn) else per_step) +
+                       (0 if world == 1 else (1 if step.buckets is None else len(step.buckets.buckets))))
+    return dict(collectives=collectives, value=world * batch * steps / el, unit="pairs/s", ms_per_step=el / steps * 1e3, steps=steps, batch_per_gpu=batch,
                 frames=2, mode="hipGraph replay of previous frame + update + forward + losses + backward" if graph else "eager autograd",
                 sync_bn=step.sync_bn,
                 gradient_exchange_ms=exch / steps, gradient_bytes=4 * nparam, final_loss=float(loss),
@@ -380,6 +391,21 @@ def main():
     seed = synth.SEED0 + 2                      # config index 2
     if a.mode in ("train", "train-graph"):
         tr = training_leg(dev, rank, world, a.steps, a.warmup, a.batch, seed, graph=a.mode == "train-graph")
+        if world > 1 and os.environ.get("TS_BENCH_PEER", "1") != "0":
+            # the same step with SyncBatchNorm's exchanges as kernels over the peer mailboxes (eager, then replayed from a hipGraph:
+            # legal for world > 1 only in this form).  After the collectives leg, and guarded: it has only ever run with the ranks on
+            # ONE device (tests/test_ddp_gpu.py) -- across devices a peer that does not answer times out (no hang) and the leg reports it.
+            for key, g in (("peer", False), ("peer_hipgraph", True)):
+                try:
+                    from temporalstereo_amd.train import graph_replay_safe
+                    if g and not graph_replay_safe():
+                        tr[key] = dict(skipped="DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in the environment when the HIP runtime started")
+                        continue
+                    r = training_leg(dev, rank, world, a.steps, a.warmup, a.batch, seed, graph=g, sync_bn="peer")
+                    tr[key] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "mode", "final_loss", "collectives")}
+                except Exception as e:
+                    tr[key] = dict(error="%s: %s" % (type(e).__name__, e))
+                    break
         if rank == 0:
             print(json.dumps(dict(metric="stereo pairs/sec, TRAINING step, FlyingThings3D 540x960 D=192 T=2 (aggregation hot path)",
                                   value=tr["value"], unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,

@@ -59,7 +59,8 @@ peer_exchange_kernel(const PeerCtx ctx, const float* src, float* dst, int n, con
     __hip_atomic_store(flags_of(ctx.region[r]) + slot * kPeerRanks + ctx.rank, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned* mine = flags_of(ctx.region[ctx.rank]) + slot * kPeerRanks + r;
     const unsigned long long t0 = wall_clock64();                          // 100 MHz
-    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+    const bool dead = ctl[1] != 0u;                                        // an earlier exchange timed out: do not wait again (176 per step)
+    while (!dead && __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
       if (wall_clock64() - t0 > 200000000ull) {                             // ~2 s: a peer is not coming
         __hip_atomic_store(ctl + 1, 1u + static_cast<unsigned>(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;

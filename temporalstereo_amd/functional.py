@@ -752,6 +752,13 @@ def _all_gather_flat(out, part, group):
 
 import os as _os
 _BN_FUSED = _os.environ.get("TS_BN_FUSED", "1") != "0"
+_EXCHANGES = [0]            # SyncBatchNorm exchanges issued by this process (forward all_gathers + backward all_reduces; bench.py reports them per step)
+
+
+def _peer_group():
+    """The installed peer-mailbox group (peer.install), or None: torch.distributed collectives."""
+    from . import peer
+    return peer.installed()
 
 
 class _ConvBNAct(torch.autograd.Function):
@@ -816,7 +823,12 @@ class _ConvBNAct(torch.autograd.Function):
                 world = dist.get_world_size(group)
                 pack[2 * C:].copy_(_count_const(n_total, y.device))
                 allp = torch.empty(world * (2 * C + 1), device=y.device, dtype=torch.float32)
-                _all_gather_flat(allp, pack, group)
+                pg = _peer_group()
+                if pg is not None:      # one kernel over the peer-mapped mailboxes (csrc/peer.hip): no communicator launch, capturable
+                    pg.all_gather(pack, allp)
+                else:
+                    _all_gather_flat(allp, pack, group)
+                _EXCHANGES[0] += 1
                 mean, var = torch.empty_like(mean), torch.empty_like(var)
                 inv_n = torch.empty(1, device=y.device, dtype=torch.float32)
                 _lib.check(L.ts_bn_sync_merge(_lib.ptr(allp), world, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(running_mean), _lib.ptr(running_var),
@@ -857,9 +869,14 @@ class _ConvBNAct(torch.autograd.Function):
         if training and group is not None:
             import torch.distributed as dist
             pack = torch.cat([s1, s2])
-            dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
-            pack = pack * n_total                                    # n_total is 1 / (global count) on the device here: pre-scaled sums,
+            pg = _peer_group()
+            if pg is not None:
+                pg.all_reduce_sum(pack, scale=n_total)               # summed in rank order and scaled inside the exchange kernel
+            else:
+                dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
+                pack = pack * n_total                                # n_total is 1 / (global count) on the device here: pre-scaled sums,
             t1, t2, count = pack[:C], pack[C:], 1.0                  # the kernel's own division is by 1 (no host read of a count)
+            _EXCHANGES[0] += 1
         dy = torch.empty_like(y)
         _lib.check(L.ts_bn_act_bwd_apply(_lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta),
                                          _lib.ptr(t1), _lib.ptr(t2), _lib.ptr(dy), B, C, N, y.stride(0), y.stride(1), g.stride(0),

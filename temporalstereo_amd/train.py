@@ -181,14 +181,24 @@ class TrainStep:
             raise RuntimeError("TrainStep(graph=True) needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in place before the HIP runtime starts "
                                "(ROCm 7.2 replays pre-built graph packets incorrectly; see train.py): start the process with it, or "
                                "call temporalstereo_amd.train.enable_graph_replay() before the first GPU call")
-        if self.graph and self.world > 1 and sync_bn:
-            # collectives are not captured: a replayed step can only normalise with per-rank statistics, which is NOT what the
+        # sync_bn: True -> the statistics exchanges are torch.distributed collectives (RCCL / gloo), one per layer and direction;
+        # "peer" -> kernels over the peer-mapped mailboxes of the node's ranks (peer.py, csrc/peer.hip): no communicator launch per
+        # layer, and -- being kernels -- part of a captured graph, which makes the replayed step legal for world > 1 (round 4; rounds
+        # 2-3 refused graph=True with SyncBatchNorm).
+        if self.graph and self.world > 1 and sync_bn and sync_bn != "peer":
+            # collectives are not captured: a replayed step could only normalise with per-rank statistics, which is NOT what the
             # reference trains with (sync_batchnorm=True, dist_train.py:94) -- refuse rather than change semantics silently
-            raise RuntimeError("TrainStep(graph=True) cannot run SyncBatchNorm across %d ranks (the statistics exchange cannot be replayed "
-                               "from a hipGraph); use graph=False, or pass sync_bn=False to accept per-rank BatchNorm explicitly" % self.world)
-        self.sync_bn = bool(sync_bn) and self.world > 1 and not self.graph
+            raise RuntimeError("TrainStep(graph=True) across %d ranks needs sync_bn='peer' (statistics exchanged by kernels, which a hipGraph "
+                               "can replay; torch.distributed collectives cannot be), or sync_bn=False to accept per-rank BatchNorm "
+                               "explicitly" % self.world)
+        self.sync_bn = bool(sync_bn) and self.world > 1
+        self.peer = None
         if self.sync_bn:
             net = tsd.sync_batchnorm(net)
+            if sync_bn == "peer":
+                from . import peer
+                self.peer = peer.PeerGroup()
+                peer.install(self.peer)
         self.net = net
         tsd.broadcast_parameters(net)
         self.l1 = DispSmoothL1Loss(max_disp=max_disp, rescale=True, global_weight=l1_global_weight,

@@ -42,15 +42,25 @@ def main(out):
     dev = torch.device("cuda", int(os.environ.get("TS_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     torch.cuda.set_device(dev)
     net = build(dev)
-    step = TrainStep(net, max_disp=64, local_map_size=1, bucket_bytes=1 << 20)        # several buckets: they go out during backward
-    assert step.sync_bn and step.buckets is not None
+    mode = os.environ.get("TS_DDP_MODE", "collectives")      # collectives | peer | peer_graph
+    if mode == "collectives":
+        step = TrainStep(net, max_disp=64, local_map_size=1, bucket_bytes=1 << 20)        # several buckets: they go out during backward
+        assert step.sync_bn and step.buckets is not None and step.peer is None
+    else:
+        # SyncBatchNorm statistics through the peer mailboxes (csrc/peer.hip); peer_graph: the whole step replayed from a hipGraph
+        step = TrainStep(net, max_disp=64, local_map_size=1, bucket_bytes=1 << 20, sync_bn="peer", graph=(mode == "peer_graph"))
+        assert step.sync_bn and step.peer is not None
     frames, gt, K, poses = scene(dev, [rank])
     losses = [float(step(frames, gt, K, poses))]
     first = {"g1::" + k: p.grad.detach().cpu().numpy() for k, p in step.net.named_parameters() if p.grad is not None}
     losses.append(float(step(frames, gt, K, poses)))
     torch.cuda.synchronize()
+    if step.peer is not None:
+        step.peer.check()                                    # no exchange timed out waiting for the other rank
     if rank == 0:
-        np.savez(out, losses=np.array(losses), launched_in_backward=step.buckets.launched_in_backward, **first,
+        from temporalstereo_amd import functional as TF
+        np.savez(out, losses=np.array(losses), launched_in_backward=step.buckets.launched_in_backward if step.buckets is not None else -1,
+                 exchanges=TF._EXCHANGES[0], **first,
                  **{"g::" + k: p.grad.detach().cpu().numpy() for k, p in step.net.named_parameters() if p.grad is not None},
                  **{"p::" + k: p.detach().cpu().numpy() for k, p in step.net.named_parameters()},
                  **{"b::" + k: b.detach().cpu().numpy() for k, b in step.net.named_buffers() if b.dtype.is_floating_point})

@@ -41,3 +41,27 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["value"] > 0.95 * d["f32_mfma_only"]["value"]
     tr = d["training"]
     assert "error" not in tr and tr["ms_per_step"] > 0 and tr["hipgraph"]["ms_per_step"] < tr["ms_per_step"]
+
+
+def test_driver_launch_of_eight_ranks():
+    """The driver's multi-GPU command, `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 --steps K --warmup W`, end to end on the one-GPU box: eight ranks on device 0 with gloo as
+    the rendezvous / barrier / max-over-ranks backend (RCCL refuses two ranks on one device; TS_BENCH_BACKEND / TS_BENCH_DEVICE are the
+    test hooks).  What this exercises before the first real SCALE run: rendezvous on 127.0.0.1, every rank building its engine, the
+    barrier + synchronize bracket, the MAX over ranks, ONE JSON line from rank 0 with the whole-job value, a clean exit of all ranks."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, TS_BENCH_BACKEND="gloo", TS_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--no-extras"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "replicas x8" and d["value"] > 0
+    # whole-job aggregate: 8 ranks x batch x steps over the slowest rank's time
+    assert abs(d["value"] - 8 * d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

@@ -702,7 +702,7 @@ def main():
             lau_b = sum(k1_algorithmic_bytes(*k) for k in launched)
             lau_t = sum(k1_times[k] for k in launched)
             traffic, traffic_file = None, None
-            for cand in ("r03_k1_hbm_traffic_pmc.json", "r02_k1_hbm_traffic_pmc.json"):
+            for cand in ("r04_k1_hbm_traffic_pmc.json", "r03_k1_hbm_traffic_pmc.json", "r02_k1_hbm_traffic_pmc.json"):
                 try:    # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected in-process)
                     with open(os.path.join(ROOT, "profiles", cand)) as fh:
                         pm = json.load(fh)
@@ -741,7 +741,7 @@ def main():
                             fused=fused,
                             beyond_infinity_cache=k1_b4,
                             traffic_source="profiles/%s: FETCH_SIZE / WRITE_SIZE passes of this command under rocprofv3 (tools/k1_traffic.py, "
-                                           "tools/prof_r03.sh); a PMC pass cannot run inside the timed process" % traffic_file)
+                                           "tools/prof_r04.sh); a PMC pass cannot run inside the timed process" % traffic_file)
         result = dict(metric="stereo pairs/sec, FlyingThings3D 540x960 D=192 (aggregation hot path)",
                       value=pairs / elapsed, unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                       ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling="weak",

@@ -43,9 +43,10 @@ def main(fetch_db, write_db):
                copy_fetch_over_true=find(F, "calib_copy") * kib / true, copy_write_over_true=find(W, "calib_copy") * kib / true)
     fx, wx = 1.0 / cal["read_fetch_over_true"], 1.0 / cal["fill_write_over_true"]
     rows = {}
-    for name, sub, grid in (("main (reference half + warped half + scale-0 correlation + pooled maps)", "block_cost_fast<true, true, 3, true>", (34, 16, 1)),
+    for name, sub, grid in (("main (reference half + warped half + scale-0 correlation + pooled maps)", "block_cost_fast<true, true, 3, true, true>", (34, 16, 1)),
                             ("expansion of the pooled maps", "block_cost_upsample_rows<true, 4>", (8, 80, 1)),
-                            ("pipeline: main without the reference half", "block_cost_fast<true, true, 3, false>", (34, 16, 1))):
+                            ("round 1-3 pipeline: main without the reference half", "block_cost_fast<true, true, 3, false, true>", (34, 16, 1)),
+                            ("round 4 pipeline: the correlation planes alone", "block_cost_fast<true, true, 3, false, false>", (34, 16, 1))):
         f, w = find(F, sub, grid) * kib, find(W, sub, grid) * kib
         rows[name] = dict(fetch_size_bytes_raw=f, write_size_bytes_raw=w, hbm_bytes=f * fx + w * wx)
     main_b = rows["main (reference half + warped half + scale-0 correlation + pooled maps)"]["hbm_bytes"]
@@ -56,9 +57,12 @@ def main(fetch_db, write_db):
                           hbm_bytes_per_launch=main_b + up_b, algorithmic_bytes=alg, ratio=(main_b + up_b) / alg,
                           correction="FETCH_SIZE x%.3f, WRITE_SIZE x%.3f (measured on the calibration streams of the same passes)" % (fx, wx),
                           calibration=cal, kernels=rows,
-                          pipeline_variant=dict(launch="ts_block_cost_sampled_warped_fwd",
-                                                hbm_bytes_per_launch=rows["pipeline: main without the reference half"]["hbm_bytes"] + up_b,
-                                                algorithmic_bytes=148968960)), indent=1))
+                          warped_variant=dict(launch="ts_block_cost_sampled_warped_fwd (rounds 1-3)",
+                                              hbm_bytes_per_launch=rows["round 1-3 pipeline: main without the reference half"]["hbm_bytes"] + up_b,
+                                              algorithmic_bytes=148968960),
+                          pipeline_variant=dict(launch="ts_block_cost_sampled_corr_fwd (round 4: what the pipeline launches)",
+                                                hbm_bytes_per_launch=rows["round 4 pipeline: the correlation planes alone"]["hbm_bytes"] + up_b,
+                                                algorithmic_bytes=65410560)), indent=1))
 
 
 if __name__ == "__main__":

@@ -52,6 +52,12 @@ def main(path, pattern="%ig_conv%"):
     tsum = sum(o[4] * o[3] for o in out)
     print("time-weighted MfmaUtil over %d dispatches of %d kernels: %.1f%%  (f32 MFMA peak 157.3 TF/s)" %
           (sum(o[3] for o in out), len(out), 100 * wsum / max(tsum, 1e-9)))
+    # the two arithmetic families apart: kernels on the bf16 pipe (x6 / x6s: six bf16 MFMAs per fp32 product
+    # block) and kernels on the f32-input MFMA
+    for label, sel in (("bf16-split kernels (ig_conv_x6*)", lambda n: "x6" in n), ("f32-input MFMA kernels", lambda n: "x6" not in n)):
+        part = [o for o in out if sel(o[1])]
+        w, t = sum(o[5] * o[4] * o[3] for o in part), sum(o[4] * o[3] for o in part)
+        print("  %-34s %4d dispatches  %9.1f us  time-weighted MfmaUtil %.1f%%" % (label, sum(o[3] for o in part), t, 100 * w / max(t, 1e-9)))
 
 
 if __name__ == "__main__":

@@ -58,7 +58,7 @@ def main():
             t = timed(lambda: ts.correlation1d(L, R, D), a.iters)
             rows.append(dict(op="correlation1d", shape=[B, C, D, H, W], algorithmic_bytes=nbytes, mean_us=t * 1e6, achieved_GBps=nbytes / t / 1e9,
                              frac_of_8TBps=nbytes / t / PEAK, flops=2.0 * B * C * D * H * W, tflops=2.0 * B * C * D * H * W / t / 1e12,
-                             note="C x D MACs per pixel on the vector ALUs (no matrix-core form: the shifted operand has no GEMM shape)"))
+                             note="a band of the row's Gram matrix on the matrix cores (v_mfma_f32_16x16x4_f32: corr_row_mfma_kernel, csrc/correlation.hip)"))
     for r in rows:
         print(json.dumps(r))
 

@@ -16,3 +16,18 @@ python tools/parity_planted_summary.py gpurun_out > $P/r04_parity_planted.txt 2>
 python tools/parity_stagewise_summary.py > $P/r04_parity_stagewise.txt 2>&1
 cp $O/x6s_bench.txt $P/r04_x6s_bench.txt; cp $O/layer_table_b1.txt $P/r04_layer_table_batch1.txt; cp $O/layer_table_b4.txt $P/r04_layer_table_batch4.txt
 cp $O/bench_train_2ranks_one_device.json $P/r04_bench_train_2ranks_one_device.json
+python - > $P/r04_parity_temporal_tail_audit.txt <<'PY'
+import json
+print("# tests/test_fullsize_gpu.py::test_temporal_tail_is_explained_pixel_by_pixel on 1xMI355X: free-running sequences against the oracle,")
+print("# every moved pixel (> 1e-3 px at its level) explained: near-tie of the oracle / sort near-tie / reach of such an event / inherited from the")
+print("# level above or from the entering state / within the soft-argmax's sensitivity to the measured cost error.  unexplained must be 0.")
+print("%-12s %5s %-8s %8s %7s %10s %12s %10s" % ("config", "frame", "level", "pixels", "moved", "near-ties", "unexplained", "max move"))
+for r in json.load(open("gpurun_out/parity_temporal_tail_audit.json")):
+    c = r["config"][:10]
+    if "level" in r:
+        print("%-12s %5d %-8s %8d %7d %10d %12d %10.2e" % (c, r["frame"], r["level"], r["pixels"], r["moved"], r["near_ties"], r["unexplained"], r["max_move"]))
+    elif "off_by_0p05" in r:
+        print("%-12s %5d %-8s full-resolution pixels off by > 0.05 px: %d, outside every explained 1/4-resolution pixel: %d" % (c, r["frame"], "full", r["off_by_0p05"], r["uncovered"]))
+    elif "differing" in r:
+        print("%-12s %5d %-8s entering state differs by > 1e-4 at %d of %d memory pixels" % (c, r["frame"], "state", r["differing"], r["pixels"]))
+PY

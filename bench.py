@@ -391,7 +391,19 @@ def main():
     seed = synth.SEED0 + 2                      # config index 2
     if a.mode in ("train", "train-graph"):
         tr = training_leg(dev, rank, world, a.steps, a.warmup, a.batch, seed, graph=a.mode == "train-graph")
+
+        def line():
+            return json.dumps(dict(metric="stereo pairs/sec, TRAINING step, FlyingThings3D 540x960 D=192 T=2 (aggregation hot path)",
+                                   value=tr["value"], unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                                   ms_per_step=tr["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                                   data="synthetic",
+                                   config=dict(workload="FlyingThings3D 540x960 (run 544x960) D=192 temporal T=2 training step, batch %d/GPU" % a.batch,
+                                               run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
+                                               parallelism="dp%d" % world, exec_mode=a.mode),
+                                   training=tr))
         if world > 1 and os.environ.get("TS_BENCH_PEER", "1") != "0":
+            if rank == 0:
+                print(line(), flush=True)      # the collectives leg is on record whatever the legs below do (a reader takes the LAST line)
             # the same step with SyncBatchNorm's exchanges as kernels over the peer mailboxes (eager, then replayed from a hipGraph:
             # legal for world > 1 only in this form).  After the collectives leg, and guarded: it has only ever run with the ranks on
             # ONE device (tests/test_ddp_gpu.py) -- across devices a peer that does not answer times out (no hang) and the leg reports it.
@@ -409,14 +421,7 @@ def main():
                     tr[key] = dict(error="%s: %s" % (type(e).__name__, e))
                     break
         if rank == 0:
-            print(json.dumps(dict(metric="stereo pairs/sec, TRAINING step, FlyingThings3D 540x960 D=192 T=2 (aggregation hot path)",
-                                  value=tr["value"], unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                                  ms_per_step=tr["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
-                                  data="synthetic",
-                                  config=dict(workload="FlyingThings3D 540x960 (run 544x960) D=192 temporal T=2 training step, batch %d/GPU" % a.batch,
-                                              run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
-                                              parallelism="dp%d" % world, exec_mode=a.mode),
-                                  training=tr)), flush=True)
+            print(line(), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -817,8 +822,12 @@ def main():
                         dict(error="exit code %d: %s" % (child.returncode, (se or so)[-400:]))
                 except subprocess.TimeoutExpired:
                     os.killpg(child.pid, signal.SIGKILL)                              # exactly the group started above
-                    child.communicate()
-                    result["training"] = dict(error="timed out (a rank stuck in a collective?)")
+                    so, _ = child.communicate()
+                    lines = [ln for ln in (so or "").splitlines() if ln.startswith("{")]
+                    if lines:       # the collectives leg had finished (its line goes out before the peer legs start)
+                        result["training"] = dict(json.loads(lines[-1])["training"], later_legs="timed out")
+                    else:
+                        result["training"] = dict(error="timed out (a rank stuck in a collective?)")
             except Exception as e:          # the headline must survive anything the extra leg does
                 result["training"] = dict(error="%s: %s" % (type(e).__name__, e))
         print(json.dumps(result), flush=True)

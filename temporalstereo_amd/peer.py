@@ -32,31 +32,45 @@ class PeerGroup:
             raise RuntimeError("PeerGroup: %d ranks, a node holds at most %d" % (self.world, int(L.ts_peer_max_ranks())))
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.max_floats = int(L.ts_peer_max_floats())
+        backend = dist.get_backend(group)
+        self._cdev = self.device if backend == "nccl" else torch.device("cpu")      # where this backend wants its tensors
+        self._mine, self._opened, failure = None, [], None
         with torch.cuda.device(self.device):
             mine = ctypes.c_void_p()
             handle = (ctypes.c_ubyte * 64)()
-            _lib.check(L.ts_peer_alloc(ctypes.byref(mine), handle), "ts_peer_alloc")
-            self._mine = mine
-            # the handles through the process group (gloo moves CPU tensors, RCCL device tensors)
-            backend = dist.get_backend(group)
-            hdev = self.device if backend == "nccl" else torch.device("cpu")
-            h = torch.tensor(list(bytes(handle)), dtype=torch.uint8, device=hdev)
+            try:
+                _lib.check(L.ts_peer_alloc(ctypes.byref(mine), handle), "ts_peer_alloc")
+                self._mine = mine
+            except RuntimeError as e:
+                failure = str(e)
+            # the handles through the process group (gloo moves CPU tensors, RCCL device tensors).  EVERY rank takes part in every
+            # collective of the set-up whatever happened to it locally, and the outcome is agreed on at the end: a rank that raised
+            # alone would leave the others waiting in the next collective.
+            h = torch.tensor(list(bytes(handle)), dtype=torch.uint8, device=self._cdev)
             allh = [torch.empty_like(h) for _ in range(self.world)]
             dist.all_gather(allh, h, group=group)
-            self._opened = []
             self.ctx = _Ctx()
             self.ctx.rank, self.ctx.world = self.rank, self.world
             for r in range(self.world):
                 if r == self.rank:
                     self.ctx.region[r] = mine.value
                     continue
+                if failure is not None:
+                    continue
                 raw = (ctypes.c_ubyte * 64)(*allh[r].cpu().tolist())
                 p = ctypes.c_void_p()
-                _lib.check(L.ts_peer_open(raw, ctypes.byref(p)), "ts_peer_open")
-                self._opened.append(p)
-                self.ctx.region[r] = p.value
+                try:
+                    _lib.check(L.ts_peer_open(raw, ctypes.byref(p)), "ts_peer_open")
+                    self._opened.append(p)
+                    self.ctx.region[r] = p.value
+                except RuntimeError as e:
+                    failure = "mailbox of rank %d: %s" % (r, e)
         self._ctxp = ctypes.cast(ctypes.pointer(self.ctx), ctypes.c_void_p)
-        dist.barrier(group=group)             # nobody exchanges before everybody has mapped everybody
+        ok = torch.tensor([0.0 if failure is None else 1.0], device=self._cdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MAX, group=group)      # also the barrier: nobody exchanges before everybody has mapped everybody
+        if float(ok.item()) != 0.0:
+            self._release()
+            raise RuntimeError("PeerGroup: the mailboxes could not be mapped on every rank (%s)" % (failure or "another rank failed"))
         self.exchanges = 0                    # issued from this process (eager calls and captures; replays are not counted)
 
     def all_gather(self, src, dst):
@@ -75,26 +89,35 @@ class PeerGroup:
         self.exchanges += 1
         return buf
 
-    def check(self):
-        """Synchronises the current stream; raises when some exchange timed out waiting for a peer."""
+    def check(self, collective=True):
+        """Synchronises the current stream; raises when some exchange timed out waiting for a peer.  collective: the ranks agree on
+        the outcome first (one all_reduce), so that either all of them raise or none does -- call it from every rank."""
         from .functional import _stream
         st = ctypes.c_int(0)
         _lib.check(_lib._real_lib().ts_peer_status(self._ctxp, ctypes.byref(st), _stream()), "ts_peer_status")
-        if st.value:
+        bad = st.value
+        if collective and dist.is_initialized():
+            t = torch.tensor([float(bad)], device=self._cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            bad = int(t.item())
+        if bad:
             raise RuntimeError("PeerGroup: rank %d did not answer an exchange within the bound (are all ranks issuing the same "
-                               "sequence of exchanges?)" % (st.value - 1))
+                               "sequence of exchanges?)" % (bad - 1))
 
-    def close(self):
+    def _release(self):
         L = _lib._real_lib()
-        torch.cuda.synchronize(self.device)
-        if dist.is_initialized():
-            dist.barrier(group=self.group)    # nobody unmaps while a peer may still write
         for p in self._opened:
             L.ts_peer_close(p)
         self._opened = []
         if self._mine is not None:
             L.ts_peer_free(self._mine)
             self._mine = None
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        if dist.is_initialized():
+            dist.barrier(group=self.group)    # nobody unmaps while a peer may still write
+        self._release()
 
 
 _INSTALLED = None

@@ -116,10 +116,10 @@ def test_peer_mailbox_syncbn_equals_the_collectives_and_replays_from_a_graph(tmp
     graph = _worker(tmp_path, "peer_graph", "graph.npz")
     assert int(peer["exchanges"]) == int(coll["exchanges"]) > 0
     w, k = _worst(coll, peer, "g1::")          # (two runs of the same step differ by this much: atomics in the splat / K1 backward)
-    assert w < 5e-4, ("peer vs collectives, first-step gradients", k, w)          # measured 0.6e-4 ... 1.7e-4
+    assert w < 8e-4, ("peer vs collectives, first-step gradients", k, w)          # measured 0.5e-4 ... 2.1e-4 over eight runs
     w, k = _worst(peer, graph, "g1::")
     print("first-step gradients, worst relative difference: peer vs collectives %.2e, graph vs eager %.2e" % (_worst(coll, peer, "g1::")[0], w))
-    assert w < 3e-4, ("graph replay vs eager, first-step gradients", k, w)       # measured 1.0e-4: the run-to-run spread of the step itself (atomics in the splat and in the K1 backward), DESIGN.md
+    assert w < 8e-4, ("graph replay vs eager, first-step gradients", k, w)       # measured 0.6e-4 ... 2.3e-4 over eight runs: the run-to-run spread of the two-rank step itself (float atomics in the splat and in the K1 backward; two processes share the device), DESIGN.md
     assert abs(float(graph["losses"][0]) - float(peer["losses"][0])) <= 1e-5 * abs(float(peer["losses"][0]))
     for k in peer.files:                                       # BatchNorm running statistics after two steps
         if k.startswith("b::"):

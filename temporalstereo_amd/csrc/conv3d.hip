@@ -507,23 +507,23 @@ ig_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
 // disjoint banks) a wave then stores 64 float4 of ONE channel: eight full 128-byte rows per instruction, a quarter of the
 // instructions.  Needs whole quads (Wo % 4 == 0 for the 8 x 32 pixel tiles, H W % 4 == 0 for the 256-pixel runs of MODE_D).
 constexpr int kEpiPitch = 272;
-template <int NCB>
-__device__ __forceinline__ void epilogue_stage(float* epi, const float (&v)[NCB][4][4], int wave, int kq, int j) {
+template <int NCB, int NPB = 4>       // NPB: 16-pixel blocks per wave (a wave's pixels are NPB * 16 consecutive tile pixels)
+__device__ __forceinline__ void epilogue_stage(float* epi, const float (&v)[NCB][NPB][4], int wave, int kq, int j) {
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb)
+    for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) epi[(cb * 16 + kq * 4 + r) * kEpiPitch + wave * 64 + pb * 16 + j] = v[cb][pb][r];
+      for (int r = 0; r < 4; ++r) epi[(cb * 16 + kq * 4 + r) * kEpiPitch + wave * (NPB * 16) + pb * 16 + j] = v[cb][pb][r];
 }
 // tile pixel quad q (0..63) of channel co: byte offset of its first pixel inside the channel plane, or kOOB
-template <int NCB, int NT = 256, class QuadOffset>
+template <int NCB, int NT = 256, int QPC = 64, class QuadOffset>       // QPC: pixel quads per channel of the tile
 __device__ __forceinline__ void epilogue_flush(const float* epi, __amdgpu_buffer_rsrc_t yr, unsigned ocs, int co_base, int Cout,
                                                QuadOffset quad_offset) {
 #pragma unroll
-  for (int it = 0; it < NCB * 1024 / NT; ++it) {
+  for (int it = 0; it < NCB * 16 * QPC / NT; ++it) {
     const int idx = static_cast<int>(threadIdx.x) + NT * it;
-    const int col = idx >> 6, q = idx & 63;
+    const int col = idx / QPC, q = idx % QPC;
     const u32x4 val = *reinterpret_cast<const u32x4*>(epi + col * kEpiPitch + q * 4);
     const unsigned po = quad_offset(q);
     const int co = co_base + col;
@@ -559,15 +559,22 @@ weight_split6_kernel(const float* __restrict__ w_t, u32x4* __restrict__ w6, int 
   }
 }
 
-template <int CB, int DL>
-__global__ void __launch_bounds__(256, 2)
+// TR: output rows of the tile.  8 (a wave owns two rows: the form of full grids) or 4 (one row per wave, round 4): on grids under a round
+// of workgroups the kernel's duration is ONE workgroup's serial chain (barrier - commit - barrier - fragment reads - MFMAs per chunk),
+// and half a tile is half a chain at 3 workgroups per CU instead of 2 -- what the transposed x6s forms gained from the same cut
+// (conv_x6s.hip).  Dilation 1 only (the staging deal below).
+template <int CB, int DL, int TR = 8>
+__global__ void __launch_bounds__(256, TR == 8 ? 2 : 3)
 ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, const float* __restrict__ scale,
                   const float* __restrict__ shift, float* __restrict__ y, const IG p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 lds6[];
   // Staged tile: rows ty0-DL .. ty0+7+DL, columns tx0-4 .. tx0+35 as ten ALIGNED quads per row (W % 4 == 0: a quad is inside
   // the image or outside it, never across its border).  One dwordx4 per (row, quad, channel): the first version staged single
   // pixels -- 32 dword gathers per thread and chunk, ~29 cycles of the texture addresser each, 60 % of the kernel's time.
-  constexpr int in_rows = 8 + 2 * DL, QPR = 10, LCOLS = 4 * QPR, NPIX = in_rows * LCOLS;
+  static_assert(TR == 8 || DL == 1, "4-row tiles: dilation 1");
+  constexpr int NPB = TR / 2;                          // 16-pixel blocks per wave
+  constexpr int SPC = TR == 8 ? 2 : 4;                  // staging threads per (row, quad): each takes 16 / SPC channels
+  constexpr int in_rows = TR + 2 * DL, QPR = 10, LCOLS = 4 * QPR, NPIX = in_rows * LCOLS;
   // pitch of a (part, group) block: a multiple of 16 entries, so that the 8 + 8 lanes of one ds_read_b128 bank group (lanes of channel group 0
   // and of group 1, same pixels) land on disjoint banks; round 3's NPIX + 1 made EVERY fragment read a 2-way conflict (8 LDS cycles for 4:
   // SQ_LDS_BANK_CONFLICT 47 % of SQ_LDS_IDX_ACTIVE).  Conflict-free reads change nothing measurable (1276 vs 1275 pairs/s) -- the LDS is 37 %
@@ -575,7 +582,7 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
   constexpr int NPIXP = NPIX;
   static_assert(NPIXP % 16 == 0, "block pitch");
   constexpr int SLOTS = in_rows * QPR;                  // (row, quad) pairs; threads [0, SLOTS) stage channels 0-7, [SLOTS, 2 SLOTS) 8-15
-  static_assert(2 * SLOTS <= 256, "staging slots");
+  static_assert(SPC * SLOTS <= 256, "staging slots");
   constexpr int COB = CB * 16;
   constexpr int WV = 3 * X6_SLOTS * 2 * COB;            // 16-byte weight vectors per chunk
   constexpr int RWN = (WV + 255) / 256;
@@ -603,13 +610,14 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
   const int ks = (bz / p.co_groups) % p.ksplit, b = bz / (p.co_groups * p.ksplit);
   const int kbeg = ks * p.kspan, kend = min(p.Cin, kbeg + p.kspan);
   const int co0 = cog * COB;
-  const int ty0 = (tile / p.tiles_x) * 8, tx0 = (tile % p.tiles_x) * 32;
+  const int ty0 = (tile / p.tiles_x) * TR, tx0 = (tile % p.tiles_x) * 32;
   const unsigned HW = static_cast<unsigned>(p.H) * p.W;
   const unsigned cstride_b = static_cast<unsigned>(p.in_cstride) * 4u;
 
-  const bool stager = threadIdx.x < 2 * SLOTS;
-  const int sg = (static_cast<int>(threadIdx.x) >= SLOTS) ? 1 : 0;            // channel group this thread stages
-  const int sslot = static_cast<int>(threadIdx.x) - sg * SLOTS;
+  const bool stager = threadIdx.x < SPC * SLOTS;
+  const int spart = static_cast<int>(threadIdx.x) / SLOTS;                    // which 16 / SPC channels of the chunk this thread stages
+  const int sg = TR == 8 ? spart : (spart >> 1), shalf = spart & 1;           // channel group; TR == 4: its first / second four channels
+  const int sslot = static_cast<int>(threadIdx.x) - spart * SLOTS;
   const int srow = sslot / QPR, squad = sslot - srow * QPR;
   unsigned goff = kOOB;
   {
@@ -634,18 +642,18 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
   const unsigned wchunk_b = static_cast<unsigned>(3 * X6_SLOTS * 2 * p.coutp) * 16u;
 
   // fragment bases (u32x4 units): B = pixel of this lane in each 16-pixel block, group kq & 1; A = channel j, group kq & 1
-  int boff[4];
+  int boff[NPB];
 #pragma unroll
-  for (int pb = 0; pb < 4; ++pb)
-    boff[pb] = (kq & 1) * NPIXP + (wave * 2 + (pb >> 1)) * LCOLS + (4 - DL) + (pb & 1) * 16 + j;
+  for (int pb = 0; pb < NPB; ++pb)
+    boff[pb] = (kq & 1) * NPIXP + (TR == 8 ? wave * 2 + (pb >> 1) : wave) * LCOLS + (4 - DL) + (pb & 1) * 16 + j;
   const int aoff = (kq & 1) * COB + j;
   const int tsel = kq >> 1;                             // which tap of a step's pair
 
-  v4f acc[CB][4];
+  v4f acc[CB][NPB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int pb = 0; pb < NPB; ++pb) acc[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
   float esc[CB][4], esh[CB][4];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
@@ -656,13 +664,14 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
       esh[cb][r] = shift ? shift[co] : 0.f;
     }
 
-  v4f rin[8];
+  constexpr int NCH = 16 / SPC;                         // channels per staging thread
+  v4f rin[NCH];
   u32x4 rw[RWN];
   auto fetch = [&](int c0) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       // channels past Cin re-read the last real one; their weights are zero
-      const unsigned co = static_cast<unsigned>(min(c0 + sg * 8 + c, p.Cin - 1)) * cstride_b;
+      const unsigned co = static_cast<unsigned>(min(c0 + spart * NCH + c, p.Cin - 1)) * cstride_b;
       rin[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, goff == kOOB ? kOOB : goff + co, 0, 0));
     }
     const unsigned wso = static_cast<unsigned>(c0 / X6_NC) * wchunk_b;
@@ -673,12 +682,14 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
     if (stager) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        unsigned part[3][4];
+        unsigned part[3][NCH / 2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split6(rin[2 * e][i], rin[2 * e + 1][i], part[0][e], part[1][e], part[2][e]);
+        for (int e = 0; e < NCH / 2; ++e) split6(rin[2 * e][i], rin[2 * e + 1][i], part[0][e], part[1][e], part[2][e]);
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt)
-          in6[pt * 2 * NPIXP + lpix + i] = u32x4{part[pt][0], part[pt][1], part[pt][2], part[pt][3]};
+        for (int pt = 0; pt < 3; ++pt) {
+          if constexpr (TR == 8) in6[pt * 2 * NPIXP + lpix + i] = u32x4{part[pt][0], part[pt][1], part[pt][2], part[pt][3]};
+          else reinterpret_cast<u32x2*>(in6 + pt * 2 * NPIXP + lpix + i)[shalf] = u32x2{part[pt][0], part[pt][1]};
+        }
       }
     }
 #pragma unroll
@@ -698,11 +709,11 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
     // the chunk's products are summed in accumulators of their own and added to the running sum with an ordinary fp32 add: the
     // matrix core aligns the 32 products of an instruction to the largest addend, the running sum included, and drops what falls
     // below its last bit -- against a chunk-sized partial sum that costs far fewer bits than against the sum of all chunks
-    v4f part[CB][4];
+    v4f part[CB][NPB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int pb = 0; pb < 4; ++pb) part[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
+      for (int pb = 0; pb < NPB; ++pb) part[cb][pb] = v4f{0.f, 0.f, 0.f, 0.f};
     bf16x8 a[2][3][CB], bv[2][3][2];
     auto load_a = [&](int s, int buf) {
       const int slot = 2 * s + tsel;
@@ -721,14 +732,15 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
 #pragma unroll
         for (int k = 0; k < 2; ++k) bv[buf][pt][k] = __builtin_bit_cast(bf16x8, in6[pt * 2 * NPIXP + boff[2 * h + k] + toff]);
     };
+    constexpr int NH = NPB / 2;                                           // half-steps per step (pixel-block pairs of a wave)
     load_a(0, 0);
     load_b(0, 0, 0);
 #pragma unroll
-    for (int u = 0; u < X6_SLOTS; ++u) {                                  // half-step u = 2 s + h
-      const int s = u >> 1, h = u & 1;
-      if (u + 1 < X6_SLOTS) {
-        load_b((u + 1) >> 1, (u + 1) & 1, (u + 1) & 1);
-        if (h == 1) load_a(s + 1, (s + 1) & 1);
+    for (int u = 0; u < 5 * NH; ++u) {                                    // half-step u = NH s + h
+      const int s = u / NH, h = u % NH;
+      if (u + 1 < 5 * NH) {
+        load_b((u + 1) / NH, (u + 1) % NH, (u + 1) & 1);
+        if (h == NH - 1) load_a(s + 1, (s + 1) & 1);
       }
       constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first
 #pragma unroll
@@ -742,7 +754,7 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int pb = 0; pb < 4; ++pb) acc[cb][pb] += part[cb][pb];
+      for (int pb = 0; pb < NPB; ++pb) acc[cb][pb] += part[cb][pb];
   }
 
   const size_t hw_o = static_cast<size_t>(p.Ho) * p.Wo;
@@ -753,10 +765,10 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
       : ig_rsrc(y + static_cast<long long>(b) * p.out_bstride, p.out_bytes);
   const unsigned ocs = split ? oplane * 4u : static_cast<unsigned>(p.out_cstride) * 4u;
   const float* ab = (p.addend && !split) ? p.addend + static_cast<size_t>(b) * p.add_bstride : nullptr;
-  float outv[CB][4][4];
+  float outv[CB][NPB][4];
 #pragma unroll
-  for (int pb = 0; pb < 4; ++pb) {
-    const int oy = ty0 + wave * 2 + (pb >> 1), ox = tx0 + (pb & 1) * 16 + j;
+  for (int pb = 0; pb < NPB; ++pb) {
+    const int oy = ty0 + (TR == 8 ? wave * 2 + (pb >> 1) : wave), ox = tx0 + (pb & 1) * 16 + j;
     const bool inside = oy < p.Ho && ox < p.Wo;
     const unsigned ppix = static_cast<unsigned>(oy) * p.Wo + ox;
 #pragma unroll
@@ -771,10 +783,10 @@ ig_conv_x6_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, con
   }
   __syncthreads();                                      // the last chunk's fragments are consumed: the tile buffers become the staging area
   float* epi = reinterpret_cast<float*>(lds6);
-  epilogue_stage<CB>(epi, outv, wave, kq, j);
+  epilogue_stage<CB, NPB>(epi, outv, wave, kq, j);
   __syncthreads();
   const unsigned obase = static_cast<unsigned>(od) * static_cast<unsigned>(hw_o);
-  epilogue_flush<CB>(epi, yr, ocs, co0, p.Cout, [&](int q) {
+  epilogue_flush<CB, 256, TR * 8>(epi, yr, ocs, co0, p.Cout, [&](int q) {
     const int oy = ty0 + (q >> 3), ox = tx0 + (q & 7) * 4;
     return (oy < p.Ho && ox < p.Wo) ? (obase + static_cast<unsigned>(oy) * p.Wo + ox) * 4u : kOOB;       // W % 4 == 0: whole quads
   });
@@ -1333,7 +1345,6 @@ int conv_hw_impl(const float* x, const float* w_t, const float* scale, const flo
 // The tap arithmetic is block_cost.hip's (the reference's normalise / un-normalise float sequence), so tap positions round identically.
 // One lane per output pixel of one candidate; the two columns of a tap are one 8-byte load (dword-aligned buffer load).
 // ------------------------------------------------------------------------------------------------
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int DL>
 __global__ void __launch_bounds__(256)
@@ -1411,12 +1422,12 @@ warp_gather_kernel(const float* __restrict__ q, const float* __restrict__ disp, 
 }
 
 // ---- x6 (bf16-split) form of the stride-1 (1,3,3) convolution ------------------------------------------------------
-template <int CB, int DL>
+template <int CB, int DL, int TR = 8>
 int launch_x6(const float* x, const void* w6, const float* scale, const float* shift, float* y, const IG& p, dim3 grid, hipStream_t st) {
-  constexpr int NPIXP = (8 + 2 * DL) * 40;
+  constexpr int NPIXP = (TR + 2 * DL) * 40;
   constexpr size_t lds = (static_cast<size_t>(3) * 2 * NPIXP + 3 * X6_SLOTS * 2 * CB * 16 + 1) * 16;
   static_assert(lds <= 80 * 1024, "ig_conv_x6_kernel: two workgroups per CU");
-  auto kern = &ig_conv_x6_kernel<CB, DL>;
+  auto kern = &ig_conv_x6_kernel<CB, DL, TR>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, static_cast<const u32x4*>(w6), scale, shift, y, p);
@@ -1532,7 +1543,14 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
   const dim3 grid(tiles, D, B * p.co_groups * p.ksplit);
   hipStream_t st = ts::as_stream(stream);
   int rc;
-  if (cb == 2) rc = dilation == 2 ? launch_x6<2, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<2, 1>(x, w6, scale, shift, y, p, grid, st);
+  // grids under 3/4 of a round of 8-row workgroups (2 per CU): 4-row tiles (ig_conv_x6_kernel, TR); TS_X6_TR=8 | 4 forces one form
+  static const long long tr_env = env_ll("TS_X6_TR", 0);
+  const long long wgs8 = static_cast<long long>(tiles) * D * B * p.co_groups * p.ksplit;
+  const bool tr4 = dilation == 1 && (tr_env ? tr_env == 4 : wgs8 < 3 * ts::kNumCU / 2);
+  if (tr4) {
+    const dim3 grid4(((H + 3) / 4) * p.tiles_x, D, B * p.co_groups * p.ksplit);
+    rc = cb == 2 ? launch_x6<2, 1, 4>(x, w6, scale, shift, y, p, grid4, st) : launch_x6<1, 1, 4>(x, w6, scale, shift, y, p, grid4, st);
+  } else if (cb == 2) rc = dilation == 2 ? launch_x6<2, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<2, 1>(x, w6, scale, shift, y, p, grid, st);
   else rc = dilation == 2 ? launch_x6<1, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6<1, 1>(x, w6, scale, shift, y, p, grid, st);
   if (rc || !split) return rc;
   long long blocks = (plane + 255) / 256;

@@ -24,6 +24,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float p, int co = 0
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 enum { MODE_HW = 0, MODE_HWT = 1, MODE_D = 2 };
 constexpr unsigned kOOB = 0x80000000u;   // buffer offset past every num_records we allow: the load returns 0
 

@@ -23,21 +23,21 @@
 namespace {
 
 enum { XS_S2 = 0, XS_T3 = 1, XS_T4 = 2 };
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int MODE>
+template <int MODE, int TR = 8>       // TR: input rows of a transposed form's tile (8: two per wave; 4: one per wave)
 struct XG {
   static constexpr bool T = MODE != XS_S2;
-  static constexpr int in_rows = T ? 10 : 9;
+  static constexpr int in_rows = T ? TR + 2 : 9;
   static constexpr int QPR = T ? 10 : 18;              // aligned quads per staged row
   static constexpr int LCOLS = 4 * QPR;
   static constexpr int NPIX = in_rows * LCOLS, NPIXP = NPIX + 1;
   static constexpr int SLOTS = in_rows * QPR;          // (row, quad) staging slots
   static constexpr int NSLOT = T ? 16 : 12;            // tap slots per chunk (4 per MFMA step)
   static constexpr int NU = T ? 4 : 3;                 // MFMA steps per chunk (T: one per parity class)
-  static constexpr int NPB = T ? 4 : 2;                // 16-pixel blocks per wave
+  static constexpr int NPB = T ? TR / 2 : 2;           // 16-pixel blocks per wave
+  static constexpr int EPI = T ? TR * 64 + 4 : 132;    // LDS pitch of a channel of the output staging
 };
-constexpr int kEpiS2 = 132, kEpiT = 516;               // LDS pitches of the output staging (see the epilogues)
+constexpr int kEpiS2 = 132;               // LDS pitches of the output staging (see the epilogues)
 
 // which weight tap (index into w_t's tap dimension) slot s multiplies, -1: none (zero weights)
 //   transposed forms, per axis and output parity: even -> option 0 = (k 1, d 0), option 1 = (k 3, d -1) [k4 only];
@@ -78,12 +78,12 @@ weight_split6_g8_kernel(const float* __restrict__ w_t, u32x4* __restrict__ w6, i
   }
 }
 
-template <int MODE, int CB>
-__global__ void __launch_bounds__(256, 2)
+template <int MODE, int CB, int TR = 8>
+__global__ void __launch_bounds__(256, TR == 4 ? 3 : 2)
 ig_conv_x6s_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, const float* __restrict__ scale,
                    const float* __restrict__ shift, float* __restrict__ y, const IG p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 lds6[];
-  using G = XG<MODE>;
+  using G = XG<MODE, TR>;
   constexpr bool T = G::T;
   static_assert(!T || CB == 1, "transposed forms: 16 output channels per workgroup (four classes of accumulators)");
   constexpr int LCOLS = G::LCOLS, NPIXP = G::NPIXP, NSLOT = G::NSLOT, NU = G::NU, NPB = G::NPB, SLOTS = G::SLOTS;
@@ -106,7 +106,7 @@ ig_conv_x6s_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   const int cog = bz % p.co_groups, b = bz / p.co_groups;
   const int co0 = cog * COB;
   // tile origin: T -> input pixels (8 x 32), S2 -> output pixels (4 x 32)
-  const int ty0 = (tile / p.tiles_x) * (T ? 8 : 4), tx0 = (tile % p.tiles_x) * 32;
+  const int ty0 = (tile / p.tiles_x) * (T ? TR : 4), tx0 = (tile % p.tiles_x) * 32;
   const int row0 = T ? ty0 - 1 : 2 * ty0 - 1, col0 = T ? tx0 - 4 : 2 * tx0 - 4;     // first staged input row / column
   const unsigned HW = static_cast<unsigned>(p.H) * p.W;
   const unsigned cstride_b = static_cast<unsigned>(p.in_cstride) * 4u;
@@ -142,7 +142,7 @@ ig_conv_x6s_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   int boff[NPB], toff[NU];
 #pragma unroll
   for (int pb = 0; pb < NPB; ++pb) {
-    if (T) boff[pb] = (wave * 2 + (pb >> 1) + 1) * LCOLS + 4 + (pb & 1) * 16 + j;       // input pixel (ty0 + 2w + (pb>>1), tx0 + ...)
+    if (T) boff[pb] = ((TR == 8 ? wave * 2 + (pb >> 1) : wave) + 1) * LCOLS + 4 + (pb & 1) * 16 + j;       // input pixel (ty0 + 2w + (pb>>1), tx0 + ...)
     else boff[pb] = (2 * wave) * LCOLS + 3 + 2 * (pb * 16 + j);                         // input pixel (2 oy - 1, 2 ox - 1): tap (0, 0)
   }
 #pragma unroll
@@ -301,17 +301,17 @@ ig_conv_x6s_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = co0 + kq * 4 + r;
-            epi[(kq * 4 + r) * kEpiT + (wave * 2 + (pb >> 1)) * 64 + 2 * ((pb & 1) * 16 + j) + pbit] =
+            epi[(kq * 4 + r) * G::EPI + (TR == 8 ? wave * 2 + (pb >> 1) : wave) * 64 + 2 * ((pb & 1) * 16 + j) + pbit] =
                 apply_act(acc[pa * 2 + pbit][0][pb][r] * esc[0][r] + esh[0][r], p.act, p.act_param, co);
           }
       __syncthreads();
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < TR; ++it) {
         const int idx = static_cast<int>(threadIdx.x) + 256 * it;
-        const int col = idx >> 7, rem = idx & 127;
+        const int col = idx / (TR * 16), rem = idx % (TR * 16);
         const int row = rem >> 4, q = rem & 15;
         const int iy = ty0 + row, oy = 2 * iy + pa, ox = 2 * tx0 + 4 * q;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(epi + col * kEpiT + row * 64 + q * 4);
+        const u32x4 val = *reinterpret_cast<const u32x4*>(epi + col * G::EPI + row * 64 + q * 4);
         const int co = co0 + col;
         const unsigned off = (iy < p.H && oy < p.Ho && ox < p.Wo && co < p.Cout)
             ? (obase + static_cast<unsigned>(oy) * p.Wo + ox) * 4u + static_cast<unsigned>(co) * ocs : kOOB;
@@ -321,14 +321,14 @@ ig_conv_x6s_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   }
 }
 
-template <int MODE, int CB>
+template <int MODE, int CB, int TR = 8>
 int launch_x6s(const float* x, const void* w6, const float* scale, const float* shift, float* y, const IG& p, dim3 grid, hipStream_t st) {
-  using G = XG<MODE>;
+  using G = XG<MODE, TR>;
   constexpr size_t main_b = (static_cast<size_t>(3) * G::NPIXP + 3 * G::NSLOT * CB * 16 + 1) * 16;
-  constexpr size_t epi_b = G::T ? static_cast<size_t>(16) * kEpiT * 4 : static_cast<size_t>(CB) * 16 * kEpiS2 * 4;
+  constexpr size_t epi_b = G::T ? static_cast<size_t>(16) * G::EPI * 4 : static_cast<size_t>(CB) * 16 * kEpiS2 * 4;
   constexpr size_t lds = main_b > epi_b ? main_b : epi_b;
   static_assert(lds <= 64 * 1024, "ig_conv_x6s_kernel: LDS tile");
-  hipLaunchKernelGGL((ig_conv_x6s_kernel<MODE, CB>), grid, dim3(256), lds, st, x, static_cast<const u32x4*>(w6), scale, shift, y, p);
+  hipLaunchKernelGGL((ig_conv_x6s_kernel<MODE, CB, TR>), grid, dim3(256), lds, st, x, static_cast<const u32x4*>(w6), scale, shift, y, p);
   return ts::launched("ig_conv_x6s_kernel");
 }
 
@@ -402,8 +402,20 @@ extern "C" int ts_conv3d_hw_x6s_fwd(const float* x, const void* w6, const float*
     return cb == 2 ? launch_x6s<XS_S2, 2>(x, w6, scale, shift, y, p, grid, st) : launch_x6s<XS_S2, 1>(x, w6, scale, shift, y, p, grid, st);
   }
   p.tiles_x = (W + 31) / 32;
-  const int tiles = ((H + 7) / 8) * p.tiles_x;
   p.co_groups = p.coutp / 16;
+  // Tile rows.  A workgroup of the 8-row form is a long serial chain (barrier - commit - barrier - fragment reads - MFMAs per chunk,
+  // then the two-half epilogue: ~15 us alone) at 226-236 VGPRs, two per CU; the 4-row form (one input row per wave: 150-160 VGPRs,
+  // 24 KB of LDS, three per CU) halves the chain.  Measured (tools/x6s_bench.py, 8 -> 4 rows): deconv4 32 -> 32 on 136 x 240 (272
+  // workgroups of 8 rows) 21.5 -> 17.8 us, the hourglasses' transposed layers 15.5 -> 10.8 and 19.4 -> 12.1; deconv2 32 -> 9 on 272 x 480
+  // (510 workgroups: a full round of the 8-row form) 23.2 -> 24.9, batch 4 flat.  So: 4 rows below 3/4 of a round.  TS_X6S_TR=4 | 8 forces one.
+  static const long long tr_env = env_ll("TS_X6S_TR", 0);
+  const long long wgs8 = static_cast<long long>((H + 7) / 8) * p.tiles_x * D * B * p.co_groups;
+  const long long tr = tr_env ? tr_env : (wgs8 < 3 * ts::kNumCU / 2 ? 4 : 8);
+  if (tr == 4) {
+    const dim3 grid(((H + 3) / 4) * p.tiles_x, D, B * p.co_groups);
+    return mode == XS_T4 ? launch_x6s<XS_T4, 1, 4>(x, w6, scale, shift, y, p, grid, st) : launch_x6s<XS_T3, 1, 4>(x, w6, scale, shift, y, p, grid, st);
+  }
+  const int tiles = ((H + 7) / 8) * p.tiles_x;
   const dim3 grid(tiles, D, B * p.co_groups);
   return mode == XS_T4 ? launch_x6s<XS_T4, 1>(x, w6, scale, shift, y, p, grid, st) : launch_x6s<XS_T3, 1>(x, w6, scale, shift, y, p, grid, st);
 }

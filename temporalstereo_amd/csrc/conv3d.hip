@@ -1545,8 +1545,9 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
   int rc;
   // grids under 3/4 of a round of 8-row workgroups (2 per CU): 4-row tiles (ig_conv_x6_kernel, TR); TS_X6_TR=8 | 4 forces one form
   static const long long tr_env = env_ll("TS_X6_TR", 0);
+  static const long long tr4_below = env_ll("TS_X6_TR4_BELOW", 3 * ts::kNumCU / 2);       // measured 384 / 576 / 768 / 1100: 1297 / 1287 / 1286 / 1273 pairs/s with three passes in flight, 934 / 935 / 936 / 942 one at a time
   const long long wgs8 = static_cast<long long>(tiles) * D * B * p.co_groups * p.ksplit;
-  const bool tr4 = dilation == 1 && (tr_env ? tr_env == 4 : wgs8 < 3 * ts::kNumCU / 2);
+  const bool tr4 = dilation == 1 && (tr_env ? tr_env == 4 : wgs8 < tr4_below);
   if (tr4) {
     const dim3 grid4(((H + 3) / 4) * p.tiles_x, D, B * p.co_groups * p.ksplit);
     rc = cb == 2 ? launch_x6<2, 1, 4>(x, w6, scale, shift, y, p, grid4, st) : launch_x6<1, 1, 4>(x, w6, scale, shift, y, p, grid4, st);

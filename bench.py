@@ -759,7 +759,7 @@ def main():
                                   parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth, input_buffer_sets=depth,
                                   weights_and_inputs=("trained checkpoint tests/golden/ckpt_planted.npz on planted-disparity scenes (tests/synth.stereo_sequence)"
                                                       if planted else "random weights, calibrated BatchNorm, smooth-noise features (--random-weights)"),
-                                  conv_arithmetic="fp32 everywhere; stride-1 (1,3,3) layers with Cin >= 16, Cout > 8 form each fp32 product from "
+                                  conv_arithmetic="fp32 everywhere; stride-1 (1,3,3) layers with Cin >= 16, Cout > 8 -- and, on grids of 256+ workgroups, the stride-2 (1,3,3) layers and the 4x4 deconvolutions (x6s) -- form each fp32 product from "
                                                   "six bf16 MFMA products with fp32 accumulation (x6: dropped terms <= 2^-24 of a product, chunks summed apart; measured max "
                                                   "error vs fp64 0.15e-6-0.26e-6 of the output magnitude, the f32-input MFMA kernel 0.3e-6-0.7e-6); "
                                                   "f32_mfma_only = this engine with that switched off"),

@@ -19,6 +19,21 @@ def main(out, mode):
     torch.cuda.set_device(dev)
     pg = PeerGroup()
     res = {}
+    if mode == "missing_peer":
+        # rank 1 never issues the exchange: rank 0's kernel must give up after its bound (no hang), and check() -- which agrees on the
+        # outcome across the ranks -- must raise on BOTH
+        if rank == 0:
+            src = torch.ones(8, device=dev); dst = torch.empty(world, 8, device=dev)
+            pg.all_gather(src, dst)
+        raised = 0
+        try:
+            pg.check()
+        except RuntimeError:
+            raised = 1
+        np.savez(out + ".rank%d.npz" % rank, raised=raised)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     g = torch.Generator().manual_seed(100 + rank)
     for it, n in enumerate([1, 17, 129, 257, 1024, 33, 64, 5, 300, 2]):       # more exchanges than slots: the slots wrap
         src = torch.randn(n, generator=g).to(dev)

@@ -53,3 +53,10 @@ def test_peer_exchange_replayed_from_a_graph(tmp_path):
         for r in ranks:
             assert np.array_equal(r["ggather%d" % k], want)
             assert np.array_equal(r["gsum%d" % k], want[0] + want[1])
+
+
+def test_a_missing_peer_times_out_instead_of_hanging(tmp_path):
+    """One rank never issues its exchange: the other's kernel gives up after its bound (~2 s of wall clock, csrc/peer.hip) and
+    PeerGroup.check() raises on both ranks (the outcome is agreed on through the process group)."""
+    ranks = _run(tmp_path, "missing_peer")
+    assert [int(r["raised"]) for r in ranks] == [1, 1]

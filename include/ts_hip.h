@@ -347,8 +347,15 @@ int ts_peer_alloc(void** region, void* handle64);
 int ts_peer_open(const void* handle64, void** region);
 int ts_peer_close(void* region);
 int ts_peer_free(void* region);
-/* status: 0, or 1 + r when rank r did not answer an exchange within ~2 s (that exchange's results are undefined) */
+/* status: 0, or 1 + r when rank r did not answer an exchange within the bound (that exchange's results and every later one's are
+ * undefined until ts_peer_reset).  ts_peer_status synchronises the stream; ts_peer_status_async (ABI 9) copies the word into PINNED
+ * host memory behind the queued work, to be read once an event recorded after the call has completed. */
 int ts_peer_status(const void* ctx, int* status, void* stream);
+int ts_peer_status_async(const void* ctx, int* host_status, void* stream);
+/* bound of one wait in milliseconds (default 120 000, or TS_PEER_TIMEOUT_MS); returns the previous one; ms <= 0 only queries */
+long long ts_peer_set_timeout_ms(long long ms);
+/* clears this rank's flags / sequence number / err word; every rank calls it, nothing in flight, between two barriers */
+int ts_peer_reset(const void* ctx, void* stream);
 /* dst [world][n] <- every rank's src [n] */
 int ts_peer_all_gather(const void* ctx, const float* src, float* dst, int n, void* stream);
 /* buf [n] <- (sum over the ranks in rank order: bit-identical everywhere) * (*scale, a device scalar, if not NULL) */

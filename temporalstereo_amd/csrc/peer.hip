@@ -15,7 +15,12 @@
 // waits until its own flags[slot][r] == q + 1 for all r (acquire) and reads the records in rank order -- so every rank sums in the
 // same order and gets bit-identical results (a ring all-reduce does not promise that).  A rank cannot finish exchange q + 1 before
 // every peer has posted q + 1, i.e. has finished READING q: with S >= 2 a slot is never overwritten while someone still reads it.
-// The wait is bounded (~2 s of wall clock): a missing peer sets the err word instead of hanging the queue; ts_peer_status reads it.
+// The wait is bounded (ts_peer_set_timeout_ms; default 120 s, TS_PEER_TIMEOUT_MS in the environment -- the order of a collective
+// watchdog: ranks of a real job drift apart by seconds around checkpoints, validation and data-loader stalls, and a rank that
+// merely arrives late must find its peers still waiting): a peer that never comes sets the err word instead of hanging the queue.
+// After that the group is DEAD -- later exchanges do not wait and their results are undefined -- until ts_peer_reset: the host
+// side reads the word every step (ts_peer_status_async, one step late, no synchronisation) and stops training (train.TrainStep).
+#include <cstdlib>
 #include <cstring>
 
 #include "ts_common.hpp"
@@ -40,7 +45,8 @@ __device__ __forceinline__ float* mail_of(void* region) { return reinterpret_cas
 // order) * (scale ? *scale : 1)
 template <int MODE>
 __global__ void __launch_bounds__(256)
-peer_exchange_kernel(const PeerCtx ctx, const float* src, float* dst, int n, const float* __restrict__ scale) {     // MODE 1: src == dst
+peer_exchange_kernel(const PeerCtx ctx, const float* src, float* dst, int n, const float* __restrict__ scale,
+                     unsigned long long timeout_ticks) {     // MODE 1: src == dst
   __shared__ unsigned s_q;
   unsigned* ctl = ctl_of(ctx.region[ctx.rank]);
   if (threadIdx.x == 0) s_q = ctl[0];
@@ -61,7 +67,7 @@ peer_exchange_kernel(const PeerCtx ctx, const float* src, float* dst, int n, con
     const unsigned long long t0 = wall_clock64();                          // 100 MHz
     const bool dead = ctl[1] != 0u;                                        // an earlier exchange timed out: do not wait again (176 per step)
     while (!dead && __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
-      if (wall_clock64() - t0 > 200000000ull) {                             // ~2 s: a peer is not coming
+      if (wall_clock64() - t0 > timeout_ticks) {                            // a peer is not coming
         __hip_atomic_store(ctl + 1, 1u + static_cast<unsigned>(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
@@ -85,6 +91,18 @@ peer_exchange_kernel(const PeerCtx ctx, const float* src, float* dst, int n, con
     }
   }
   if (threadIdx.x == 0) ctl[0] = q + 1u;
+}
+
+// Bound of one wait in ticks of the 100 MHz wall clock.  Process-wide like the chunk cap of the convolutions: a captured graph keeps
+// the value it was captured with.
+unsigned long long g_timeout_ticks = 0;
+unsigned long long timeout_ticks() {
+  if (g_timeout_ticks == 0) {
+    long long ms = 120000;
+    if (const char* e = getenv("TS_PEER_TIMEOUT_MS")) { const long long v = atoll(e); if (v > 0) ms = v; }
+    g_timeout_ticks = static_cast<unsigned long long>(ms) * 100000ull;
+  }
+  return g_timeout_ticks;
 }
 
 int check_ctx(const PeerCtx* c, int n, const char* what) {
@@ -154,12 +172,40 @@ extern "C" int ts_peer_status(const void* ctx, int* status, void* stream) {
   return TS_OK;
 }
 
+// The err word into pinned host memory behind the work queued on `stream` (no synchronisation): the caller reads *host_status once
+// an event recorded after this call has completed -- train.TrainStep does that one step late, every step.
+extern "C" int ts_peer_status_async(const void* ctx, int* host_status, void* stream) {
+  const PeerCtx* c = static_cast<const PeerCtx*>(ctx);
+  TS_REQUIRE_PTR(c); TS_REQUIRE_PTR(host_status);
+  hipError_t e = hipMemcpyAsync(host_status, static_cast<char*>(c->region[c->rank]) + kFlagBytes + sizeof(unsigned), sizeof(int),
+                                hipMemcpyDeviceToHost, ts::as_stream(stream));
+  return e == hipSuccess ? TS_OK : ts::fail(static_cast<int>(e), "peer_status_async: %s", hipGetErrorString(e));
+}
+
+// Bound of one wait, milliseconds (> 0).  Returns the previous bound.
+extern "C" long long ts_peer_set_timeout_ms(long long ms) {
+  const long long old = static_cast<long long>(timeout_ticks() / 100000ull);
+  if (ms > 0) g_timeout_ticks = static_cast<unsigned long long>(ms) * 100000ull;
+  return old;
+}
+
+// Back to the state after ts_peer_alloc: flags, sequence number and err word of THIS rank's mailbox cleared.  Collective by
+// contract: every rank calls it with nothing in flight, between two barriers of the caller's (PeerGroup.reset does that).
+extern "C" int ts_peer_reset(const void* ctx, void* stream) {
+  const PeerCtx* c = static_cast<const PeerCtx*>(ctx);
+  TS_REQUIRE_PTR(c);
+  hipError_t e = hipStreamSynchronize(ts::as_stream(stream));
+  if (e == hipSuccess) e = hipMemset(c->region[c->rank], 0, kFlagBytes + kCtlBytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return e == hipSuccess ? TS_OK : ts::fail(static_cast<int>(e), "peer_reset: %s", hipGetErrorString(e));
+}
+
 // dst [world][n] <- every rank's src [n], rank order
 extern "C" int ts_peer_all_gather(const void* ctx, const float* src, float* dst, int n, void* stream) {
   const PeerCtx* c = static_cast<const PeerCtx*>(ctx);
   if (int rc = check_ctx(c, n, "peer_all_gather")) return rc;
   TS_REQUIRE_PTR(src); TS_REQUIRE_PTR(dst);
-  hipLaunchKernelGGL(peer_exchange_kernel<0>, dim3(1), dim3(256), 0, ts::as_stream(stream), *c, src, dst, n, nullptr);
+  hipLaunchKernelGGL(peer_exchange_kernel<0>, dim3(1), dim3(256), 0, ts::as_stream(stream), *c, src, dst, n, nullptr, timeout_ticks());
   return ts::launched("peer_exchange_kernel");
 }
 
@@ -168,6 +214,6 @@ extern "C" int ts_peer_all_reduce_sum(const void* ctx, float* buf, int n, const 
   const PeerCtx* c = static_cast<const PeerCtx*>(ctx);
   if (int rc = check_ctx(c, n, "peer_all_reduce_sum")) return rc;
   TS_REQUIRE_PTR(buf);
-  hipLaunchKernelGGL(peer_exchange_kernel<1>, dim3(1), dim3(256), 0, ts::as_stream(stream), *c, buf, buf, n, scale);
+  hipLaunchKernelGGL(peer_exchange_kernel<1>, dim3(1), dim3(256), 0, ts::as_stream(stream), *c, buf, buf, n, scale, timeout_ticks());
   return ts::launched("peer_exchange_kernel");
 }

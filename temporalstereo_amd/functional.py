@@ -755,10 +755,11 @@ _BN_FUSED = _os.environ.get("TS_BN_FUSED", "1") != "0"
 _EXCHANGES = [0]            # SyncBatchNorm exchanges issued by this process (forward all_gathers + backward all_reduces; bench.py reports them per step)
 
 
-def _peer_group():
-    """The installed peer-mailbox group (peer.install), or None: torch.distributed collectives."""
+def _peer_group(group, n_floats):
+    """The installed peer-mailbox group (peer.install) when it spans `group` and carries `n_floats` per exchange, else None:
+    torch.distributed collectives (a SyncBatchNorm over a sub-group, or with C >= 512, never goes through the wrong mailboxes)."""
     from . import peer
-    return peer.installed()
+    return peer.for_group(group, n_floats)
 
 
 class _ConvBNAct(torch.autograd.Function):
@@ -823,7 +824,7 @@ class _ConvBNAct(torch.autograd.Function):
                 world = dist.get_world_size(group)
                 pack[2 * C:].copy_(_count_const(n_total, y.device))
                 allp = torch.empty(world * (2 * C + 1), device=y.device, dtype=torch.float32)
-                pg = _peer_group()
+                pg = _peer_group(group, 2 * C + 1)
                 if pg is not None:      # one kernel over the peer-mapped mailboxes (csrc/peer.hip): no communicator launch, capturable
                     pg.all_gather(pack, allp)
                 else:
@@ -869,7 +870,7 @@ class _ConvBNAct(torch.autograd.Function):
         if training and group is not None:
             import torch.distributed as dist
             pack = torch.cat([s1, s2])
-            pg = _peer_group()
+            pg = _peer_group(group, 2 * C)
             if pg is not None:
                 pg.all_reduce_sum(pack, scale=n_total)               # summed in rank order and scaled inside the exchange kernel
             else:

@@ -3,7 +3,10 @@
     pg = PeerGroup()                      # after torch.distributed is initialised, one GPU per rank (or one shared GPU in tests)
     pg.all_gather(src, dst)               # dst [world, n] <- every rank's src [n]       (one kernel, capturable in a hipGraph)
     pg.all_reduce_sum(buf, scale=None)    # buf <- sum over ranks (rank order) * scale
-    pg.check()                            # raises if a peer did not answer an exchange
+    pg.check()                            # raises if a peer did not answer an exchange (synchronises; the ranks agree first)
+    pg.poll()                             # the same question without synchronising: answers for the work queued before the PREVIOUS poll
+    pg.reset()                            # collective: back to the state after construction (after a time-out the group is dead until then)
+    set_timeout_ms(ms)                    # bound of one wait (default 120 s / TS_PEER_TIMEOUT_MS), process-wide
 
 The handles travel through torch.distributed (all_gather of 64 bytes per rank, any backend) ONCE; after that no communicator is
 involved.  Used by functional._ConvBNAct for the SyncBatchNorm statistics when installed with `install()` (train.TrainStep does
@@ -72,19 +75,34 @@ class PeerGroup:
             self._release()
             raise RuntimeError("PeerGroup: the mailboxes could not be mapped on every rank (%s)" % (failure or "another rank failed"))
         self.exchanges = 0                    # issued from this process (eager calls and captures; replays are not counted)
+        self._status = torch.zeros(1, dtype=torch.int32).pin_memory()         # poll(): the err word lands here, one poll late
+        self._status_ev = None
+
+    def _check_args(self, what, *tensors):
+        """float32, contiguous, on this group's device.  CONTRACT (not checkable here): the exchanges of a rank are ordered on the
+        device -- one stream, or streams ordered by events as TrainStep's warm-up / capture / replay are; the device-side sequence
+        counter is read and advanced by every exchange kernel, two concurrent ones would take the same slot."""
+        from .functional import _stream
+        for t in tensors:
+            if t is None:
+                continue
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("PeerGroup.%s: tensors must be contiguous float32 on %s (got %s, %s, contiguous=%s)"
+                                 % (what, self.device, t.dtype, t.device, t.is_contiguous()))
+        return _stream()
 
     def all_gather(self, src, dst):
         n = src.numel()
-        if dst.numel() != n * self.world or src.dtype != torch.float32 or dst.dtype != torch.float32:
+        if dst.numel() != n * self.world:
             raise ValueError("PeerGroup.all_gather: dst must hold world x src floats")
-        from .functional import _stream
-        _lib.check(_lib._real_lib().ts_peer_all_gather(self._ctxp, _lib.ptr(src), _lib.ptr(dst), n, _stream()), "ts_peer_all_gather")
+        st = self._check_args("all_gather", src, dst)
+        _lib.check(_lib._real_lib().ts_peer_all_gather(self._ctxp, _lib.ptr(src), _lib.ptr(dst), n, st), "ts_peer_all_gather")
         self.exchanges += 1
         return dst
 
     def all_reduce_sum(self, buf, scale=None):
-        from .functional import _stream
-        _lib.check(_lib._real_lib().ts_peer_all_reduce_sum(self._ctxp, _lib.ptr(buf), buf.numel(), _lib.ptr(scale), _stream()),
+        st = self._check_args("all_reduce_sum", buf, scale)
+        _lib.check(_lib._real_lib().ts_peer_all_reduce_sum(self._ctxp, _lib.ptr(buf), buf.numel(), _lib.ptr(scale), st),
                    "ts_peer_all_reduce_sum")
         self.exchanges += 1
         return buf
@@ -104,6 +122,34 @@ class PeerGroup:
             raise RuntimeError("PeerGroup: rank %d did not answer an exchange within the bound (are all ranks issuing the same "
                                "sequence of exchanges?)" % (bad - 1))
 
+    def poll(self):
+        """The err word WITHOUT synchronising: queues an asynchronous copy of it behind the work issued so far and returns what the
+        copy queued by the PREVIOUS poll brought back (that one has normally long completed: train.TrainStep polls once per step, so
+        a time-out is noticed one step late and training stops there).  Raises like check(collective=False)."""
+        from .functional import _stream
+        bad = 0
+        if self._status_ev is not None:
+            self._status_ev.synchronize()
+            bad = int(self._status[0])
+        with torch.cuda.device(self.device):
+            _lib.check(_lib._real_lib().ts_peer_status_async(self._ctxp, ctypes.c_void_p(self._status.data_ptr()), _stream()), "ts_peer_status_async")
+            self._status_ev = torch.cuda.Event()
+            self._status_ev.record()
+        if bad:
+            raise RuntimeError("PeerGroup: rank %d did not answer an exchange within the bound; the statistics exchanged since then are "
+                               "undefined -- stop, or PeerGroup.reset() on every rank and restore the last good state" % (bad - 1))
+
+    def reset(self):
+        """Collective: every rank, nothing in flight.  Flags, sequence counter and err word cleared -- the state after construction."""
+        from .functional import _stream
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)                     # nobody clears while a peer may still write
+        with torch.cuda.device(self.device):
+            _lib.check(_lib._real_lib().ts_peer_reset(self._ctxp, _stream()), "ts_peer_reset")
+        self._status_ev = None
+        self._status.zero_()
+        dist.barrier(group=self.group)                     # nobody exchanges before everybody has cleared
+
     def _release(self):
         L = _lib._real_lib()
         for p in self._opened:
@@ -114,20 +160,42 @@ class PeerGroup:
             self._mine = None
 
     def close(self):
+        if self._mine is None and not self._opened:
+            return
         torch.cuda.synchronize(self.device)
         if dist.is_initialized():
             dist.barrier(group=self.group)    # nobody unmaps while a peer may still write
         self._release()
+        if installed() is self:
+            install(None)
+
+
+def set_timeout_ms(ms):
+    """Bound of one wait of an exchange kernel in milliseconds (process-wide; a captured graph keeps the bound it was captured with).
+    Returns the previous bound.  Default 120 000 (TS_PEER_TIMEOUT_MS overrides): ranks of a real job drift apart by seconds."""
+    return int(_lib._real_lib().ts_peer_set_timeout_ms(int(ms)))
 
 
 _INSTALLED = None
 
 
 def install(pg):
-    """Route the SyncBatchNorm exchanges of functional._ConvBNAct through `pg` (None: back to torch.distributed collectives)."""
+    """Route the SyncBatchNorm exchanges of functional._ConvBNAct through `pg` (None: back to torch.distributed collectives).
+    Only exchanges over pg's own process group take it (`for_group`)."""
     global _INSTALLED
     _INSTALLED = pg
 
 
 def installed():
     return _INSTALLED
+
+
+def for_group(group, n_floats):
+    """The installed PeerGroup if it spans exactly `group` (None == the default group) and can carry `n_floats` per exchange; else None
+    (the caller uses torch.distributed)."""
+    pg = _INSTALLED
+    if pg is None or n_floats > pg.max_floats:
+        return None
+    a = pg.group if pg.group is not None else dist.group.WORLD
+    b = group if group is not None else dist.group.WORLD
+    return pg if a is b else None

@@ -193,12 +193,16 @@ class TrainStep:
                                "explicitly" % self.world)
         self.sync_bn = bool(sync_bn) and self.world > 1
         self.peer = None
+        from . import peer as _peer
+        if _peer.installed() is not None:
+            # a PeerGroup left installed by an earlier TrainStep of this process is not this step's: exchanges of a step that
+            # did not ask for the mailboxes go through torch.distributed
+            _peer.install(None)
         if self.sync_bn:
             net = tsd.sync_batchnorm(net)
             if sync_bn == "peer":
-                from . import peer
-                self.peer = peer.PeerGroup()
-                peer.install(self.peer)
+                self.peer = _peer.PeerGroup()
+                _peer.install(self.peer)
         self.net = net
         tsd.broadcast_parameters(net)
         self.l1 = DispSmoothL1Loss(max_disp=max_disp, rescale=True, global_weight=l1_global_weight,
@@ -229,6 +233,23 @@ class TrainStep:
         # (Tried and dropped in round 3: the weight-gradient launches on a forked side stream inside the capture -- they depend only on
         # dy, 15 % of the step's device time, small grids.  The replayed graph got SLOWER, 15.0 vs 13.4 ms: forked captures replay
         # badly on ROCm 7.2, as the inference graph already showed)
+
+    def close(self):
+        """Collective when sync_bn='peer' (a barrier: nobody unmaps a mailbox a peer may still write): uninstalls and releases the
+        peer group.  Idempotent; the step object must not be called afterwards."""
+        pg, self.peer = self.peer, None
+        if pg is not None:
+            from . import peer as _peer
+            if _peer.installed() is pg:
+                _peer.install(None)
+            pg.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _set_training(self, mode):
         """net.train(mode) without nn.Module.__setattr__'s bookkeeping on ~640 modules (2.4 ms of host time per step)."""
@@ -350,6 +371,10 @@ class TrainStep:
             # BatchNorm running statistics are updated inside the statistics kernels (raw pointers; under graph replay no host code
             # runs at all): bump their versions like the in-place framework update would, for everything that stamps (storage, version)
             torch.autograd.graph.increment_version(self._stat_buffers)
+        if self.peer is not None:
+            # a time-out of an exchange leaves garbage statistics behind and kills the group: noticed here one step late (no
+            # synchronisation: the err word is copied behind the queued work and read at the next step), and training stops
+            self.peer.poll()
         t3 = time.perf_counter()
         # host-side issue times (the device runs behind them); the exchange entry includes waiting for the reduced buckets
         self.timings = dict(forward_backward_issue_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3, clip_step_issue_ms=(t3 - t2) * 1e3)

@@ -95,3 +95,26 @@ def check_temporal_update(g, info, tol_mean, tol_far):
         close(info["local_map"], g["out_local_map"], "local_map")
         assert info["local_map_size"] == int(g["local_map_size"])
     assert info["use_past_cost"] == bool(int(g["use_past_cost"]))
+
+
+def multi_rank_env(world, **extra):
+    """Environment of a `world`-rank GPU sub-process launch, chosen by what the box has:
+
+    * >= `world` devices: ONE RANK PER DEVICE on RCCL (backend "nccl", device = LOCAL_RANK) -- so that a `-m gpu` run on a multi-GPU
+      node exercises RCCL over xGMI and the peer mailboxes across a device boundary by itself (the reference's arrangement:
+      pl.Trainer(strategy='ddp'), projects/TemporalStereo/dist_train.py:82-96);
+    * fewer: every rank on device 0 with gloo carrying the collectives (RCCL refuses two ranks on one device): TS_BENCH_BACKEND /
+      TS_BENCH_DEVICE, the hooks bench.py and the workers read.
+
+    Returns (env, arrangement) with arrangement 'one rank per device, nccl' | 'all ranks on device 0, gloo'."""
+    env = dict(os.environ, MIOPEN_FIND_MODE="2", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TS_BENCH_BACKEND", "TS_BENCH_DEVICE"):
+        env.pop(k, None)
+    forced = os.environ.get("TS_TEST_MULTI_RANK", "")            # "one_device" forces the gloo arrangement on a multi-GPU box
+    if torch.cuda.device_count() >= world and forced != "one_device":
+        arrangement = "one rank per device, nccl"
+    else:
+        env.update(TS_BENCH_BACKEND="gloo", TS_BENCH_DEVICE="0")
+        arrangement = "all ranks on device 0, gloo"
+    env.update({k: str(v) for k, v in extra.items()})
+    return env, arrangement

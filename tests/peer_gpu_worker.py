@@ -1,5 +1,6 @@
 """Worker of tests/test_peer_gpu.py (not collected): one rank of a peer-mailbox group (temporalstereo_amd/peer.py) on the GPU.
-Both ranks sit on device 0 of the single-GPU test box (TS_BENCH_DEVICE); the handles travel over gloo."""
+One rank per device over RCCL when the box has the devices, all ranks on device 0 with the handles over gloo otherwise
+(TS_BENCH_BACKEND / TS_BENCH_DEVICE, set by tests/helpers.multi_rank_env)."""
 import os
 import sys
 
@@ -25,12 +26,26 @@ def main(out, mode):
         if rank == 0:
             src = torch.ones(8, device=dev); dst = torch.empty(world, 8, device=dev)
             pg.all_gather(src, dst)
+        polled = 0
+        try:
+            pg.poll()                                   # queues the copy of the err word behind the exchange
+            torch.cuda.synchronize()
+            pg.poll()                                   # ... and this one reads what it brought back
+        except RuntimeError:
+            polled = 1
         raised = 0
         try:
             pg.check()
         except RuntimeError:
             raised = 1
-        np.savez(out + ".rank%d.npz" % rank, raised=raised)
+        # the group is dead until every rank resets it; afterwards an ordinary exchange works again
+        pg.reset()
+        src = torch.full((8,), float(rank + 1), device=dev); dst = torch.empty(world, 8, device=dev)
+        pg.all_gather(src, dst)
+        pg.check()
+        ok = int(bool((dst.cpu() == torch.arange(1, world + 1, dtype=torch.float32).view(-1, 1)).all()))
+        np.savez(out + ".rank%d.npz" % rank, raised=raised, polled=polled, after_reset_ok=ok)
+        pg.close()
         dist.barrier()
         dist.destroy_process_group()
         return

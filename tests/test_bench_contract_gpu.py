@@ -45,15 +45,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 def test_driver_launch_of_eight_ranks():
     """The driver's multi-GPU command, `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
-    --master-port P bench.py --gpus 8 --steps K --warmup W`, end to end on the one-GPU box: eight ranks on device 0 with gloo as
-    the rendezvous / barrier / max-over-ranks backend (RCCL refuses two ranks on one device; TS_BENCH_BACKEND / TS_BENCH_DEVICE are the
-    test hooks).  What this exercises before the first real SCALE run: rendezvous on 127.0.0.1, every rank building its engine, the
+    --master-port P bench.py --gpus 8 --steps K --warmup W`, end to end: on an eight-GPU node exactly as the driver runs it (one rank per device, RCCL);
+    on a smaller box eight ranks on device 0 with gloo as the rendezvous / barrier / max-over-ranks backend (RCCL refuses two ranks
+    on one device; TS_BENCH_BACKEND / TS_BENCH_DEVICE are the test hooks, tests/helpers.multi_rank_env).  What this exercises before the first real SCALE run: rendezvous on 127.0.0.1, every rank building its engine, the
     barrier + synchronize bracket, the MAX over ranks, ONE JSON line from rank 0 with the whole-job value, a clean exit of all ranks."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, TS_BENCH_BACKEND="gloo", TS_BENCH_DEVICE="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
+    from helpers import multi_rank_env
+    env, arrangement = multi_rank_env(8)            # eight devices: the driver's command as it is (RCCL, one rank per GPU); else device 0 + gloo
+    print("arrangement:", arrangement)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--no-extras"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

@@ -1,8 +1,9 @@
 """GPU, two ranks: the data-parallel training step of the real aggregator (SyncBatchNorm between the HIP BatchNorm kernels + bucketed
 gradient all-reduce from backward hooks + fused clip / RMSprop) equals the single-process step on the batch of two.
 Counterpart of the reference's `pl.Trainer(strategy='ddp', sync_batchnorm=True)` (projects/TemporalStereo/dist_train.py:82-96).
-A single-GPU box cannot run RCCL with two ranks (one rank per device), so the collectives go over gloo with both ranks on device 0
-(the test hooks of bench.py: TS_BENCH_BACKEND / TS_BENCH_DEVICE); the multi-GPU RCCL run is the driver's."""
+The arrangement follows the box (tests/helpers.multi_rank_env): with two or more devices the ranks take one device each and the
+collectives are RCCL's (SyncBatchNorm exchanges, bucketed all-reduce and the peer mailboxes then cross xGMI); a single-GPU box cannot
+run RCCL with two ranks, so there both ranks share device 0 and gloo carries the collectives (TS_BENCH_BACKEND / TS_BENCH_DEVICE)."""
 import json
 import os
 import socket
@@ -13,6 +14,8 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import multi_rank_env
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -22,9 +25,8 @@ def _free_port():
 
 
 def _env():
-    env = dict(os.environ, TS_BENCH_BACKEND="gloo", TS_BENCH_DEVICE="0", MIOPEN_FIND_MODE="2")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
+    env, arrangement = multi_rank_env(2)
+    print("arrangement:", arrangement)
     return env
 
 

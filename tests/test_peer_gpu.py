@@ -1,7 +1,8 @@
 """GPU, two ranks: the peer-mailbox exchange of csrc/peer.hip (SyncBatchNorm's statistics exchanges as kernels over hipIpc-mapped
 memory, reference role: torch's SyncBatchNorm under Lightning's sync_batchnorm=True, projects/TemporalStereo/dist_train.py:94).
-Both ranks on device 0 (a single-GPU box), handles over gloo; the mapping, the slot protocol and the graph replay are the
-production path -- what the box cannot show is the xGMI hop between two devices."""
+The arrangement follows the box (tests/helpers.multi_rank_env): with as many devices as ranks every rank takes its own device and
+the handles travel over RCCL -- the mailboxes are then mapped ACROSS devices (hipIpc over xGMI); on a single-GPU box all ranks share
+device 0 and gloo carries the handles (the mapping, the slot protocol and the graph replay are the production path either way)."""
 import os
 import socket
 import subprocess
@@ -9,6 +10,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from helpers import multi_rank_env
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,10 +21,9 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(tmp_path, mode, world=2):
-    env = dict(os.environ, TS_BENCH_BACKEND="gloo", TS_BENCH_DEVICE="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
+def _run(tmp_path, mode, world=2, **extra):
+    env, arrangement = multi_rank_env(world, **extra)
+    print("arrangement:", arrangement)
     out = str(tmp_path / "peer")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "peer_gpu_worker.py"), out, mode]
@@ -56,7 +58,11 @@ def test_peer_exchange_replayed_from_a_graph(tmp_path):
 
 
 def test_a_missing_peer_times_out_instead_of_hanging(tmp_path):
-    """One rank never issues its exchange: the other's kernel gives up after its bound (~2 s of wall clock, csrc/peer.hip) and
-    PeerGroup.check() raises on both ranks (the outcome is agreed on through the process group)."""
-    ranks = _run(tmp_path, "missing_peer")
+    """One rank never issues its exchange: the other's kernel gives up after its bound (set to 2 s here; the default is a
+    watchdog-sized 120 s, csrc/peer.hip) and PeerGroup.check() raises on both ranks (the outcome is agreed on through the process
+    group); poll() -- what TrainStep asks every step, without synchronising -- reports it one poll late; reset() revives the group."""
+    ranks = _run(tmp_path, "missing_peer", TS_PEER_TIMEOUT_MS=2000)
     assert [int(r["raised"]) for r in ranks] == [1, 1]
+    assert int(ranks[0]["polled"]) == 1                   # the rank whose kernel timed out hears of it from poll() as well
+    for r in ranks:
+        assert int(r["after_reset_ok"]) == 1

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r02t
+O=$GRAFT_REPO_ROOT/gpurun_out/${OUT:-r02t}
 rm -rf $O; mkdir -p $O
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/trace -o t -- bash -c "cd $GRAFT_REPO_ROOT && python bench.py --mode ${TRAIN_MODE:-train} --steps ${TRAIN_STEPS:-10} --warmup 3 > $O/bench_train_under_rocprof.json" > $O/trace.log 2>&1)
 T=$(find $O/trace -name "*.db" | head -1)

@@ -122,7 +122,10 @@ int ts_bn_sync_merge(const float* gathered, int world, int C, float* mean, float
                      float* running_var, float momentum, float* inv_count, void* stream);
 /* Single-rank training forms (nothing to exchange between the statistics and their use): statistics + normalise/activate in two
  * launches, backward sums + input gradient in two (each a partial-sums kernel, then one whose workgroups finish their channel's
- * sums themselves in the fixed order of the three-launch forms -- same values).  ts_bn_train_bwd: count = B*N elements. */
+ * sums themselves in the fixed order of the three-launch forms -- same values).  ts_bn_train_bwd: count = B*N elements.
+ * ABI 9: channels of at most ts_bn_set_small_elems() elements (B*N; default below, TS_BN_SMALL_ELEMS) take ONE launch each way -- a
+ * workgroup per channel does both passes (per-thread fp32 partial sums combined in double: the same statistics to rounding). */
+long long ts_bn_set_small_elems(long long n);   /* returns the previous bound; n < 0 only queries */
 int ts_bn_train_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
                     long long* num_batches_tracked, const float* gamma, const float* beta, float* out, void* workspace,
                     int B, int C, long long N, long long x_bstride, long long x_cstride, long long out_bstride,

@@ -85,6 +85,7 @@ SIGNATURES = {
     "ts_peer_close": (c_int, [c_ptr]),
     "ts_peer_free": (c_int, [c_ptr]),
     "ts_peer_status": (c_int, [c_ptr, ctypes.POINTER(c_int), c_ptr]),
+    "ts_bn_set_small_elems": (ctypes.c_longlong, [ctypes.c_longlong]),
     "ts_peer_status_async": (c_int, [c_ptr, c_ptr, c_ptr]),
     "ts_peer_set_timeout_ms": (ctypes.c_longlong, [ctypes.c_longlong]),
     "ts_peer_reset": (c_int, [c_ptr, c_ptr]),
@@ -147,7 +148,7 @@ SIGNATURES = {
 _QUERIES = frozenset(n for n in SIGNATURES if n.endswith("_bytes") or n.startswith("ts_plan_") or
                      n in ("ts_version", "ts_last_error_string", "ts_conv_cout_pad", "ts_conv3d_hw_x6_supported", "ts_conv3d_hw_x6s_supported", "ts_peer_max_floats", "ts_peer_max_ranks",
                            "ts_peer_alloc", "ts_peer_open", "ts_peer_close", "ts_peer_free", "ts_peer_status", "ts_peer_status_async",
-                           "ts_peer_set_timeout_ms", "ts_peer_reset"))
+                           "ts_peer_set_timeout_ms", "ts_peer_reset", "ts_bn_set_small_elems"))
 
 
 def lib():

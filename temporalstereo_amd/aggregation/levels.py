@@ -64,15 +64,23 @@ class _Level(nn.Module):
         """coarse.py:84-105 / fine.py:105-122: append the k memory candidates, sort along D and
         permute the volume accordingly."""
         memory = prev_info.get('cost_memory', None)
+        hip = init_cost.is_cuda and init_cost.dtype == torch.float32
         if memory is None or not prev_info.get('use_past_cost', False):
-            mem_s = torch.zeros_like(disp_sample[:, :self.topk])
-            mem_v = torch.zeros_like(mem_s).unsqueeze(dim=1)
+            if hip:     # shared read-only zeros instead of two fill launches per level and frame
+                mem_s = TF.const_zeros((disp_sample.shape[0], self.topk) + tuple(disp_sample.shape[2:]), disp_sample.device)
+                mem_v = mem_s.unsqueeze(dim=1)
+            else:
+                mem_s = torch.zeros_like(disp_sample[:, :self.topk])
+                mem_v = torch.zeros_like(mem_s).unsqueeze(dim=1)
         else:
             mem_s, mem_v = memory['disp_sample'], memory['cost_volume']
             if resize_to is not None:
                 H, W = resize_to
-                mem_s = F.interpolate(mem_s * W / mem_s.shape[-1], size=(H, W), mode='bilinear', align_corners=True)
-                mem_v = F.interpolate(mem_v, size=(H, W), mode='bilinear', align_corners=True)
+                if hip and mem_s.shape == mem_v.shape:       # both maps in one launch (the value scale inside)
+                    mem_s, mem_v = TF.resize_bilinear_pair(mem_s, mem_v, (H, W), float(W) / mem_s.shape[-1], 1.0)
+                else:
+                    mem_s = F.interpolate(mem_s * W / mem_s.shape[-1], size=(H, W), mode='bilinear', align_corners=True)
+                    mem_v = F.interpolate(mem_v, size=(H, W), mode='bilinear', align_corners=True)
             mem_v = mem_v.unsqueeze(dim=1)
         mem_v = self.past_conv(mem_v)
         disp_sample = torch.cat([disp_sample, mem_s], dim=1)
@@ -102,7 +110,10 @@ class CoarseAggregation(_Level):
     def forward(self, left, right, prev_info: dict):
         B, _, H, W = left.shape
         raw_cost = TF.block_cost(left, right, int(self.num_sample), self.block_cost_scale)
-        disp_sample = torch.arange(self.num_sample, device=left.device, dtype=left.dtype)
+        if left.is_cuda and left.dtype == torch.float32:
+            disp_sample = TF.const_arange(self.num_sample, left.device)
+        else:
+            disp_sample = torch.arange(self.num_sample, device=left.device, dtype=left.dtype)
         disp_sample = disp_sample.view(1, -1, 1, 1).expand(B, self.num_sample, H, W)
         init_cost = self.init3d(raw_cost)
         init_cost, disp_sample = self._merge_memory(init_cost, disp_sample, prev_info, resize_to=(H, W))
@@ -182,6 +193,11 @@ class PreciseAggregation(_Level):
         disp, memory_sample, memory_volume = self.predict_disp(final_cost, disp_sample, off, k=self.topk)
         full_disp = self.refinement.decoder(disp, left, spx2l)
         prev_info['prev_disp'] = full_disp.detach()
+        if memory_sample.is_cuda and memory_sample.dtype == torch.float32:         # precise.py:100-103, both maps in one launch
+            h2, w2 = memory_sample.shape[-2] // 2, memory_sample.shape[-1] // 2      # F.interpolate(scale_factor=1/2): floor
+            ms, mv = TF.resize_bilinear_pair(memory_sample, memory_volume, (h2, w2), 0.5, 1.0)
+            prev_info['cost_memory'] = {'disp_sample': ms, 'cost_volume': mv}
+            return full_disp, disp, final_cost, off, disp_sample, prev_info
         prev_info['cost_memory'] = {                                               # precise.py:100-103
             'disp_sample': F.interpolate(memory_sample / 2, scale_factor=1 / 2, mode='bilinear', align_corners=True),
             'cost_volume': F.interpolate(memory_volume, scale_factor=1 / 2, mode='bilinear', align_corners=True),

@@ -14,6 +14,8 @@
 // HBM-bound element kernels: 16 bytes per lane where the plane length allows it.  Cross-rank statistics
 // (SyncBatchNorm, dist.py) enter between bn_stats and bn_apply_act / between bn_bwd_reduce and bn_bwd_apply as
 // all-reduced [C] vectors: the kernels take mean / var / s1 / s2 / n as arguments.
+#include <cstdlib>
+
 #include "ts_common.hpp"
 
 namespace {
@@ -286,6 +288,153 @@ bn_bwd_finish_apply_kernel(const float* __restrict__ x, const float* __restrict_
     }
 }
 
+// ---- one-launch forms for SMALL layers ------------------------------------------------------------------------------------------
+// Most train-mode layers of the pyramid are small (a channel of the 1/16 ... 1/64 hourglass levels is 405 ... 28,560 elements): their
+// two launches each way are two launch latencies around a few microseconds of traffic.  One workgroup of 1024 threads per channel
+// does both passes itself -- sums (per-thread fp32 partials of x - pivot, combined in double in a fixed order), then the
+// normalisation / input gradient out of L2 -- so such a layer costs ONE launch forward and ONE backward.
+constexpr int kSmallThreads = 1024;
+constexpr long long kSmallElems = 10240;          // per channel (B * N).  Measured (tools/exp/bn_small_bench.py, us per call, one / two launches): N = 405 ... 8160: 6.0-6.7 / 8.8-9.5 forward, 7.3-7.8 / 10.3-10.6 backward; N = 24480: 10.3 / 9.4 and 16.2 / 10.5 (one CU streams the channel twice); 65280: 19.9 / 9.5
+
+__device__ __forceinline__ void block_sum2_double(double& a, double& b) {      // kSmallThreads threads -> every thread
+  __shared__ double sa[kSmallThreads / 64], sb[kSmallThreads / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  double ra = 0.0, rb = 0.0;
+#pragma unroll
+  for (int i = 0; i < kSmallThreads / 64; ++i) { ra += sa[i]; rb += sb[i]; }
+  a = ra;
+  b = rb;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(kSmallThreads)
+bn_train_fwd_small_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ var,
+                          float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                          long long* __restrict__ num_batches_tracked, const float* __restrict__ gamma,
+                          const float* __restrict__ beta, float* __restrict__ out, const BNA p) {
+  const int c = blockIdx.x;
+  const float pivot = x[static_cast<size_t>(c) * p.xc];
+  float s = 0.f, q = 0.f;
+  const long long n4 = VEC ? p.N / 4 : 0;          // VEC: N, the strides and the bases are multiples of 4 elements
+  for (int b = 0; b < p.B; ++b) {
+    const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+    for (long long i = threadIdx.x; i < n4; i += kSmallThreads) {
+      const float4 u = reinterpret_cast<const float4*>(xp)[i];
+      const float v0 = u.x - pivot, v1 = u.y - pivot, v2 = u.z - pivot, v3 = u.w - pivot;
+      s += (v0 + v1) + (v2 + v3);
+      q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+    }
+    for (long long i = 4 * n4 + threadIdx.x; i < p.N; i += kSmallThreads) {
+      const float v = xp[i] - pivot;
+      s += v;
+      q += v * v;
+    }
+  }
+  double ds = s, dq = q;
+  block_sum2_double(ds, dq);
+  const double cnt = static_cast<double>(p.B) * static_cast<double>(p.N);
+  const double m1 = ds / cnt;
+  const double v = fmax(dq / cnt - m1 * m1, 0.0);
+  const float m = static_cast<float>(m1 + static_cast<double>(pivot));
+  const float vf = static_cast<float>(v);
+  if (threadIdx.x == 0) {
+    mean[c] = m;
+    var[c] = vf;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      const double unb = cnt > 1.0 ? v * cnt / (cnt - 1.0) : v;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * static_cast<float>(unb);
+    }
+    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+  }
+  const float is = rsqrtf(vf + p.eps);
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const float sc = is * g, sh = be - m * sc;
+  for (int b = 0; b < p.B; ++b) {
+    const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+    float* op = out + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
+    for (long long i = threadIdx.x; i < n4; i += kSmallThreads) {
+      const float4 u = reinterpret_cast<const float4*>(xp)[i];
+      reinterpret_cast<float4*>(op)[i] = make_float4(act_fwd(u.x * sc + sh, p.act), act_fwd(u.y * sc + sh, p.act),
+                                                      act_fwd(u.z * sc + sh, p.act), act_fwd(u.w * sc + sh, p.act));
+    }
+    for (long long i = 4 * n4 + threadIdx.x; i < p.N; i += kSmallThreads) op[i] = act_fwd(xp[i] * sc + sh, p.act);
+  }
+}
+
+// p.xb / p.xc: strides of x AND of dx;  p.ob / p.oc: strides of dy
+template <bool VEC>
+__global__ void __launch_bounds__(kSmallThreads)
+bn_train_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                          const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                          float* __restrict__ s1o, float* __restrict__ s2o, float* __restrict__ dx, const BNA p) {
+  const int c = blockIdx.x;
+  const float m = mean[c], is = rsqrtf(var[c] + p.eps);
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  float a = 0.f, bsum = 0.f;
+  const long long n4 = VEC ? p.N / 4 : 0;
+  auto term = [&](float xv, float gv, float& dz, float& xh) {
+    xh = (xv - m) * is;
+    dz = gv * act_grad(xh * g + be, p.act);
+  };
+  for (int b = 0; b < p.B; ++b) {
+    const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+    const float* gp = dy + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
+    for (long long i = threadIdx.x; i < n4; i += kSmallThreads) {
+      const float4 u = reinterpret_cast<const float4*>(xp)[i], w = reinterpret_cast<const float4*>(gp)[i];
+      float d0, d1, d2, d3, h0, h1, h2, h3;
+      term(u.x, w.x, d0, h0); term(u.y, w.y, d1, h1); term(u.z, w.z, d2, h2); term(u.w, w.w, d3, h3);
+      a += (d0 + d1) + (d2 + d3);
+      bsum += (d0 * h0 + d1 * h1) + (d2 * h2 + d3 * h3);
+    }
+    for (long long i = 4 * n4 + threadIdx.x; i < p.N; i += kSmallThreads) {
+      float dz, xh;
+      term(xp[i], gp[i], dz, xh);
+      a += dz;
+      bsum += dz * xh;
+    }
+  }
+  double da = a, db = bsum;
+  block_sum2_double(da, db);
+  const float s1 = static_cast<float>(da), s2 = static_cast<float>(db);
+  if (threadIdx.x == 0) { s1o[c] = s1; s2o[c] = s2; }
+  const float a1 = s1 * p.inv_n, a2 = s2 * p.inv_n;
+  for (int b = 0; b < p.B; ++b) {
+    const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+    const float* gp = dy + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
+    float* op = dx + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
+    for (long long i = threadIdx.x; i < n4; i += kSmallThreads) {
+      const float4 u = reinterpret_cast<const float4*>(xp)[i], w = reinterpret_cast<const float4*>(gp)[i];
+      float d0, d1, d2, d3, h0, h1, h2, h3;
+      term(u.x, w.x, d0, h0); term(u.y, w.y, d1, h1); term(u.z, w.z, d2, h2); term(u.w, w.w, d3, h3);
+      reinterpret_cast<float4*>(op)[i] = make_float4((d0 - a1 - h0 * a2) * is * g, (d1 - a1 - h1 * a2) * is * g,
+                                                      (d2 - a1 - h2 * a2) * is * g, (d3 - a1 - h3 * a2) * is * g);
+    }
+    for (long long i = 4 * n4 + threadIdx.x; i < p.N; i += kSmallThreads) {
+      float dz, xh;
+      term(xp[i], gp[i], dz, xh);
+      op[i] = (dz - a1 - xh * a2) * is * g;
+    }
+  }
+}
+
+long long g_bn_small_elems = -1;
+bool bn_vec(const void* a, const void* b, const void* c, long long N, long long s0, long long s1, long long s2, long long s3) {
+  return N % 4 == 0 && s0 % 4 == 0 && s1 % 4 == 0 && s2 % 4 == 0 && s3 % 4 == 0 && ts::aligned16(a) && ts::aligned16(b) && (!c || ts::aligned16(c));
+}
+
+bool bn_small(int B, long long N) {
+  if (g_bn_small_elems < 0) { const char* e = getenv("TS_BN_SMALL_ELEMS"); g_bn_small_elems = e ? atoll(e) : kSmallElems; }
+  return static_cast<long long>(B) * N <= g_bn_small_elems;
+}
+
 int chunks_for(long long N, int B, int C, long long& chunk) {
   // enough workgroups to fill the chip (C * B * nchunk >= ~1024) without making chunks shorter than 1024 elements
   int n = static_cast<int>((1024 + static_cast<long long>(B) * C - 1) / (static_cast<long long>(B) * C));
@@ -297,6 +446,14 @@ int chunks_for(long long N, int B, int C, long long& chunk) {
 }
 
 }  // namespace
+
+// experiments: the size (B * N elements per channel) up to which ts_bn_train_{fwd,bwd} take their one-launch form; < 0 only queries
+extern "C" long long ts_bn_set_small_elems(long long n) {
+  (void)bn_small(1, 1);
+  const long long old = g_bn_small_elems;
+  if (n >= 0) g_bn_small_elems = n;
+  return old;
+}
 
 extern "C" size_t ts_bn_workspace_bytes(int B, int C, long long N) {
   if (B <= 0 || C <= 0 || N <= 0) return 0;
@@ -409,6 +566,16 @@ extern "C" int ts_bn_train_fwd(const float* x, float* mean, float* var, float* r
   TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535, TS_ERR_SHAPE, "bn_train_fwd: bad size");
   TS_REQUIRE(act >= 0 && act <= 2, TS_ERR_UNSUPPORTED, "bn_train_fwd: activation %d", act);
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(out); TS_REQUIRE_PTR(workspace);
+  if (bn_small(B, N)) {             // one launch: a workgroup per channel does the sums and the normalisation
+    const BNA a{B, C, N, x_bstride, x_cstride, out_bstride, out_cstride, act, 1, eps, 0.f};
+    if (bn_vec(x, out, nullptr, N, x_bstride, x_cstride, out_bstride, out_cstride))
+      hipLaunchKernelGGL(bn_train_fwd_small_kernel<true>, dim3(C), dim3(kSmallThreads), 0, ts::as_stream(stream), x, mean, var, running_mean,
+                         running_var, momentum, num_batches_tracked, gamma, beta, out, a);
+    else
+      hipLaunchKernelGGL(bn_train_fwd_small_kernel<false>, dim3(C), dim3(kSmallThreads), 0, ts::as_stream(stream), x, mean, var, running_mean,
+                         running_var, momentum, num_batches_tracked, gamma, beta, out, a);
+    return ts::launched("bn_train_fwd_small_kernel");
+  }
   BN p{B, C, N, x_bstride, x_cstride, 0, 0};
   p.nchunk = chunks_for(N, B, C, p.chunk);
   float2* partial = reinterpret_cast<float2*>(workspace);
@@ -431,6 +598,15 @@ extern "C" int ts_bn_train_bwd(const float* x, const float* dy, const float* mea
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(dy); TS_REQUIRE_PTR(mean); TS_REQUIRE_PTR(var); TS_REQUIRE_PTR(sum_dz);
   TS_REQUIRE_PTR(sum_dz_xhat); TS_REQUIRE_PTR(dx); TS_REQUIRE_PTR(workspace);
   const BNA p{B, C, N, x_bstride, x_cstride, dy_bstride, dy_cstride, act, 1, eps, 1.f / count};
+  if (bn_small(B, N)) {
+    if (bn_vec(x, dy, dx, N, x_bstride, x_cstride, dy_bstride, dy_cstride))
+      hipLaunchKernelGGL(bn_train_bwd_small_kernel<true>, dim3(C), dim3(kSmallThreads), 0, ts::as_stream(stream), x, dy, mean, var, gamma,
+                         beta, sum_dz, sum_dz_xhat, dx, p);
+    else
+      hipLaunchKernelGGL(bn_train_bwd_small_kernel<false>, dim3(C), dim3(kSmallThreads), 0, ts::as_stream(stream), x, dy, mean, var, gamma,
+                         beta, sum_dz, sum_dz_xhat, dx, p);
+    return ts::launched("bn_train_bwd_small_kernel");
+  }
   long long chunk;
   const int n = chunks_for(N, B, C, chunk);
   float2* partial = reinterpret_cast<float2*>(workspace);

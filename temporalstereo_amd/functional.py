@@ -543,19 +543,21 @@ def _d_backward(x, weight, dy, geom, need_x, need_w):
 
 
 class _Conv3dD(torch.autograd.Function):
-    """Raw Conv3d (k,1,1) / ConvTranspose3d (3,1,1) stride 2, padding 1, output_padding 1 along D."""
+    """Raw Conv3d (k,1,1) / ConvTranspose3d (3,1,1) stride 2, padding 1, output_padding 1 along D (+ bias in the kernel's epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, dilation, padding, transposed):
-        x, y, ctx.geom = _d_forward(x, weight, stride, dilation, padding, transposed)
+    def forward(ctx, x, weight, stride, dilation, padding, transposed, bias=None):
+        x, y, ctx.geom = _d_forward(x, weight, stride, dilation, padding, transposed, bias)
         ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx, dw = _d_backward(x, weight, dy, ctx.geom, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return dx, dw, None, None, None, None
+        gb = dy.sum(dim=(0, 2, 3, 4)) if (ctx.has_bias and ctx.needs_input_grad[6]) else None
+        return dx, dw, None, None, None, None, gb
 
 
 _ONES = {}
@@ -954,7 +956,7 @@ def conv3d(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(
     if kind == "hw":
         y = _Conv3dHW.apply(x, weight, stride[1], dilation[1], False)
     elif kind == "d":
-        y = _Conv3dD.apply(x, weight, stride[0], dilation[0], padding[0], False)
+        return _Conv3dD.apply(x, weight, stride[0], dilation[0], padding[0], False, bias)       # bias in the epilogue
     else:
         raise NotImplementedError("conv3d: kernel %s stride %s padding %s dilation %s has no HIP kernel"
                                   % (tuple(weight.shape[2:]), stride, padding, dilation))
@@ -967,7 +969,7 @@ def conv_transpose3d(x, weight, bias=None, stride=(1, 2, 2), padding=(0, 1, 1), 
     if kind == "hw":
         y = _Conv3dHW.apply(x, weight, 2, 1, True)
     elif kind == "d":
-        y = _Conv3dD.apply(x, weight, 2, 1, 1, True)
+        y = _Conv3dD.apply(x, weight, 2, 1, 1, True, None)
     else:
         raise NotImplementedError("conv_transpose3d: kernel %s stride %s padding %s output_padding %s has no HIP kernel"
                                   % (tuple(weight.shape[2:]), stride, padding, output_padding))
@@ -1282,6 +1284,95 @@ def unet_upsample(logits, disp):
     return _UNetUpsample.apply(logits, disp)
 
 
+class _ResizePair(torch.autograd.Function):
+    """(F.interpolate(x0 * s0, size), F.interpolate(x1 * s1, size)), bilinear, align_corners=True, in one launch
+    (ts_resize_bilinear_pair_fwd): the top-k memory's candidates and costs (precise.py:100-103, coarse.py:91-96).  The memory is
+    temporal state -- nothing in a training step differentiates it -- so the backward (the framework's own adjoint, recomputed)
+    exists for completeness."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, H, W, s0, s1):
+        _require_gpu(x0, x1)
+        a, b = _lib.contiguous(x0), _lib.contiguous(x1)
+        if a.shape != b.shape or a.dim() != 4:
+            raise ValueError("resize_bilinear_pair: two [B,C,h,w] maps of one shape")
+        B, C, h, w = a.shape
+        o0 = torch.empty((B, C, H, W), device=a.device, dtype=torch.float32)
+        o1 = torch.empty_like(o0)
+        _lib.check(_lib.lib().ts_resize_bilinear_pair_fwd(_lib.ptr(a), _lib.ptr(b), _lib.ptr(o0), _lib.ptr(o1), B, C, h, w, H, W,
+                                                          float(s0), float(s1), _stream()), "ts_resize_bilinear_pair_fwd")
+        ctx.meta = (tuple(a.shape), H, W, float(s0), float(s1))
+        ctx.set_materialize_grads(False)
+        return o0, o1
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        shape, H, W, s0, s1 = ctx.meta
+        outs = []
+        for g, sc in ((g0, s0), (g1, s1)):
+            if g is None:
+                outs.append(None)
+                continue
+            with torch.enable_grad():
+                x = torch.zeros(shape, device=g.device, dtype=g.dtype, requires_grad=True)
+                y = torch.nn.functional.interpolate(x * sc, size=(H, W), mode="bilinear", align_corners=True)
+            outs.append(torch.autograd.grad(y, x, g)[0])
+        return outs[0], outs[1], None, None, None, None
+
+
+def resize_bilinear_pair(x0, x1, size, scale0=1.0, scale1=1.0):
+    return _ResizePair.apply(x0, x1, int(size[0]), int(size[1]), float(scale0), float(scale1))
+
+
+_CONST = {}
+
+
+def const_zeros(shape, device):
+    """A shared all-zero tensor (READ-ONLY by contract: the absent cost memory of a first frame) instead of a fill launch per call."""
+    key = ("z", tuple(shape), device)
+    if key not in _CONST:
+        if torch.cuda.is_current_stream_capturing():       # a capture's allocations belong to its pool: nothing of them is kept
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        _CONST[key] = torch.zeros(shape, device=device, dtype=torch.float32)
+    return _CONST[key]
+
+
+def const_arange(n, device):
+    key = ("a", int(n), device)
+    if key not in _CONST:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.arange(n, device=device, dtype=torch.float32)
+        _CONST[key] = torch.arange(n, device=device, dtype=torch.float32)
+    return _CONST[key]
+
+
+class _WeightedTotal(torch.autograd.Function):
+    """sum_i w_i * term_i of 0-d loss terms: one stack + one dot product forward, one multiplication backward (the framework's
+    form -- a multiplication per term each way, a stack and a sum -- was ~25 one-element launches per training step)."""
+
+    @staticmethod
+    def forward(ctx, wvec, *terms):
+        ctx.save_for_backward(wvec)
+        return torch.dot(torch.stack([t.reshape(()) for t in terms]), wvec)
+
+    @staticmethod
+    def backward(ctx, g):
+        (wvec,) = ctx.saved_tensors
+        gv = wvec * g
+        return (None,) + tuple(gv.unbind(0))
+
+
+_WVEC = {}
+
+
+def weighted_total(terms, weights):
+    """sum_i weights[i] * terms[i] (0-d tensors; weights: python floats)."""
+    key = (tuple(float(w) for w in weights), terms[0].device)
+    if key not in _WVEC:
+        _WVEC[key] = torch.tensor(key[0], device=terms[0].device, dtype=torch.float32)
+    return _WeightedTotal.apply(_WVEC[key], *terms)
+
+
 # --------------------------------------------------------------------------------------------- K4
 class _TopkSoftArgmax(torch.autograd.Function):
     """K4a.  ts_topk_softargmax_{fwd,bwd}; returns (disp, topk_disp, topk_cost)."""
@@ -1303,7 +1394,8 @@ class _TopkSoftArgmax(torch.autograd.Function):
         _lib.check(rc, "ts_topk_softargmax_fwd")
         ctx.save_for_backward(tdisp, tcost, tidx, disp)
         ctx.meta = (B, D, H, W, int(k))
-        return disp, tdisp, tcost
+        ctx.set_materialize_grads(False)         # unused outputs (the top-k planes when nothing differentiates the memory) arrive as None,
+        return disp, tdisp, tcost                # which the kernel takes as NULL: no zero-fill launches
 
     @staticmethod
     def backward(ctx, g_disp, g_tdisp, g_tcost):

@@ -155,6 +155,18 @@ class Conv3d(nn.Conv3d, _NormAct):
         super().__init__(*args, **kwargs)
         self.norm, self.activation = norm, act
 
+    def forward_then(self, x, activation):
+        """forward(x) followed by `activation` ('SiLU' | 'ReLU') for a wrapper that has none of its own -- on the HIP path inside the
+        same conv -> BatchNorm -> activation node (ResidualBlock3D applies F.silu to conv4's output, module.py:276)."""
+        if _hip_conv(x) and self.activation is None:
+            from . import functional as TF
+            kind = TF.conv3d_supported(tuple(self.weight.shape), self.stride, self.padding, self.dilation, self.groups)
+            if kind and self._fusable() is None:
+                geom = (self.stride[1], self.dilation[1], False) if kind == "hw" else (self.stride[0], self.dilation[0], self.padding[0], False)
+                return TF.conv_bn_act(x, self._parameters["weight"], self._parameters["bias"], self._modules["norm"], activation, kind, geom)
+        y = self.forward(x)
+        return F.silu(y) if activation == "SiLU" else F.relu(y)
+
     def forward(self, x):
         if _hip_conv(x):
             from . import functional as TF

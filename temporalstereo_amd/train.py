@@ -278,10 +278,21 @@ class TrainStep:
             cur = frames[-1]
             state = {k: v for k, v in info.items() if k in ("cost_memory", "use_past_cost", "local_map", "local_map_size") and v is not None}
             disps, costs, samples, offs, _, _ = net(cur[0], cur[1], cur[2], cur[3], state)
-            losses = {}
-            losses.update(self.l1(disps, gt))
-            losses.update(self.wars(costs, offs, samples, gt))
-            total = torch.stack(list(losses.values())).sum()        # (one cat + one reduction instead of six additions, each way)
+            if disps[0].is_cuda:
+                # the loss objects' terms (losses.py: same kernels, same weights) combined by ONE weighted sum instead of a
+                # multiplication per term each way, a stack and a sum: weights[i] * global_weight multiplied on the host
+                l1w = self.l1.weights if self.l1.weights is not None else [1.0] * len(disps)
+                ww = self.wars.weights if self.wars.weights is not None else [1.0] * len(costs)
+                terms = [self.l1.loss_per_level(d, gt) for d in disps] + \
+                        [self.wars.loss_per_level(c, o, s, gt) for c, o, s in zip(costs, offs, samples)]
+                weights = [float(w) * float(self.l1.global_weight) for w in l1w[:len(disps)]] + \
+                          [float(w) * float(self.wars.global_weight) for w in ww[:len(costs)]]
+                total = TF.weighted_total(terms, weights)
+            else:
+                losses = {}
+                losses.update(self.l1(disps, gt))
+                losses.update(self.wars(costs, offs, samples, gt))
+                total = torch.stack(list(losses.values())).sum()
             total.backward()
         return total.detach()
 

@@ -228,9 +228,10 @@ def test_batchnorm_two_launch_form_equals_the_three_launch_form(monkeypatch):
     ts_bn_act_bwd_reduce / _apply.  Same partials, same fixed summation order: outputs, gradients and running statistics must be
     identical to the bit."""
     import copy
-    from temporalstereo_amd import functional as TF, layers
+    from temporalstereo_amd import functional as TF, layers, _lib
     dev = torch.device("cuda:0")
     res = {}
+    old = _lib.lib().ts_bn_set_small_elems(0)           # (this layer is small enough for the one-launch form, tested below)
     for fused in (True, False):
         monkeypatch.setattr(TF, "_BN_FUSED", fused)
         torch.manual_seed(3)
@@ -240,6 +241,48 @@ def test_batchnorm_two_launch_form_equals_the_three_launch_form(monkeypatch):
         y.backward(torch.from_numpy(synth.normal(92, "g", tuple(y.shape))).to(dev))
         res[fused] = [y.detach(), x.grad, m.weight.grad, m.norm.weight.grad, m.norm.bias.grad, m.norm.running_mean.clone(),
                       m.norm.running_var.clone(), m.norm.num_batches_tracked.clone()]
+    _lib.lib().ts_bn_set_small_elems(old)
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
     assert int(res[True][-1]) == 1
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 3, 21, 36), (1, 24, 2, 17, 30), (1, 8, 1, 9, 15), (3, 5, 1, 7, 11)])
+def test_batchnorm_one_launch_form_for_small_layers(shape):
+    """Channels of at most ts_bn_set_small_elems() elements take ONE launch each way (a workgroup per channel: sums, then the
+    normalisation / input gradient): against the two-launch form to rounding, and against float64 framework ops like the fused node
+    itself (reference behaviour: conv -> nn.BatchNorm3d -> SiLU in train mode, layers/basic_layers.py:194-235)."""
+    from temporalstereo_amd import layers, _lib
+    dev = torch.device("cuda:0")
+    B, C, D, H, W = shape
+    res = {}
+    L = _lib.lib()
+    old = L.ts_bn_set_small_elems(-1)
+    assert B * D * H * W <= old, "default bound moved: pick smaller shapes"
+    try:
+        for cap in (old, 0):
+            L.ts_bn_set_small_elems(cap)
+            torch.manual_seed(5)
+            m = layers.Conv3d(C, C + 3, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), bias=False, norm=("BN3d", C + 3), activation="SiLU").to(dev).train()
+            with torch.no_grad():
+                m.norm.weight.uniform_(0.5, 1.5); m.norm.bias.normal_(0, 0.3)
+            x = torch.from_numpy(synth.normal(191, "x", shape)).to(dev).requires_grad_(True)
+            y = m(x)
+            y.backward(torch.from_numpy(synth.normal(192, "g", tuple(y.shape))).to(dev))
+            res[cap] = [y.detach(), x.grad, m.weight.grad, m.norm.weight.grad, m.norm.bias.grad, m.norm.running_mean.clone(), m.norm.running_var.clone()]
+            last = m
+    finally:
+        L.ts_bn_set_small_elems(old)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max()) / (float(b.double().abs().max()) + 1e-12)
+    for a, b in zip(res[old], res[0]):
+        assert rel(a, b) < 2e-6
+    # float64 framework ops on the same weights
+    ref = torch.nn.Sequential(torch.nn.Conv3d(C, C + 3, (1, 3, 3), 1, (0, 1, 1), bias=False), torch.nn.BatchNorm3d(C + 3), torch.nn.SiLU()).double().to(dev).train()
+    with torch.no_grad():
+        ref[0].weight.copy_(last.weight.double()); ref[1].weight.copy_(last.norm.weight.double()); ref[1].bias.copy_(last.norm.bias.double())
+    xd = torch.from_numpy(synth.normal(191, "x", shape)).to(dev).double().requires_grad_(True)
+    yd = ref(xd)
+    yd.backward(torch.from_numpy(synth.normal(192, "g", tuple(yd.shape))).to(dev).double())
+    want = [yd.detach(), xd.grad, ref[0].weight.grad, ref[1].weight.grad, ref[1].bias.grad]
+    for a, b in zip(res[old][:5], want):
+        assert rel(a, b) < 2e-5

@@ -26,7 +26,7 @@ def test_product_never_imports_oracle_or_reference():
 
 
 def test_runtime_files_do_not_read_reference():
-    for rel in ("bench.py", "__graft_entry__.py"):
+    for rel in ("bench.py", "__graft_entry__.py", "benchlegs/common.py", "benchlegs/k1.py", "benchlegs/extras.py", "benchlegs/training.py"):
         assert "/root/reference" not in open(os.path.join(ROOT, rel)).read()
     for path in _sources(os.path.join(ROOT, "tests"), (".py",)):
         if os.path.basename(path) == "test_layout.py":

@@ -218,6 +218,35 @@ def _native_sequence(case):
     return outs, info
 
 
+def _timed_form_sequence(case):
+    """The same frames through the forms bench.py TIMES: single-frame configurations through
+    InferenceEngine(pipeline=3, inputs='bind') -- four calls on the bound tensors, i.e. all three buffer sets of the pipeline and the
+    first one again, every call's output checked --; temporal configurations through the two-phase begin / finish schedule of
+    tools/sequence_bench.py (frame t+1's state-independent half issued before frame t's state update).
+    -> list over frames of lists of (full, quarter) maps (one entry per call of that frame)."""
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    frames = case.c["frames"]
+    if frames == 1:
+        eng = InferenceEngine(case.net, backend="native", replay="plan", inputs="bind", pipeline=3)
+        outs = []
+        for _ in range(4):
+            on = eng(*case.frames_gpu[0], {})
+            outs.append((on[0][0].detach().clone(), on[0][1].detach().clone()))
+        torch.cuda.synchronize()
+        return [outs], _clone_info(on[5])
+    eng = InferenceEngine(case.net, backend="native", replay="plan", inputs="bind")
+    on = eng.finish(eng.begin(*case.frames_gpu[0]), {})
+    info = _clone_info(on[5])
+    outs = [[(on[0][0].detach().clone(), on[0][1].detach().clone())]]
+    for t in range(1, frames):
+        h = eng.begin(*case.frames_gpu[t])                 # before the state update of frame t-1, as the timed schedule issues it
+        info = case.native_update(t, info)
+        on = eng.finish(h, dict(info))
+        info = _clone_info(on[5])
+        outs.append([(on[0][0].detach().clone(), on[0][1].detach().clone())])
+    return outs, info
+
+
 _PLANTED = ("planted_c1_s0", "planted_c1_s1", "planted_c1_s2", "planted_c2_s0", "planted_c3_s0", "planted_c4_s0",
             "planted_c2_s1", "planted_c3_s1", "planted_c4_s1")
 
@@ -259,6 +288,44 @@ def test_end_to_end_against_reference_fixtures_every_frame(fixture):
         assert float(dm.mean()) < 1e-3
     finally:
         rep.dump("parity_end_to_end_planted.json")
+
+
+@pytest.mark.parametrize("fixture", _PLANTED)
+def test_end_to_end_fixtures_through_the_forms_bench_times(fixture):
+    """The nine reference-made fixtures once more, through what bench.py reports: the three-deep pipelined engine on bound inputs
+    (its `value`) for the single-frame configurations, the two-phase begin / finish schedule (its `sequence` object) for the
+    temporal ones.  Same bars as the plain engine above: |dEPE| < 1e-3 px per frame, mean |d| < 1e-3 px."""
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture + ".npz"))
+    name = str(g["config"])
+    c = PT.CONFIGS[name]
+    dev = torch.device("cuda:0")
+    case = PT.PlantedCase(c, int(g["seed"]), dev)
+    for t in range(c["frames"]):
+        assert abs(case.input_checksum[t] - float(g["input_checksum_%d" % t])) <= 1e-9 * abs(float(g["input_checksum_%d" % t]))
+    outs, info = _timed_form_sequence(case)
+    plain, _ = _native_sequence(case)
+    rep = PT.Report()
+    sub = int(g["sub"])
+    try:
+        for t, calls in enumerate(outs):
+            ref = torch.from_numpy(g["disp_full_sub_%d" % t]).double()
+            for k, (full, quarter) in enumerate(calls):
+                e = PT.epe(full, case.gt[t], case.max_disp)
+                d = (full[:, :, ::sub, ::sub].cpu().double() - ref).abs()
+                same = bool(torch.equal(full, plain[t][0]))
+                rep.add(what="timed form vs reference fixture", fixture=fixture, config=name, frame=t, call=k, epe=e,
+                        epe_reference=float(g["epe_%d" % t]), delta_epe=abs(e - float(g["epe_%d" % t])), mean_abs=float(d.mean()),
+                        max_abs=float(d.max()), bit_identical_to_plain_engine=same)
+                assert abs(e - float(g["epe_%d" % t])) < 1e-3, "%s frame %d call %d: EPE %.6f vs %.6f" % (fixture, t, k, e, float(g["epe_%d" % t]))
+                assert float(d.mean()) < 1e-3
+                assert float((d > 0.05).double().mean()) < (1e-3 if t else 1e-5)
+                if c["frames"] == 1:
+                    assert same, "the pipelined engine's output differs from the plain engine's on the same inputs"
+        dm = (info["cost_memory"]["disp_sample"].cpu().double() - torch.from_numpy(g["mem_out_disp_sample"]).double()).abs()
+        assert float(dm.mean()) < 1e-3
+    finally:
+        rep.dump("parity_end_to_end_timed_forms.json")
 
 
 # seeds per configuration for the oracle-side sweep (the oracle is a CPU pass per frame: configs[3] is 32 of them per seed)

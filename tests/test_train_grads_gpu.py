@@ -35,10 +35,14 @@ def _check(cond, msg):
         assert cond, msg
 
 
-def test_whole_aggregator_gradients_match_the_reference_autograd():
+@pytest.mark.parametrize("fixture", ["planted_train_grads", "planted_train_grads_c1"])
+def test_whole_aggregator_gradients_match_the_reference_autograd(fixture):
+    """planted_train_grads: 128x192, B=2, element by element; planted_train_grads_c1 (round 5): BASELINE configs[1]'s own size,
+    544x960, D=192, B=1 -- the reference's train-mode forward + backward run there on the CPU, stored as loss terms, norms and
+    seeded projections of every gradient (tools/gen_golden.py --only-planted-grads-c1)."""
     import bench
     from temporalstereo_amd.losses import DispSmoothL1Loss, WarssersteinDistanceLoss
-    g = load("planted_train_grads")
+    g = load(fixture)
     dev = torch.device("cuda:0")
     B, H, W, ns, max_disp, seed = (int(g[k]) for k in ("B", "H", "W", "num_sample", "max_disp", "seed"))
     net = bench.build_model(dev, seed, ns)
@@ -70,10 +74,17 @@ def test_whole_aggregator_gradients_match_the_reference_autograd():
         for i in range(3):
             for side, ts in (("left", lf), ("right", rf)):
                 gr = ts[i].grad
-                rmax, rl2, bad = _rel(gr[:, ::8], torch.from_numpy(g["g_%s_%d" % (side, i)]))
-                rn = abs(float(gr.double().norm()) - float(g["g_%s_%d_norm" % (side, i)])) / float(g["g_%s_%d_norm" % (side, i)])
-                rep.add(what="feature gradient", key="%s_%d" % (side, i), rel_max=rmax, rel_l2=rl2, frac_off=bad, rel_norm=rn)
-                _check(rl2 < 1e-3 and bad < 1e-3 and rn < 1e-3, ("feature gradient", side, i, rmax, rl2, bad, rn))
+                n_ref = float(g["g_%s_%d_norm" % (side, i)])
+                rn = abs(float(gr.double().norm()) - n_ref) / n_ref
+                if "g_%s_%d" % (side, i) in g:
+                    rmax, rl2, bad = _rel(gr[:, ::8], torch.from_numpy(g["g_%s_%d" % (side, i)]))
+                    rep.add(what="feature gradient", key="%s_%d" % (side, i), rel_max=rmax, rel_l2=rl2, frac_off=bad, rel_norm=rn)
+                    _check(rl2 < 1e-3 and bad < 1e-3 and rn < 1e-3, ("feature gradient", side, i, rmax, rl2, bad, rn))
+                else:       # full size: norm and a seeded projection (scale of a projection = the gradient's norm)
+                    pr = torch.from_numpy(synth.normal(seed, "projf%s%d" % (side, i), tuple(gr.shape))).double()
+                    rp = abs(float((gr.double().cpu() * pr).sum()) - float(g["g_%s_%d_proj" % (side, i)])) / n_ref
+                    rep.add(what="feature gradient (norm / projection)", key="%s_%d" % (side, i), rel_norm=rn, rel_proj=rp)
+                    _check(rn < 1e-3 and rp < 1e-3, ("feature gradient", side, i, rn, rp))
         named = dict(net.named_parameters())
         top = float(g["f64::all_norm"].max())
         exactly_zero = {str(k) for k, n64 in zip(g["all_keys"], g["f64::all_norm"]) if n64 < 1e-10 * top}     # decided in float64
@@ -88,16 +99,25 @@ def test_whole_aggregator_gradients_match_the_reference_autograd():
         assert sorted(k for k in named if named[k].grad is not None) == keys          # same set of parameters receives a gradient
         assert [str(x) for x in g["no_grad_keys"]] == sorted(k for k in named if named[k].grad is None)
         # (weights: a sum over all pixels, so a flipped pixel is diluted; 1 % of the gradient's norm in norm and projection)
-        for k, n_ref, p_ref in zip(keys, g["all_norm"], g["all_proj"]):
+        # At 544x960 a gradient is a sum over half a million pixels and the reference's OWN float32 backward sits up to 1.1e-3 (of the
+        # gradient's norm) from its float64 one (precise.init3d.1.conv4.conv.0.norm.bias; 1.0e-3 on precise.refinement.conv4.0.weight):
+        # there the arbiter is the float64 run and a key's bar is max(1e-3, 3 x the reference's own float32 deviation on that key).
+        full_size = fixture.endswith("_c1")
+        for i, (k, n_ref, p_ref) in enumerate(zip(keys, g["all_norm"], g["all_proj"])):
             gr = named[k].grad.double().cpu()
             n = float(gr.norm())
             p = float((gr.flatten() * torch.from_numpy(synth.normal(seed, "proj" + k, (gr.numel(),))).double()).sum())
+            bar = 1e-3
+            if full_size:
+                n64, p64 = float(g["f64::all_norm"][i]), float(g["f64::all_proj"][i])
+                own = max(abs(float(n_ref) - n64), abs(float(p_ref) - p64)) / max(n64, 1e-12)
+                bar, n_ref, p_ref = max(1e-3, 3.0 * own), n64, p64
             rn = abs(n - n_ref) / max(n_ref, 1e-12)
             rp = abs(p - p_ref) / max(n_ref, 1e-12)             # a projection's scale is the gradient's norm
-            rep.add(what="every parameter: gradient norm / projection", key=k, rel_norm=rn, rel_proj=rp)
+            rep.add(what="every parameter: gradient norm / projection", key=k, rel_norm=rn, rel_proj=rp, bar=bar)
             if k in exactly_zero:
                 _check(n < 1e-5 * top, (k, n))
             else:
-                _check(rn < 1e-3 and rp < 1e-3, (k, n, float(n_ref), p, float(p_ref)))
+                _check(rn < bar and rp < bar, (k, n, float(n_ref), p, float(p_ref), bar))
     finally:
-        rep.dump("parity_train_grads.json")
+        rep.dump("parity_train_grads.json" if fixture == "planted_train_grads" else "parity_train_grads_c1.json")

@@ -331,8 +331,10 @@ def planted_cases(M, only=None):
         print("   ", name, "EPE per frame", [float(arrs["epe_%d" % t]) for t in range(frames)])
 
 
-def planted_gradient_case(M):
-    """Gradient fixture of the whole aggregator: the reference's aggregator in train() mode with the
+def planted_gradient_case(M, full_size=False):
+    """full_size: the same at BASELINE configs[1]'s size (544x960, D=192, B=1), stored as norms / projections only
+    (planted_train_grads_c1, < 200 KB).
+    Gradient fixture of the whole aggregator: the reference's aggregator in train() mode with the
     committed checkpoint on a small planted scene, the reference's OWN loss objects with the sceneflow.yaml weights behind the
     wrapper's full-resolution rescale (projects/TemporalStereo/TemporalStereo.py:305-309), loss.backward() by the framework's
     autograd -- run twice: in float32 (what the reference computes) and in float64 (the same modules and inputs cast to double:
@@ -342,12 +344,13 @@ def planted_gradient_case(M):
     import torch.nn.functional as F
     import parity_tools as PT
     from architecture.modeling.losses import DispSmoothL1Loss, WarssersteinDistanceLoss
-    B, H, W, ns = 2, 128, 192, 4
+    B, H, W, ns = (1, 544, 960, 12) if full_size else (2, 128, 192, 4)
     max_disp = 16 * ns
-    seed = synth.SEED0 + 600
+    seed = synth.SEED0 + (610 if full_size else 600)
+    fx = 1050.0 if full_size else 300.0
     dims = dict(SCENEFLOW); dims['coarse'] = dict(SCENEFLOW['coarse'], num_sample=ns)
-    sc = synth.stereo_sequence(seed, B, H, W, frames=1, max_disp=max_disp, fx=300.0, baseline=1.0)
-    arrs = dict(seed=seed, B=B, H=H, W=W, num_sample=ns, max_disp=max_disp, fx=300.0,
+    sc = synth.stereo_sequence(seed, B, H, W, frames=1, max_disp=max_disp, fx=fx, baseline=1.0)
+    arrs = dict(seed=seed, B=B, H=H, W=W, num_sample=ns, max_disp=max_disp, fx=fx,
                 input_checksum=np.float64(synth.checksum(list(sc["frames"][0]))))
     for tag, dt in (("", torch.float32), ("f64::", torch.float64)):
         torch.set_default_dtype(dt)                  # the reference creates constants (candidates, zero memory) in the default dtype
@@ -370,7 +373,11 @@ def planted_gradient_case(M):
         for i in range(3):          # every eighth channel in full + norm and a seeded projection of the whole tensor
             for side, ts in (("left", lf), ("right", rf)):
                 g = ts[i].grad
-                arrs[tag + "g_%s_%d" % (side, i)] = g[:, ::8]
+                if not full_size:
+                    arrs[tag + "g_%s_%d" % (side, i)] = g[:, ::8]
+                else:       # norms and a seeded projection only
+                    pr = T(synth.normal(seed, "projf%s%d" % (side, i), tuple(g.shape))).double()
+                    arrs[tag + "g_%s_%d_proj" % (side, i)] = np.float64((g.double() * pr).sum())
                 arrs[tag + "g_%s_%d_norm" % (side, i)] = np.float64(g.double().norm())
         named = dict(net.named_parameters())
         picks = [k for k in named if k.endswith(("init3d.0.conv.0.weight", "init3d.0.conv.0.bias", "init3d.0.conv.1.weight", "past_conv.weight",
@@ -381,6 +388,8 @@ def planted_gradient_case(M):
         picks += [k for k in named if "init3d.1." in k and k.endswith(".weight") and k.startswith("fine.")][:8]
         picks += [k for k in named if "convex_upsample" in k and k.endswith(".weight") and k.startswith("coarse.")][:4]
         picks = [k for k in dict.fromkeys(picks) if named[k].grad is not None and named[k].numel() <= 40000]
+        if full_size:
+            picks = [k for k in picks if named[k].numel() <= 600]          # a few small tensors element by element
         arrs["picked"] = np.array(picks)
         for k in picks:
             arrs[tag + "gw::" + k] = named[k].grad
@@ -397,7 +406,7 @@ def planted_gradient_case(M):
         a, b = arrs["gw::" + str(k)].double(), arrs["f64::gw::" + str(k)].double()
         worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-30)))
     print("    reference fp32 vs fp64 backward, worst relative L2 over the picked weights: %.3g" % worst)
-    save("planted_train_grads", **arrs)
+    save("planted_train_grads_c1" if full_size else "planted_train_grads", **arrs)
 
 
 def temporal_update_cases(M):
@@ -556,6 +565,9 @@ def main():
         planted_cases(M, [a for a in sys.argv[1:] if a.startswith("planted_")] or None)
         if not any(a.startswith("planted_") for a in sys.argv[1:]):
             planted_gradient_case(M)
+        return
+    if "--only-planted-grads-c1" in sys.argv:
+        planted_gradient_case(M, full_size=True)
         return
     if "--only-planted-grads" in sys.argv:
         planted_gradient_case(M)

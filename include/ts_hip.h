@@ -280,6 +280,18 @@ typedef struct {
   int flip, reserved;
 } ts_weight_layout_desc;               /* 64 bytes */
 int ts_conv_weight_layout_many(const void* table, int n, int blocks_x, void* stream);
+/* General form (ABI 9): out[a*out_stride_a + t*out_stride_t + col0 + b] = w[a*stride_a + b*stride_b + (flip ? T-1-t : t)*stride_t] for
+ * b < nb -- only those elements are written (padding is the caller's, zeroed once).  One entry per (destination region, source):
+ * concatenations along Cout, block-diagonal pairs and re-pitched arrays are entries over the framework's own parameters, so an
+ * inference engine re-folds ALL its kernel-layout weights after an optimizer step in one launch (aggregation/native.py Tape). */
+typedef struct {
+  const float* w; float* out;
+  int A, T, nb, col0;
+  long long stride_a, stride_b, stride_t;
+  long long out_stride_a, out_stride_t;
+  int flip, reserved;
+} ts_weight_layout_desc2;              /* 80 bytes */
+int ts_conv_weight_layout_many2(const void* table, int n, int blocks_x, void* stream);
 /* Upper bound (8 | 16 | 32, default 32) on the input-channel chunk -- hence the LDS footprint -- of the
  * convolution launches that follow on this host thread: short chunks when kernels of several streams
  * should share the CUs, long chunks for a lone dependent chain.  Recordable in a plan. */
@@ -508,7 +520,8 @@ int ts_space_to_depth2_fwd(const float* x, float* z, int B, int C, int H, int W,
 int ts_deconv2d_k4s2_weight_to_conv3(const float* w, float* out, int Cin, int Cout, int cin_pad, void* stream);
 int ts_deconv2d_k4s2_wgrad_from_conv3(const float* dw3, float* dw, int Cin, int Cout, void* stream);
 /* eval-mode BatchNorm folded into the convolution epilogue for a whole step in one launch: table = n ts_bn_fold_entry in DEVICE memory;
- * scale[c] = gamma / sqrt(var + eps), shift[c] = beta + (bias - mean) * scale for c < C, 0 for C <= c < pad (gamma / beta / bias may be NULL) */
+ * scale[c] = gamma / sqrt(var + eps), shift[c] = beta + (bias - mean) * scale for c < C, 0 for C <= c < pad (gamma / beta / bias may be NULL;
+ * mean / var NULL (ABI 9) = no BatchNorm behind the convolution: scale 1, shift = bias) */
 typedef struct ts_bn_fold_entry { const float* gamma; const float* beta; const float* mean; const float* var; const float* bias;
                                   float* scale; float* shift; int C, pad; } ts_bn_fold_entry;
 int ts_bn_fold_many(const void* table, int n, float eps, void* stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "ts_peer_all_reduce_sum": (c_int, [c_ptr, c_f32p, c_int, c_f32p, c_ptr]),
     "ts_conv_weight_layout": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_longlong] * 3 + [c_int, c_ptr]),
     "ts_conv_weight_layout_many": (c_int, [c_ptr, c_int, c_int, c_ptr]),
+    "ts_conv_weight_layout_many2": (c_int, [c_ptr, c_int, c_int, c_ptr]),
     "ts_conv_set_chunk_cap": (c_int, [c_int]),
     "ts_conv3d_hw_x6_supported": (c_int, [c_int] * 6),
     "ts_conv3d_hw_x6_weight_bytes": (ctypes.c_size_t, [c_int] * 2),

@@ -11,6 +11,8 @@ Static-buffer contract: inputs are copied into graph-owned buffers, outputs are 
 tensors that the next call overwrites (clone what must outlive the next frame).  The temporal state
 `prev_info` is part of the signature: a graph is built per (shapes, which state entries exist).
 """
+import os
+
 import torch
 
 
@@ -150,6 +152,7 @@ class InferenceEngine:
         # step, load_state_dict's copy_) bumps all versions, .to() moves all storages; an edit of a single tensor by
         # hand is what refresh() is for.
         self._tensors = list(net.parameters()) + list(net.buffers())
+        self._built_ptrs = [t.data_ptr() for t in self._tensors]
         self._sentinels = self._tensors[::16] + self._tensors[-1:]
         self._stamp = self._weights_stamp()
         self._stale = False
@@ -170,18 +173,51 @@ class InferenceEngine:
         dev = next(self.module.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("InferenceEngine needs the module on the GPU (there is no CPU path)")
+        tensors = list(self.module.parameters()) + list(self.module.buffers())
+        same_storage = dev == self.device and len(tensors) == len(self._tensors) and \
+            all(a is b and a.data_ptr() == p for a, b, p in zip(tensors, self._tensors, self._built_ptrs))
+        if self.backend == "native" and same_storage and not self.net.tape.unsupported and os.environ.get("TS_ENGINE_REFOLD_IN_PLACE", "1") != "0":
+            # the same tensors with new values (optimizer step, load_state_dict): every folded array re-made IN PLACE by a few
+            # table-driven launches (native.Tape); the recorded plans / captured graphs keep pointing at the right arrays, so
+            # nothing is dropped or re-recorded
+            torch.cuda.synchronize(self.device)    # passes in flight on the engine's own streams still read the arrays ...
+            self.net.refresh_weights()
+            torch.cuda.synchronize(self.device)    # ... and the next pass's helper streams do not wait for the caller's stream
+            self._stamp = self._weights_stamp()
+            self._stale = False
+            return
         torch.cuda.synchronize(self.device)        # passes still in flight read the buffers about to be dropped
         self.device = dev
         if self.backend == "native":
             self.net.device = dev
             with torch.cuda.device(dev):
                 self.net._build(self.module)
+                torch.cuda.synchronize(dev)        # helper streams do not wait for the caller's stream, where the fold just ran
         self._graphs.clear()
         self._turn.clear()
         self._tensors = list(self.module.parameters()) + list(self.module.buffers())
+        self._built_ptrs = [t.data_ptr() for t in self._tensors]
         self._sentinels = self._tensors[::16] + self._tensors[-1:]
         self._stamp = self._weights_stamp()
         self._stale = False
+
+    def refold_in_stream(self):
+        """In-place re-fold (native.Tape) on the CALLER's stream without host synchronisation, for a caller that issues its passes
+        one at a time on that same stream (pipeline == 1: every pass forks its helper streams from the caller's stream and joins
+        them back, so the re-fold is ordered between two passes) -- train.TrainStep does this once per step for the previous
+        frames.  The recorded plans stay valid."""
+        if self.backend != "native" or self.pipeline != 1:
+            raise RuntimeError("refold_in_stream: native backend, one pass at a time")
+        if self._stale or self.net.tape.unsupported or any(t.data_ptr() != p for t, p in zip(self._tensors, self._built_ptrs)):
+            was = self.module.training
+            self.module.train(False)
+            try:
+                self.refresh()
+            finally:
+                self.module.train(was)
+            return
+        self.net.refresh_weights()
+        self._stamp = self._weights_stamp()
 
     def _capture(self, args):
         static_in = args if self.bind else _clone_static(args)

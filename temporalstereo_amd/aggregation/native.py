@@ -162,10 +162,111 @@ def _act_code(mod):
     raise NotImplementedError("activation %r has no fused kernel epilogue" % (mod,))
 
 
+class Tape:
+    """How every kernel-layout array of a NativeAggregator derives from the module's parameters and buffers, so that the arrays
+    can be RE-MADE IN PLACE (same storage: recorded launch plans and captured graphs stay valid) by a handful of table-driven
+    launches -- ts_conv_weight_layout_many2 for all weight arrays, ts_bn_fold_many for all scale / shift vectors, one split launch
+    per bf16-split copy -- instead of ~2,000 framework launches of a rebuild.  Used by InferenceEngine.refresh() after the weights
+    changed and, once per step, by train.TrainStep for the previous (eval) frames of a training step.
+    Entries are recorded while the aggregator is built (`with tape:` around _build); arrays the tape cannot express raise at
+    record time (`unsupported`), and refresh() then reports that a rebuild is needed."""
+
+    def __init__(self):
+        self.layouts = []        # (out tensor, out_offset_elems, weight param, A, T, nb, col0, sa, sb, st, out_sa, out_st)
+        self.folds = []          # (gamma, beta, mean, var, bias, scale view, shift view, C)
+        self.splits = []         # (Folded, "x6" | "x6s", mode)
+        self.eps = None
+        self.unsupported = []
+        self._tables = None
+
+    def __enter__(self):
+        global _TAPE
+        self._outer, _TAPE = _TAPE, self
+        return self
+
+    def __exit__(self, *exc):
+        global _TAPE
+        _TAPE = self._outer
+        return False
+
+    def layout(self, out, weight, transposed, rows=None, col0=0, out_st=None, src_cin0=0, cout_sel=None):
+        """out [.., taps, pitch] <- the [Cin][taps][Cout] layout of `weight` ([Cout, Cin, taps...] or, transposed, [Cin, Cout, taps...]).
+        rows: (first, count) input channels of the SOURCE written to out's leading rows; col0: first destination column;
+        out_st: destination tap pitch (default: out's own); cout_sel: (first, count) output channels of the source."""
+        w = weight
+        d0, d1 = w.shape[0], w.shape[1]
+        T = w[0, 0].numel()
+        cout, cin = (d1, d0) if transposed else (d0, d1)
+        s_ci, s_co = ((d1 * T, T) if transposed else (T, d1 * T))
+        c0, nci = rows if rows is not None else (0, cin)
+        o0, nco = cout_sel if cout_sel is not None else (0, cout)
+        self.layouts.append(dict(out=out, w=w, A=nci, T=T, nb=nco, col0=col0, sa=s_ci, sb=s_co, st=1, src_off=(c0 + src_cin0) * s_ci + o0 * s_co,
+                                 out_sa=out.stride(0), out_st=out.stride(1) if out_st is None else out_st))
+        self._tables = None
+
+    def fold(self, scale, shift, bias, bn, cout):
+        if bn is not None:
+            if self.eps is not None and float(bn.eps) != self.eps:
+                self.unsupported.append("BatchNorm layers with different eps")
+            self.eps = float(bn.eps)
+        self.folds.append(dict(scale=scale, shift=shift, bias=bias, bn=bn, C=cout))
+        self._tables = None
+
+    def _upload(self, dev):
+        import numpy as np
+        lay = np.zeros(len(self.layouts), dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("A", "<i4"), ("T", "<i4"), ("nb", "<i4"), ("col0", "<i4"),
+                                                          ("sa", "<i8"), ("sb", "<i8"), ("st", "<i8"), ("osa", "<i8"), ("ost", "<i8"),
+                                                          ("flip", "<i4"), ("reserved", "<i4")]))
+        most = 1
+        for i, e in enumerate(self.layouts):
+            w = e["w"]
+            if not w.is_contiguous():
+                raise RuntimeError("Tape: a source weight is not contiguous")
+            lay[i] = (w.data_ptr() + 4 * e["src_off"], e["out"].data_ptr(), e["A"], e["T"], e["nb"], e["col0"], e["sa"], e["sb"], e["st"],
+                      e["out_sa"], e["out_st"], 0, 0)
+            most = max(most, e["A"] * e["T"] * e["nb"])
+        fo = np.zeros(len(self.folds), dtype=np.dtype([("gamma", "<u8"), ("beta", "<u8"), ("mean", "<u8"), ("var", "<u8"), ("bias", "<u8"),
+                                                       ("scale", "<u8"), ("shift", "<u8"), ("C", "<i4"), ("pad", "<i4")]))
+        P = lambda t: t.data_ptr() if t is not None else 0
+        for i, e in enumerate(self.folds):
+            bn = e["bn"]
+            if bn is not None:
+                g, b = (bn.weight, bn.bias) if bn.affine else (None, None)
+                fo[i] = (P(g), P(b), P(bn.running_mean), P(bn.running_var), P(e["bias"]), P(e["scale"]), P(e["shift"]), e["C"], e["C"])
+            else:
+                fo[i] = (0, 0, 0, 0, P(e["bias"]), P(e["scale"]), P(e["shift"]), e["C"], e["C"])
+        up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev)
+        self._tables = (up(lay), up(fo), min(64, (most + 255) // 256))
+
+    def refresh(self, dev):
+        """Re-make every recorded array from the CURRENT parameters / running statistics, in place, on the current stream."""
+        if self.unsupported:
+            raise RuntimeError("Tape.refresh: %s -- rebuild the aggregator instead" % "; ".join(self.unsupported))
+        L = _lib.lib()
+        if self._tables is None:
+            self._upload(dev)
+        lay, fo, blocks = self._tables
+        if self.layouts:
+            _lib.check(L.ts_conv_weight_layout_many2(_lib.ptr(lay), len(self.layouts), blocks, _stream()), "ts_conv_weight_layout_many2")
+        if self.folds:
+            _lib.check(L.ts_bn_fold_many(_lib.ptr(fo), len(self.folds), self.eps if self.eps is not None else 1e-5, _stream()), "ts_bn_fold_many")
+        for f, kind, mode in self.splits:
+            if kind == "x6":
+                _lib.check(L.ts_conv3d_hw_x6_weight_split(f.w.data_ptr(), f.w6.data_ptr(), f.cin, f.cout, _stream()), "ts_conv3d_hw_x6_weight_split")
+            else:
+                _lib.check(L.ts_conv3d_hw_x6s_weight_split(f.w.data_ptr(), f.w6s.data_ptr(), f.cin, f.cout, f.w.shape[2], mode, _stream()),
+                           "ts_conv3d_hw_x6s_weight_split")
+
+
+_TAPE = None
+
+
 class Folded:
     """Kernel-ready form of one conv (+BatchNorm (+activation))."""
 
     def __init__(self, weight, bias, bn, act, transposed, kind):
+        self._tape = _TAPE
+        self.src = (weight, bias, bn, transposed)
         w = weight.detach().float()
         if transposed:                      # ConvTranspose: [Cin, Cout, ...] -> [Cout, Cin, ...]
             w = w.transpose(0, 1)
@@ -195,6 +296,11 @@ class Folded:
         else:
             shift[:cout] = b
         self.scale, self.shift = scale.contiguous(), shift.contiguous()
+        if _TAPE is not None:
+            if weight.dtype != torch.float32:
+                _TAPE.unsupported.append("non-fp32 weights")
+            _TAPE.layout(self.w, weight.detach(), transposed)
+            _TAPE.fold(self.scale, self.shift, bias, bn, cout)
 
 
 def fold_split_input(f, n):
@@ -204,7 +310,9 @@ def fold_split_input(f, n):
     head, rest = object.__new__(Folded), object.__new__(Folded)
     for g, lo, hi in ((head, 0, n), (rest, n, f.cin)):
         g.cin, g.cout, g.kind, g.kshape = hi - lo, f.cout, f.kind, f.kshape
-        g.w = f.w[lo:hi].contiguous()
+        g._tape = getattr(f, "_tape", None)
+        g.w = f.w[lo:hi].contiguous()          # a leading-rows slice is contiguous: a VIEW of f.w (an in-place re-fold of f reaches it)
+        assert g.w.data_ptr() == f.w[lo:hi].data_ptr()
     head.act, rest.act = ACT_NONE, f.act
     head.scale, head.shift = torch.ones_like(f.scale), torch.zeros_like(f.shift)
     rest.scale, rest.shift = f.scale, f.shift
@@ -228,6 +336,18 @@ def fold_concat(a, b):
     f.shift = torch.zeros(pad, device=a.w.device)
     f.scale[:a.cout] = a.scale[:a.cout]; f.scale[a.cout:f.cout] = b.scale[:b.cout]
     f.shift[:a.cout] = a.shift[:a.cout]; f.shift[a.cout:f.cout] = b.shift[:b.cout]
+    f._tape = getattr(a, "_tape", None)
+    if f._tape is not None:
+        col = 0
+        for g in (a, b):
+            src = getattr(g, "src", None)
+            if src is None:
+                f._tape.unsupported.append("concatenation of derived layers")
+                break
+            weight, bias, bn, transposed = src
+            f._tape.layout(f.w, weight.detach(), transposed, col0=col)
+            f._tape.fold(f.scale[col:col + g.cout], f.shift[col:col + g.cout], bias, bn, g.cout)
+            col += g.cout
     return f
 
 
@@ -262,6 +382,8 @@ def x6_weights(f):
         w6 = torch.empty(int(L.ts_conv3d_hw_x6_weight_bytes(f.cin, f.cout)), device=f.w.device, dtype=torch.uint8)
         _lib.check(L.ts_conv3d_hw_x6_weight_split(f.w.data_ptr(), w6.data_ptr(), f.cin, f.cout, _stream()), "ts_conv3d_hw_x6_weight_split")
         f.w6 = w6
+        if getattr(f, "_tape", None) is not None:
+            f._tape.splits.append((f, "x6", 0))
     return w6
 
 
@@ -286,6 +408,11 @@ def x6s_weights(f, mode):
         _lib.check(L.ts_conv3d_hw_x6s_weight_split(f.w.data_ptr(), w6.data_ptr(), f.cin, f.cout, f.w.shape[2], mode, _stream()),
                    "ts_conv3d_hw_x6s_weight_split")
         f.w6s = w6
+        f.w6s_mode = mode
+        if getattr(f, "_tape", None) is not None:
+            f._tape.splits.append((f, "x6s", mode))
+    elif getattr(f, "w6s_mode", mode) != mode:
+        raise RuntimeError("x6s_weights: this layer's weights were split for mode %d, asked for mode %d" % (f.w6s_mode, mode))
     return w6
 
 
@@ -494,6 +621,13 @@ def split_sampled_first_layer(f0, scales):
     q.w = torch.zeros(C, 1, pad, device=rest.w.device, dtype=torch.float32)
     q.w[:, 0, :q.cout] = rest.w[:C, :, :rest.cout].reshape(C, 9 * rest.cout)         # [c][tap][co] -> plane tap * Cout + co
     q.scale, q.shift = torch.ones(pad, device=q.w.device), torch.zeros(pad, device=q.w.device)
+    q._tape = getattr(f0, "_tape", None)
+    if q._tape is not None:
+        src = getattr(f0, "src", None)
+        if src is None or src[3]:
+            q._tape.unsupported.append("first layer of a sampled level is itself derived")
+        else:       # q.w[c][0][tap * Cout + co] = W[co][C + c][tap]: rows = the warped half's input channels, tap pitch = Cout
+            q._tape.layout(q.w, src[0].detach(), False, rows=(C, C), out_st=rest.cout)
     return left, rest, corr, q
 
 
@@ -559,6 +693,11 @@ class Heads:
         f.scale = torch.ones(pad, device=f.w.device); f.shift = torch.zeros(pad, device=f.w.device)
         f.scale[0], f.scale[1] = self.c1.scale[0], self.o1.scale[0]
         f.shift[0], f.shift[1] = self.c1.shift[0], self.o1.shift[0]
+        f._tape = _TAPE
+        if _TAPE is not None:
+            for k, (m, g) in enumerate(((mod.cost_head[1], self.c1), (mod.off_head[1], self.o1))):
+                _TAPE.layout(f.w[k * C:(k + 1) * C], m.weight.detach(), False, col0=k)          # rows [kC, (k+1)C), column k
+                _TAPE.fold(f.scale[k:k + 1], f.shift[k:k + 1], m.bias, getattr(m, "norm", None), 1)
         self.pair = f
 
     def __call__(self, x):
@@ -850,6 +989,12 @@ class NativeAggregator:
         self.device = dev
         with torch.cuda.device(dev):
             self._build(net)
+            # The fold runs as ~2,000 framework launches on the CALLER's stream, and the two-phase / pipelined schedules start their
+            # helper streams WITHOUT waiting for that stream (engine.begin, _staged_pass): a first pass issued right behind the build
+            # could read half-folded weights -- and make its bf16-split copies from them, for good.  Seen once in nine runs of the
+            # two-phase schedule on freshly built engines (round 5: a KITTI-size first frame 57 px off); the build is rare, so it
+            # simply completes here.
+            torch.cuda.synchronize(dev)
         self.fast, self.aux = qualified_streams(dev, 2, private=private_streams)
         self.pipeline_slot = None            # set by the engine while it records one of its double-buffered plans
         self.overlap = True
@@ -857,7 +1002,16 @@ class NativeAggregator:
     def _build(self, net):
         """Fold BatchNorm / bias into per-channel scale and shift and re-lay the weights out for the kernels.  The
         result is a private COPY of the parameters: call again (InferenceEngine.refresh does) after they change."""
-        self.coarse, self.fine, self.precise = NativeCoarse(net.coarse), NativeFine(net.fine), NativePrecise(net.precise)
+        self.tape = Tape()
+        with self.tape:
+            self.coarse, self.fine, self.precise = NativeCoarse(net.coarse), NativeFine(net.fine), NativePrecise(net.precise)
+
+    def refresh_weights(self):
+        """The module's parameters / running statistics changed: re-make every folded array IN PLACE (Tape) -- a few launches on the
+        current stream; recorded plans and captured graphs that point into the arrays stay valid.  Raises if some array of this
+        model cannot be expressed by the tape (rebuild then)."""
+        with torch.cuda.device(self.device):
+            self.tape.refresh(self.device)
 
     def _coarse_level(self, l16, r16, prev_info, out, mask=None, vol=None):
         rng = 4

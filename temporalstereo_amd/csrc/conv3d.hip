@@ -978,6 +978,33 @@ weight_layout_many_kernel(const WeightLayoutDesc* __restrict__ table) {
   }
 }
 
+// The general form (ABI 9): an entry writes `nb` columns starting at column `col0` of a destination whose row (a) and tap (t)
+// pitches are given -- never the padding around them.  With it every derived weight array of the inference engine is a table
+// entry over the framework's own parameter: a concatenation of two layers along Cout (two entries, col0 = 0 and Cout_a), the
+// block-diagonal pair of the prediction heads, the 1x1 "Q" weights of the warp-commuted first layer (tap pitch = Cout) -- and
+// the whole engine re-folds after an optimizer step in ONE launch (aggregation/native.py, Tape).
+struct WeightLayoutDesc2 {           // == ts_weight_layout_desc2 of include/ts_hip.h (80 bytes)
+  const float* w; float* out;
+  int A, T, nb, col0;
+  long long sa, sb, st;
+  long long out_sa, out_st;
+  int flip, reserved;
+};
+static_assert(sizeof(WeightLayoutDesc2) == 80, "table entry layout");
+
+__global__ void __launch_bounds__(256)
+weight_layout_many2_kernel(const WeightLayoutDesc2* __restrict__ table) {
+  const WeightLayoutDesc2 d = table[blockIdx.y];
+  const long long n = static_cast<long long>(d.A) * d.T * d.nb;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(i % d.nb);
+    const long long r = i / d.nb;
+    const int t = static_cast<int>(r % d.T), a = static_cast<int>(r / d.T);
+    d.out[a * d.out_sa + t * d.out_st + d.col0 + b] = d.w[a * d.sa + b * d.sb + (d.flip ? d.T - 1 - t : t) * d.st];
+  }
+}
+
 // extent checks shared by the entry points: buffer addressing is 32-bit per batch element
 bool ig_extent(IG& p, int KT) {
   const unsigned long long in_b = (static_cast<unsigned long long>(p.Cin - 1) * p.in_cstride + static_cast<unsigned long long>(p.D) * p.H * p.W) * 4ull;
@@ -1807,6 +1834,14 @@ extern "C" int ts_conv_weight_layout(const float* w, float* out, int A, int T, i
 
 // table: n entries of ts_weight_layout_desc in DEVICE memory; blocks_x: workgroups per entry (entries larger than
 // blocks_x * 256 elements are covered by a grid-stride loop, smaller ones leave the surplus workgroups idle).
+extern "C" int ts_conv_weight_layout_many2(const void* table, int n, int blocks_x, void* stream) {
+  TS_REQUIRE(n > 0 && n <= 65535 && blocks_x > 0 && blocks_x <= 4096, TS_ERR_SHAPE, "conv_weight_layout_many2: bad table size");
+  TS_REQUIRE_PTR(table);
+  hipLaunchKernelGGL(weight_layout_many2_kernel, dim3(static_cast<unsigned>(blocks_x), static_cast<unsigned>(n)), dim3(256), 0,
+                     ts::as_stream(stream), static_cast<const WeightLayoutDesc2*>(table));
+  return ts::launched("weight_layout_many2_kernel");
+}
+
 extern "C" int ts_conv_weight_layout_many(const void* table, int n, int blocks_x, void* stream) {
   TS_REQUIRE(n > 0 && n <= 65535 && blocks_x > 0 && blocks_x <= 4096, TS_ERR_SHAPE, "conv_weight_layout_many: bad table size");
   TS_REQUIRE_PTR(table);

@@ -160,8 +160,11 @@ bn_fold_many_kernel(const FoldEntry* __restrict__ table, float eps) {
   for (int c = threadIdx.x; c < e.pad; c += 64) {
     float s = 0.f, t = 0.f;
     if (c < e.C) {
-      s = (e.gamma ? e.gamma[c] : 1.f) / sqrtf(e.var[c] + eps);
-      t = (e.beta ? e.beta[c] : 0.f) + ((e.bias ? e.bias[c] : 0.f) - e.mean[c]) * s;
+      // var == NULL: no BatchNorm behind the convolution (scale 1, shift = bias)
+      s = e.var ? (e.gamma ? e.gamma[c] : 1.f) / sqrtf(e.var[c] + eps) : 1.f;
+      // (separately rounded product and sum, as the framework's `beta + (bias - mean) * s` of aggregation/native.Folded: an in-place
+      // re-fold must give the bits a rebuild gives)
+      t = __fadd_rn(e.beta ? e.beta[c] : 0.f, __fmul_rn((e.bias ? e.bias[c] : 0.f) - (e.mean ? e.mean[c] : 0.f), s));
     }
     e.scale[c] = s;
     e.shift[c] = t;

@@ -230,6 +230,14 @@ class TrainStep:
         # the previous frames run in eval() / no_grad: their conv -> BatchNorm -> activation wrappers become one convolution launch
         # each, the BatchNorm folded into its epilogue; all folds of the step are recomputed by one launch (functional.BNFolds)
         self.folds = TF.BNFolds() if (on_gpu and os.environ.get("TS_TRAIN_BN_FOLDS", "1") != "0") else None
+        # Round 5: the previous frames through the INFERENCE form of the same network (aggregation.native: bf16-split convolutions,
+        # the warp-commuted first layers, channel-sliced outputs instead of torch.cat, merged heads -- ~110 launches instead of ~210
+        # per frame), its folded arrays re-made in place from the current parameters / running statistics once per step by native.Tape
+        # (three table-driven launches + one per bf16-split copy; round 4 tried this with a full rebuild per step -- ~2,000
+        # framework launches -- and lost).  Built lazily at the first step with previous frames; TS_TRAIN_NATIVE_PREV=0 keeps the
+        # module path for them.
+        self._native_prev = None
+        self._use_native_prev = on_gpu and os.environ.get("TS_TRAIN_NATIVE_PREV", "1") != "0"
         # (Tried and dropped in round 3: the weight-gradient launches on a forked side stream inside the capture -- they depend only on
         # dy, 15 % of the step's device time, small grids.  The replayed graph got SLOWER, 15.0 vs 13.4 ms: forked captures replay
         # badly on ROCm 7.2, as the inference graph already showed)
@@ -251,6 +259,39 @@ class TrainStep:
         self.close()
         return False
 
+    def _previous_frame_network(self):
+        """The inference form of the network for the eval / no_grad frames, its folded arrays brought up to date with the current
+        parameters and running statistics (in place; inside a capture this is part of the captured step).  None: module path."""
+        if not self._use_native_prev:
+            return None
+        if self._native_prev is None:
+            from .aggregation.engine import InferenceEngine
+            from .aggregation.native import NativeAggregator
+            try:
+                self._set_training(False)
+                if self.graph:
+                    # captured step: the aggregator itself, on one stream (forked captures replay badly on ROCm 7.2)
+                    agg = NativeAggregator(self.net)
+                    agg.overlap = False
+                    eng = None
+                else:
+                    # eager step: the pass replayed from a recorded launch plan (one host call instead of ~110 issued from Python)
+                    eng = InferenceEngine(self.net, backend="native", replay="plan", inputs="copy")
+                    agg = eng.net
+                if agg.tape.unsupported:
+                    raise NotImplementedError("; ".join(agg.tape.unsupported))
+                self._native_prev = (agg, eng)
+                return eng if eng is not None else agg   # just built from the current values
+            except NotImplementedError:                  # a model the inference form does not cover: the module path serves it
+                self._use_native_prev = False
+                return None
+        agg, eng = self._native_prev
+        if eng is not None:
+            eng.refold_in_stream()
+            return eng
+        agg.refresh_weights()
+        return agg
+
     def _set_training(self, mode):
         """net.train(mode) without nn.Module.__setattr__'s bookkeeping on ~640 modules (2.4 ms of host time per step)."""
         for m in self._modules:
@@ -267,10 +308,11 @@ class TrainStep:
             if self.folds is not None and len(frames) > 1:
                 self.folds.refresh()
             info = {}
+            prev_net = self._previous_frame_network() if len(frames) > 1 else None
             for t, fr in enumerate(frames[:-1]):
                 self._set_training(False)
                 with torch.no_grad():
-                    info = net(fr[0], fr[1], fr[2], fr[3], dict(info))[5]
+                    info = (prev_net if prev_net is not None else net)(fr[0], fr[1], fr[2], fr[3], dict(info))[5]
                     H, W = fr[2].shape[-2:]
                     info = temporal.update_map(dict(info), K, poses[t + 1][0], poses[t + 1][1], self.baseline, H, W,
                                                use_past_cost=True, local_map_size=self.local_map_size)

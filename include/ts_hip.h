@@ -292,6 +292,15 @@ typedef struct {
   int flip, reserved;
 } ts_weight_layout_desc2;              /* 80 bytes */
 int ts_conv_weight_layout_many2(const void* table, int n, int blocks_x, void* stream);
+/* Deferred finishes of ts_conv3d_{hw,d}_bwd_weight (ABI 9): between ts_conv_wgrad_defer(1) and (0) the calls ON THIS HOST THREAD leave
+ * their partial sums in the caller's workspaces -- which must stay alive -- and dw unwritten; ts_conv_wgrad_take moves the kept
+ * descriptors into a HOST table (48 bytes each), which the caller copies to the device and hands to ts_conv_wgrad_finish_many: one
+ * launch sums every layer's partials (same sums, same order as the per-layer finish).  A training step saves ~95 launches with it. */
+typedef struct { const float* part; float* dw; int gx, nitems, cob, Cin, Cout, KT, ciblocks, block0; } ts_wgrad_finish_desc;   /* 48 bytes */
+int ts_conv_wgrad_defer(int on);           /* returns the previous setting */
+int ts_conv_wgrad_pending(void);
+int ts_conv_wgrad_take(void* host_table, size_t capacity_bytes, int* n, int* total_blocks);
+int ts_conv_wgrad_finish_many(const void* table, int n, int total_blocks, void* stream);
 /* Upper bound (8 | 16 | 32, default 32) on the input-channel chunk -- hence the LDS footprint -- of the
  * convolution launches that follow on this host thread: short chunks when kernels of several streams
  * should share the CUs, long chunks for a lone dependent chain.  Recordable in a plan. */

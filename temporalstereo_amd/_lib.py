@@ -94,6 +94,10 @@ SIGNATURES = {
     "ts_conv_weight_layout": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_longlong] * 3 + [c_int, c_ptr]),
     "ts_conv_weight_layout_many": (c_int, [c_ptr, c_int, c_int, c_ptr]),
     "ts_conv_weight_layout_many2": (c_int, [c_ptr, c_int, c_int, c_ptr]),
+    "ts_conv_wgrad_defer": (c_int, [c_int]),
+    "ts_conv_wgrad_pending": (c_int, []),
+    "ts_conv_wgrad_take": (c_int, [c_ptr, c_size, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "ts_conv_wgrad_finish_many": (c_int, [c_ptr, c_int, c_int, c_ptr]),
     "ts_conv_set_chunk_cap": (c_int, [c_int]),
     "ts_conv3d_hw_x6_supported": (c_int, [c_int] * 6),
     "ts_conv3d_hw_x6_weight_bytes": (ctypes.c_size_t, [c_int] * 2),
@@ -149,7 +153,8 @@ SIGNATURES = {
 _QUERIES = frozenset(n for n in SIGNATURES if n.endswith("_bytes") or n.startswith("ts_plan_") or
                      n in ("ts_version", "ts_last_error_string", "ts_conv_cout_pad", "ts_conv3d_hw_x6_supported", "ts_conv3d_hw_x6s_supported", "ts_peer_max_floats", "ts_peer_max_ranks",
                            "ts_peer_alloc", "ts_peer_open", "ts_peer_close", "ts_peer_free", "ts_peer_status", "ts_peer_status_async",
-                           "ts_peer_set_timeout_ms", "ts_peer_reset", "ts_bn_set_small_elems"))
+                           "ts_peer_set_timeout_ms", "ts_peer_reset", "ts_bn_set_small_elems",
+                           "ts_conv_wgrad_defer", "ts_conv_wgrad_pending", "ts_conv_wgrad_take"))
 
 
 def lib():

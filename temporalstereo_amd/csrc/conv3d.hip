@@ -18,7 +18,9 @@
 // below replaced it (6-70 TFLOP/s on the same layers).
 // Weights are pre-laid out [Cin][taps][CoutPad] (output channel contiguous) by the host.
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "conv_common.hpp"
 
@@ -1207,6 +1209,51 @@ wgrad_finish(const float* __restrict__ part, float* __restrict__ dw, int gx, int
   }
 }
 
+// ---- deferred finish (round 5) -------------------------------------------------------------------------------------------------
+// A training step's backward runs ~95 weight-gradient kernels, each followed by its own wgrad_finish launch of a few microseconds.
+// Nothing reads a weight gradient before the optimizer, so inside ts_conv_wgrad_defer(1) ... (0) the finish launches are not issued:
+// their descriptors are kept and ONE wgrad_finish_many launch sums every layer's partials at the end of backward
+// (ts_conv_wgrad_take -> table -> ts_conv_wgrad_finish_many).  Same sums in the same order as wgrad_finish.
+struct WgradFinishDesc {             // == ts_wgrad_finish_desc of include/ts_hip.h (48 bytes)
+  const float* part; float* dw;
+  int gx, nitems, cob, Cin, Cout, KT;
+  int ciblocks, block0;              // block0: first workgroup of this entry in the flat grid (rows x ciblocks workgroups per entry)
+};
+static_assert(sizeof(WgradFinishDesc) == 48, "table entry layout");
+thread_local bool g_wgrad_defer = false;      // set around single calls by the thread that issues them (autograd's backward thread)
+std::mutex g_wgrad_mutex;                     // the kept descriptors are the process's: backward runs on autograd's thread, the
+std::vector<WgradFinishDesc> g_wgrad_pending; // step that collects them on the caller's
+
+__global__ void __launch_bounds__(256)
+wgrad_finish_many(const WgradFinishDesc* __restrict__ table, int n) {
+  __shared__ float red[4][64];
+  // the entry of this workgroup: last one with block0 <= blockIdx.x (n <= a few hundred, the table sits in L2)
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= static_cast<int>(blockIdx.x)) lo = mid; else hi = mid - 1;
+  }
+  const WgradFinishDesc d = table[lo];
+  const int local = static_cast<int>(blockIdx.x) - d.block0;
+  const int rows = d.nitems * 4;
+  const int row = local % rows, cib = local / rows;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* src = d.part + (static_cast<size_t>(cib) * d.gx * d.nitems * 4 + row) * 64 + lane;
+  const size_t pitch = static_cast<size_t>(d.nitems) * 256;
+  float s = 0.f;
+#pragma unroll 8
+  for (int g = wave; g < d.gx; g += 4) s += src[g * pitch];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) {
+    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const int item = row >> 2, r = row & 3;
+    const int tap = item / d.cob, cb = item - tap * d.cob;
+    const int co = cb * 16 + (lane >> 4) * 4 + r, ci = cib * 16 + (lane & 15);
+    if (co < d.Cout && ci < d.Cin) d.dw[(static_cast<size_t>(co) * d.Cin + ci) * d.KT + tap] = t;
+  }
+}
+
 // workgroups per input-channel block: the chip filled about twice over all blocks (every workgroup ends
 // with one partial of `items` KiB, so more of them only lengthens wgrad_finish)
 int wgrad_groups(int ciblocks) {
@@ -1246,6 +1293,13 @@ int launch_wgrad(const float* x, const float* dy, float* dw, WG p, void* workspa
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   hipLaunchKernelGGL(kern, dim3(gx, ciblocks), dim3(256), lds, st, x, dy, part, p);
+  if (g_wgrad_defer) {             // the finish joins the step's one wgrad_finish_many launch (ts_conv_wgrad_take)
+    {
+      std::lock_guard<std::mutex> lock(g_wgrad_mutex);
+      g_wgrad_pending.push_back(WgradFinishDesc{part, dw, gx, nitems, cob, p.Cin, p.Cout, KT, ciblocks, 0});
+    }
+    return ts::launched("wgrad_kernel");
+  }
   hipLaunchKernelGGL(wgrad_finish, dim3(nitems * 4, ciblocks), dim3(256), 0, st, part, dw, gx, nitems, cob, p.Cin, p.Cout, KT);
   return ts::launched("wgrad_kernel");
 }
@@ -1801,6 +1855,45 @@ extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const floa
 }
 
 extern "C" int ts_conv_cout_pad(int cout) { return cout_bucket(cout); }
+
+// Deferred weight-gradient finishes (see wgrad_finish_many).  defer(1): the ts_conv3d_*_bwd_weight calls that follow ON THIS HOST
+// THREAD leave their partial sums in the caller's workspaces (which must stay alive) and dw unwritten; returns the previous setting.
+extern "C" int ts_conv_wgrad_defer(int on) {
+  const int was = g_wgrad_defer ? 1 : 0;
+  g_wgrad_defer = on != 0;
+  return was;
+}
+extern "C" int ts_conv_wgrad_pending(void) {
+  std::lock_guard<std::mutex> lock(g_wgrad_mutex);
+  return static_cast<int>(g_wgrad_pending.size());
+}
+// Moves the pending descriptors (of every thread of the process) into `host_table` (capacity in bytes; 48 bytes per entry, block0 filled in):
+// *n entries, *total_blocks workgroups for ts_conv_wgrad_finish_many.  The list is cleared.
+extern "C" int ts_conv_wgrad_take(void* host_table, size_t capacity_bytes, int* n, int* total_blocks) {
+  TS_REQUIRE_PTR(host_table); TS_REQUIRE_PTR(n); TS_REQUIRE_PTR(total_blocks);
+  std::lock_guard<std::mutex> lock(g_wgrad_mutex);
+  const size_t cnt = g_wgrad_pending.size();
+  TS_REQUIRE(cnt * sizeof(WgradFinishDesc) <= capacity_bytes, TS_ERR_SHAPE, "conv_wgrad_take: %zu entries do not fit %zu bytes", cnt, capacity_bytes);
+  int blocks = 0;
+  WgradFinishDesc* out = static_cast<WgradFinishDesc*>(host_table);
+  for (size_t i = 0; i < cnt; ++i) {
+    out[i] = g_wgrad_pending[i];
+    out[i].block0 = blocks;
+    blocks += out[i].nitems * 4 * out[i].ciblocks;
+  }
+  *n = static_cast<int>(cnt);
+  *total_blocks = blocks;
+  g_wgrad_pending.clear();
+  return TS_OK;
+}
+// table: n entries (ts_wgrad_finish_desc) in DEVICE memory, as written by ts_conv_wgrad_take
+extern "C" int ts_conv_wgrad_finish_many(const void* table, int n, int total_blocks, void* stream) {
+  TS_REQUIRE(n > 0 && total_blocks > 0, TS_ERR_SHAPE, "conv_wgrad_finish_many: empty table");
+  TS_REQUIRE_PTR(table);
+  hipLaunchKernelGGL(wgrad_finish_many, dim3(static_cast<unsigned>(total_blocks)), dim3(256), 0, ts::as_stream(stream),
+                     static_cast<const WgradFinishDesc*>(table), n);
+  return ts::launched("wgrad_finish_many");
+}
 
 // Cap the K-chunk size (and with it the LDS footprint: 16-106 KB per workgroup at 32, 16-50 KB at 8) of the
 // convolution launches that follow on this host thread.  Long chunks shorten a lone kernel's dependent

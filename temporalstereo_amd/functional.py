@@ -434,6 +434,72 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, a
     return x, y, (B, Cin, Cout, D, H, W, stride, dilation, transposed)
 
 
+class WgradDefer:
+    """The ~95 wgrad_finish launches of a training step's backward as ONE (ts_conv_wgrad_finish_many, csrc/conv3d.hip).
+
+    Inside `with defer:` the weight-gradient calls of convolutions whose weight was used ONCE in the step's forward pass leave
+    their partial sums in their workspaces (kept alive here) and return a dw that is written only by `flush()` -- called by the step
+    after backward(), before anything reads a gradient.  Weights used more than once (the UNet image encoder runs on both views) are
+    accumulated by autograd as soon as the second gradient arrives, so they keep the immediate finish: uses are counted during the
+    forward pass.  Not for steps whose gradient buckets go out during backward (dist.GradientBuckets reads .grad from hooks)."""
+
+    def __init__(self):
+        self.uses = {}              # weight.data_ptr() -> forward uses in this step
+        self.keep = []              # partial-sum workspaces awaiting the flush
+        self._host = [None, None]
+        self._dev = None
+        self._turn = 0
+        self._copied = [None, None]
+        self.cap = 512 * 48
+
+    def __enter__(self):
+        global _WGRAD_DEFER
+        self._outer, _WGRAD_DEFER = _WGRAD_DEFER, self
+        self.uses = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _WGRAD_DEFER
+        _WGRAD_DEFER = self._outer
+        return False
+
+    def used(self, weight):
+        k = weight.data_ptr()
+        self.uses[k] = self.uses.get(k, 0) + 1
+
+    def single_use(self, weight):
+        return self.uses.get(weight.data_ptr(), 0) == 1
+
+    def flush(self):
+        import ctypes
+        L = _lib.lib()
+        if int(L.ts_conv_wgrad_pending()) == 0:
+            self.keep = []
+            return
+        dev = self.keep[0].device
+        if self._dev is None:
+            self._dev = torch.empty(self.cap, dtype=torch.uint8, device=dev)
+            self._host = [torch.empty(self.cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        capturing = torch.cuda.is_current_stream_capturing()
+        turn = self._turn
+        if self._copied[turn] is not None and not capturing:
+            self._copied[turn].synchronize()             # the upload that last read this pinned table has completed
+        host = self._host[turn]
+        n, blocks = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(L.ts_conv_wgrad_take(ctypes.c_void_p(host.data_ptr()), self.cap, ctypes.byref(n), ctypes.byref(blocks)), "ts_conv_wgrad_take")
+        self._dev.copy_(host, non_blocking=True)
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._copied[turn] = ev
+            self._turn ^= 1
+        _lib.check(L.ts_conv_wgrad_finish_many(_lib.ptr(self._dev), n.value, blocks.value, _stream()), "ts_conv_wgrad_finish_many")
+        self.keep = []
+
+
+_WGRAD_DEFER = None
+
+
 def _wgrad_workspace(cin, cout, taps, device):
     """Partial-sum buffer of ``ts_conv3d_*_bwd_weight`` (symmetric in the channel counts' roles: the larger of
     the two orders covers the transposed form, which exchanges them)."""
@@ -461,12 +527,19 @@ def _hw_backward(x, weight, dy, geom, need_x, need_w):
     if need_w:
         dw = torch.empty_like(weight)
         ws, nws = _wgrad_workspace(Cin, Cout, 9, x.device)
-        if transposed:     # roles exchanged: a stride-2 convolution maps dy (2H x 2W) to x
-            rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, D, 2 * H, 2 * W, 2, 1,
-                                           dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _lib.ptr(ws), nws, _stream())
-        else:
-            rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, D, H, W, stride, dilation,
-                                           x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _lib.ptr(ws), nws, _stream())
+        defer = _WGRAD_DEFER if (_WGRAD_DEFER is not None and _WGRAD_DEFER.single_use(weight)) else None
+        was = L.ts_conv_wgrad_defer(1) if defer is not None else 0      # (this thread: backward runs on autograd's own)
+        try:
+            if transposed:     # roles exchanged: a stride-2 convolution maps dy (2H x 2W) to x
+                rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, D, 2 * H, 2 * W, 2, 1,
+                                               dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _lib.ptr(ws), nws, _stream())
+            else:
+                rc = L.ts_conv3d_hw_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, D, H, W, stride, dilation,
+                                               x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _lib.ptr(ws), nws, _stream())
+        finally:
+            if defer is not None:
+                L.ts_conv_wgrad_defer(was)
+                defer.keep.append(ws)
         _lib.check(rc, "ts_conv3d_hw_bwd_weight")
     return dx, dw
 
@@ -532,12 +605,19 @@ def _d_backward(x, weight, dy, geom, need_x, need_w):
     if need_w:
         dw = torch.empty_like(weight)
         ws, nws = _wgrad_workspace(Cin, Cout, k, x.device)
-        if transposed:
-            rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, 2 * Din, H, W, 3, 2, 1, 1,
-                                          dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _lib.ptr(ws), nws, _stream())
-        else:
-            rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, Din, H, W, k, stride, dilation,
-                                          padding, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _lib.ptr(ws), nws, _stream())
+        defer = _WGRAD_DEFER if (_WGRAD_DEFER is not None and _WGRAD_DEFER.single_use(weight)) else None
+        was = L.ts_conv_wgrad_defer(1) if defer is not None else 0
+        try:
+            if transposed:
+                rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), B, Cout, Cin, 2 * Din, H, W, 3, 2, 1, 1,
+                                              dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), _lib.ptr(ws), nws, _stream())
+            else:
+                rc = L.ts_conv3d_d_bwd_weight(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, Cin, Cout, Din, H, W, k, stride, dilation,
+                                              padding, x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), _lib.ptr(ws), nws, _stream())
+        finally:
+            if defer is not None:
+                L.ts_conv_wgrad_defer(was)
+                defer.keep.append(ws)
         _lib.check(rc, "ts_conv3d_d_bwd_weight")
     return dx, dw
 
@@ -905,6 +985,8 @@ def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False)
     'ReLU'; family 'hw' geom (stride, dilation, transposed) / family 'd' geom (stride, dilation, padding, transposed)."""
     # parameters / buffers straight from the module's dictionaries: nn.Module.__getattr__ (the fallback every `bn.weight`,
     # `bn.running_mean` ... goes through) was ~10 lookups x 180 wrappers per frame
+    if _WGRAD_DEFER is not None and weight.requires_grad and torch.is_grad_enabled():
+        _WGRAD_DEFER.used(weight)          # (counted where a backward will follow: no_grad frames do not count)
     d, P, Bf = bn.__dict__, bn._parameters, bn._buffers
     rmean = Bf.get("running_mean")
     training = d["training"] or rmean is None
@@ -953,6 +1035,8 @@ def conv3d_supported(weight_shape, stride, padding, dilation, groups, transposed
 def conv3d(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1)):
     """F.conv3d on the HIP kernels for the (1,3,3) / (k,1,1) families (fp32, GPU)."""
     kind = conv3d_supported(tuple(weight.shape), stride, padding, dilation, 1)
+    if _WGRAD_DEFER is not None and weight.requires_grad and torch.is_grad_enabled():
+        _WGRAD_DEFER.used(weight)
     if kind == "hw":
         y = _Conv3dHW.apply(x, weight, stride[1], dilation[1], False)
     elif kind == "d":
@@ -966,6 +1050,8 @@ def conv3d(x, weight, bias=None, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(
 def conv_transpose3d(x, weight, bias=None, stride=(1, 2, 2), padding=(0, 1, 1), output_padding=(0, 1, 1)):
     """F.conv_transpose3d on the HIP kernels: (1,3,3) stride (1,2,2) or (3,1,1) stride (2,1,1), padding 1, output_padding 1."""
     kind = conv3d_supported(tuple(weight.shape), stride, padding, (1, 1, 1), 1, True, output_padding)
+    if _WGRAD_DEFER is not None and weight.requires_grad and torch.is_grad_enabled():
+        _WGRAD_DEFER.used(weight)
     if kind == "hw":
         y = _Conv3dHW.apply(x, weight, 2, 1, True)
     elif kind == "d":

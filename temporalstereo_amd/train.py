@@ -236,6 +236,9 @@ class TrainStep:
         # (three table-driven launches + one per bf16-split copy; round 4 tried this with a full rebuild per step -- ~2,000
         # framework launches -- and lost).  Built lazily at the first step with previous frames; TS_TRAIN_NATIVE_PREV=0 keeps the
         # module path for them.
+        # one wgrad_finish launch per step instead of one per layer (functional.WgradDefer); not when gradient buckets go out during
+        # backward (their hooks read .grad as soon as it arrives)
+        self.wgrad_defer = TF.WgradDefer() if (on_gpu and self.buckets is None and os.environ.get("TS_TRAIN_WGRAD_DEFER", "1") != "0") else None
         self._native_prev = None
         self._use_native_prev = on_gpu and os.environ.get("TS_TRAIN_NATIVE_PREV", "1") != "0"
         # (Tried and dropped in round 3: the weight-gradient launches on a forked side stream inside the capture -- they depend only on
@@ -302,6 +305,7 @@ class TrainStep:
         """frames: list of (left_feats, right_feats, left_image, right_image), oldest first; poses[t] = (T_now, inv_T_past)."""
         net = self.net
         with (self.layouts if self.layouts is not None else contextlib.nullcontext()), \
+                (self.wgrad_defer if self.wgrad_defer is not None else contextlib.nullcontext()), \
                 (self.folds if (self.folds is not None and len(frames) > 1) else contextlib.nullcontext()):
             if self.layouts is not None:
                 self.layouts.refresh()
@@ -336,6 +340,8 @@ class TrainStep:
                 losses.update(self.wars(costs, offs, samples, gt))
                 total = torch.stack(list(losses.values())).sum()
             total.backward()
+            if self.wgrad_defer is not None:
+                self.wgrad_defer.flush()                 # every deferred weight gradient is final from here on
         return total.detach()
 
     # ------------------------------------------------------------------------------------------------------------

@@ -126,6 +126,9 @@ int ts_bn_sync_merge(const float* gathered, int world, int C, float* mean, float
  * ABI 9: channels of at most ts_bn_set_small_elems() elements (B*N; default below, TS_BN_SMALL_ELEMS) take ONE launch each way -- a
  * workgroup per channel does both passes (per-thread fp32 partial sums combined in double: the same statistics to rounding). */
 long long ts_bn_set_small_elems(long long n);   /* returns the previous bound; n < 0 only queries */
+/* out[c] = sum over batch and pixels of x [B,C,N] (a convolution's bias gradient), deterministic; workspace: ts_bn_workspace_bytes(B, C, N) */
+int ts_channel_sum_fwd(const float* x, float* out, void* workspace, int B, int C, long long N, long long bstride, long long cstride,
+                       void* stream);
 int ts_bn_train_fwd(const float* x, float* mean, float* var, float* running_mean, float* running_var, float momentum,
                     long long* num_batches_tracked, const float* gamma, const float* beta, float* out, void* workspace,
                     int B, int C, long long N, long long x_bstride, long long x_cstride, long long out_bstride,

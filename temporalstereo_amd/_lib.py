@@ -86,6 +86,7 @@ SIGNATURES = {
     "ts_peer_free": (c_int, [c_ptr]),
     "ts_peer_status": (c_int, [c_ptr, ctypes.POINTER(c_int), c_ptr]),
     "ts_bn_set_small_elems": (ctypes.c_longlong, [ctypes.c_longlong]),
+    "ts_channel_sum_fwd": (c_int, [c_f32p, c_f32p, c_ptr, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_ptr]),
     "ts_peer_status_async": (c_int, [c_ptr, c_ptr, c_ptr]),
     "ts_peer_set_timeout_ms": (ctypes.c_longlong, [ctypes.c_longlong]),
     "ts_peer_reset": (c_int, [c_ptr, c_ptr]),

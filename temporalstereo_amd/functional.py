@@ -434,6 +434,17 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, a
     return x, y, (B, Cin, Cout, D, H, W, stride, dilation, transposed)
 
 
+def _channel_sum(dy):
+    """dy [B, C, ...] -> [C]: sum over batch and pixels (a convolution's bias gradient) on ts_channel_sum_fwd."""
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    B, C = dy.shape[0], dy.shape[1]
+    N = dy.numel() // (B * C)
+    out = torch.empty(C, device=dy.device, dtype=torch.float32)
+    ws = torch.empty(_q("ts_bn_workspace_bytes", B, C, N), device=dy.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().ts_channel_sum_fwd(_lib.ptr(dy), _lib.ptr(out), _lib.ptr(ws), B, C, N, C * N, N, _stream()), "ts_channel_sum_fwd")
+    return out
+
+
 class WgradDefer:
     """The ~95 wgrad_finish launches of a training step's backward as ONE (ts_conv_wgrad_finish_many, csrc/conv3d.hip).
 
@@ -636,7 +647,7 @@ class _Conv3dD(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx, dw = _d_backward(x, weight, dy, ctx.geom, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        gb = dy.sum(dim=(0, 2, 3, 4)) if (ctx.has_bias and ctx.needs_input_grad[6]) else None
+        gb = _channel_sum(dy) if (ctx.has_bias and ctx.needs_input_grad[6]) else None
         return dx, dw, None, None, None, None, gb
 
 
@@ -744,7 +755,7 @@ class _Deconv2dK4S2(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx, dw = _dc_backward(x, weight, dy, ctx.geom, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        gb = dy.sum(dim=(0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gb = _channel_sum(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, gb
 
 
@@ -976,7 +987,7 @@ class _ConvBNAct(torch.autograd.Function):
             dx, dw = _d_backward(x, weight, dy, cg, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         gbias = None
         if has_bias and ctx.needs_input_grad[2]:
-            gbias = dy.sum(dim=[0] + list(range(2, dy.dim())))     # == 0 up to rounding in train mode (BatchNorm removes the mean)
+            gbias = _channel_sum(dy)                               # == 0 up to rounding in train mode (BatchNorm removes the mean)
         return dx, dw, gbias, gaffine[0], gaffine[1], None, None, None, None, None, None, None, None, None, None, None
 
 

@@ -1036,6 +1036,7 @@ struct WG {
   int stride, dil, pad, k;
   int tiles_x, tiles_per_plane, ntiles;       // ntiles = B * Do * tiles_per_plane
   int cop;                                    // LDS pitch of a dY pixel row (== 17 mod 32)
+  int vec;                                    // MODE_HW: 16-byte staging of X (W % 4 == 0, aligned planes)
   long long x_bstride, x_cstride, dy_bstride, dy_cstride;
   unsigned x_bytes, dy_bytes;
 };
@@ -1082,6 +1083,41 @@ wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* _
     if (MODE == MODE_HW) { ty0 = (sp / p.tiles_x) * TRW; tx0 = (sp % p.tiles_x) * 32; }
     __syncthreads();                                             // the previous tile's fragments are consumed
     // ---- stage X: 16 channels of the haloed input tile (zero padding / ragged channels via out-of-range offsets)
+    // Vector form (round 5; W % 4 == 0, 16-byte aligned planes): a tile row as ALIGNED quads from column tx0 ST - 4 on -- one
+    // dwordx4 per (row, quad, channel) instead of four dword gathers, whole cache lines instead of 136-byte runs (this staging, not
+    // the matrix phase, is what the kernel's duration follows: the first layers' 50-198 MB inputs streamed at 0.6-0.8 TB/s).
+    if constexpr (MODE == MODE_HW) {
+      if (p.vec) {
+        constexpr int QPR = (in_cols + 4 - DL + 3) / 4;                 // quads per tile row
+        constexpr int SL = in_rows * QPR;                              // (row, quad) slots of a channel plane
+        constexpr int CPT = (SL <= 128) ? 8 : 16;                      // channels per thread: two threads share a slot where they fit
+        const int slot = (SL <= 128) ? static_cast<int>(threadIdx.x & 127) : static_cast<int>(threadIdx.x);
+        const int cfirst = (SL <= 128) ? static_cast<int>(threadIdx.x >> 7) * 8 : 0;
+        if (slot < SL) {
+          const int cy = slot / QPR, qx = slot - cy * QPR;
+          const int gy = ty0 * ST - DL + cy, gx4 = tx0 * ST - 4 + 4 * qx;
+          const bool rowok = gy >= 0 && gy < p.H && gx4 >= 0 && gx4 < p.W;      // W % 4 == 0: a quad is inside the image or outside it
+          const unsigned off = rowok ? (static_cast<unsigned>(od) * HW + static_cast<unsigned>(gy) * p.W + gx4) * 4u : kOOB;
+          u32x4 v[CPT];
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) {
+            const int ch = ci0 + cfirst + c;
+            const unsigned so = static_cast<unsigned>(min(ch, p.Cin - 1)) * static_cast<unsigned>(p.x_cstride) * 4u;
+            v[c] = __builtin_amdgcn_raw_buffer_load_b128(xr, (ch < p.Cin) ? off : kOOB, so, 0);
+          }
+          const int cx0 = 4 * qx - (4 - DL);                             // tile column of the quad's first element
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int cx = cx0 + e;
+            if (cx >= 0 && cx < in_cols) {
+#pragma unroll
+              for (int c = 0; c < CPT; ++c) xs[(cy * in_cols + cx) * CIP + cfirst + c] = __uint_as_float(v[c][e]);
+            }
+          }
+        }
+      }
+    }
+    if (MODE != MODE_HW || !p.vec) {
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
       const int i = threadIdx.x + 256 * q;
@@ -1107,6 +1143,7 @@ wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* _
 #pragma unroll
         for (int c = 0; c < 16; ++c) xs[i * CIP + c] = v[c];
       }
+    }
     }
     // ---- stage dY: every output channel of the tile's pixels
     for (int i = threadIdx.x; i < NPX; i += 256) {
@@ -1256,9 +1293,23 @@ wgrad_finish_many(const WgradFinishDesc* __restrict__ table, int n) {
 
 // workgroups per input-channel block: the chip filled about twice over all blocks (every workgroup ends
 // with one partial of `items` KiB, so more of them only lengthens wgrad_finish)
-int wgrad_groups(int ciblocks) {
-  static const long long per_cu_env = env_ll("TS_WGRAD_GROUPS_PER_CU", 2);
-  const int per_cu = per_cu_env > 0 ? static_cast<int>(per_cu_env) : 2;
+// Round 5: as many workgroups as are RESIDENT at once -- floor(160 KB / LDS footprint) per CU, at most 4 -- and never one more: the
+// round-3 rule (ceil(2 x 256 / blocks)) gave the coarse first layer 24 x 22 = 528 workgroups of 73 KB, i.e. one full round of 512 and
+// a tail of 16 (120 us; 23 x 22 = 506: 94 us), and the Cout <= 16 first layers of the sampled levels (40 KB: three fit) two per CU
+// (304 -> 8 on 5 x 136 x 240: 262 -> 214 us with three).  Layers whose workgroups fit once per CU keep two rounds.
+// TS_WGRAD_GROUPS_PER_CU > 0 forces the old rule with that many per CU.
+int wgrad_groups(int ciblocks, size_t lds_bytes) {
+  static const long long per_cu_env = env_ll("TS_WGRAD_GROUPS_PER_CU", 0);
+  if (per_cu_env > 0) return (static_cast<int>(per_cu_env) * ts::kNumCU + ciblocks - 1) / ciblocks;
+  int fit = static_cast<int>((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+  fit = fit < 1 ? 1 : (fit > 4 ? 4 : fit);
+  const int target = (fit >= 2 ? fit : 2) * ts::kNumCU;
+  const int g = target / ciblocks;
+  return g < 1 ? 1 : g;
+}
+int wgrad_groups_max(int ciblocks) {      // what the workspace is sized for
+  static const long long per_cu_env = env_ll("TS_WGRAD_GROUPS_PER_CU", 0);
+  const int per_cu = per_cu_env > 4 ? static_cast<int>(per_cu_env) : 4;
   return (per_cu * ts::kNumCU + ciblocks - 1) / ciblocks;
 }
 
@@ -1280,9 +1331,11 @@ int launch_wgrad(const float* x, const float* dy, float* dw, WG p, void* workspa
     p.tiles_per_plane = (p.Ho * p.Wo + 255) / 256;
   }
   p.ntiles = p.B * p.Do * p.tiles_per_plane;
+  static const bool vec_ok = env_not_zero("TS_WGRAD_VEC");
+  p.vec = (MODE == MODE_HW && vec_ok && p.W % 4 == 0 && ts::aligned16(x) && p.x_cstride % 4 == 0 && p.x_bstride % 4 == 0) ? 1 : 0;
   const int ciblocks = (p.Cin + 15) / 16;
   const int cob = (p.Cout + 15) / 16, nitems = KT * cob;
-  int gx = wgrad_groups(ciblocks);
+  int gx = wgrad_groups(ciblocks, lds);
   if (gx > p.ntiles) gx = p.ntiles;
   if (gx < 1) gx = 1;
   const size_t need = static_cast<size_t>(gx) * ciblocks * nitems * 256 * sizeof(float);
@@ -1716,7 +1769,7 @@ extern "C" int ts_conv3d_hw_bwd_data(const float* dy, const float* w_b, float* d
 extern "C" size_t ts_conv3d_bwd_weight_workspace_bytes(int Cin, int Cout, int taps) {
   if (Cin <= 0 || Cout <= 0 || taps <= 0) return 0;
   const int ciblocks = (Cin + 15) / 16, cob = (Cout + 15) / 16;
-  return static_cast<size_t>(wgrad_groups(ciblocks)) * ciblocks * taps * cob * 256 * sizeof(float);
+  return static_cast<size_t>(wgrad_groups_max(ciblocks)) * ciblocks * taps * cob * 256 * sizeof(float);
 }
 
 extern "C" int ts_conv3d_hw_bwd_weight(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int D, int H,

@@ -95,6 +95,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_deconv2d_k4s2_weight_to_conv3), TS_PLAN_OP(ts_deconv2d_k4s2_wgrad_from_conv3),
     TS_PLAN_OP(ts_clip_rmsprop_step),       TS_PLAN_OP(ts_bn_sync_merge),
     TS_PLAN_OP(ts_bn_fold_many),
+    TS_PLAN_OP(ts_conv_weight_layout_many2), TS_PLAN_OP(ts_conv_wgrad_finish_many), TS_PLAN_OP(ts_channel_sum_fwd),
 };
 
 struct Call {

@@ -13,7 +13,7 @@ L = _lib.lib()
 st = _lib.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = [  # B, Cin, Cout, D, H, W, stride
     (1, 32, 32, 1, 272, 480, 1), (1, 64, 32, 1, 272, 480, 1), (1, 128, 32, 1, 272, 480, 1), (1, 64, 64, 1, 136, 240, 1),
-    (1, 176, 8, 5, 136, 240, 1), (1, 32, 64, 1, 272, 480, 2), (1, 352, 32, 12, 34, 60, 1), (1, 32, 32, 12, 34, 60, 1), (1, 16, 16, 5, 68, 120, 1),
+    (1, 176, 8, 5, 136, 240, 1), (1, 304, 8, 5, 136, 240, 1), (1, 304, 16, 5, 68, 120, 1), (1, 32, 64, 1, 272, 480, 2), (1, 352, 32, 12, 34, 60, 1), (1, 32, 32, 12, 34, 60, 1), (1, 16, 16, 5, 68, 120, 1),
 ]
 for B, Cin, Cout, D, H, W, s in SHAPES:
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1

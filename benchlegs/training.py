@@ -44,6 +44,8 @@ def training_leg(dev, rank, world, steps, warmup, batch, seed, graph=False, sync
         ex0 = TF._EXCHANGES[0]
         loss = step(frames, gt, K, poses)             # (graph: the capture -- two warm-up passes and the capture issue the exchanges 3x)
         per_step = (TF._EXCHANGES[0] - ex0) // (3 if graph else 1)
+        if graph:       # inputs resident where the captured step reads them (the contract of the headline's inputs='bind')
+            frames, gt, K, poses = step.bound_inputs()
         for _ in range(max(warmup - 1, 0)):
             loss = step(frames, gt, K, poses)
         torch.cuda.synchronize()

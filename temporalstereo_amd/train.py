@@ -385,6 +385,14 @@ class TrainStep:
         with torch.cuda.graph(self._g):
             self._loss = self._forward_backward(*self._static)
 
+    def bound_inputs(self):
+        """graph=True, after the first call: the (frames, gt, K, poses) tensors the captured step reads.  A producer that writes the
+        next sample INTO them (the data pipeline's device-side collate, the backbone's outputs) and passes them back in saves the
+        ~25 device-to-device copies per step that arbitrary inputs need -- the `inputs='bind'` contract of InferenceEngine."""
+        if not self.graph or self._static is None:
+            raise RuntimeError("bound_inputs(): a graph=True step, after its first call")
+        return self._static
+
     def _all_reduce_flat(self):
         grads = [p.grad for p in self.params if p.grad is not None]
         flat = torch._utils._flatten_dense_tensors(grads)
@@ -407,7 +415,8 @@ class TrainStep:
                     raise RuntimeError("TrainStep(graph=True): this call's inputs do not have the structure / shapes / dtypes the graph was "
                                        "captured with (%d tensors); build a new TrainStep for a new geometry" % len(dsts))
                 for dst, src in zip(dsts, srcs):
-                    dst.detach().copy_(src, non_blocking=True)
+                    if dst.data_ptr() != src.data_ptr():         # (a caller that fills `bound_inputs()` in place copies nothing)
+                        dst.detach().copy_(src, non_blocking=True)
             self._g.replay()
             loss = self._loss.clone()                                # the graph's own buffer is overwritten by the next replay
             t1 = time.perf_counter()

@@ -1687,8 +1687,12 @@ int launch_dense(const float* left, const float* right, const float* disp, float
   TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(disp);
   if (MODE != 1) TS_REQUIRE_PTR(out);
   if (MODE != 0) TS_REQUIRE_PTR(maxbits);
-  const bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(disp) && (MODE == 1 || ts::aligned16(out));
-  const size_t lds_bytes = (static_cast<size_t>(2) * TRD * 4 * s.Wqp * 4 + static_cast<size_t>(GRP) * TRD * 4 * s.Wq) * sizeof(float) + (vec ? 1024 * 16 : 0);
+  bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(disp) && (MODE == 1 || ts::aligned16(out));
+  const size_t base_bytes = (static_cast<size_t>(2) * TRD * 4 * s.Wqp * 4 + static_cast<size_t>(GRP) * TRD * 4 * s.Wq) * sizeof(float);
+  // the run-order (16-byte) form keeps 16 KB of candidates in LDS on top of the row staging: where that no longer fits (aligned maps
+  // of roughly 384 <= W <= 508) the row-order form serves, as it did before the run-order form existed
+  if (vec && base_bytes + 1024 * 16 > 64 * 1024) vec = false;
+  const size_t lds_bytes = base_bytes + (vec ? 1024 * 16 : 0);
   TS_REQUIRE(lds_bytes <= 64 * 1024, TS_ERR_UNSUPPORTED, "cat/dif_fms: W=%d too wide for the row staging", W);
   const int CO = (MODE == 0) ? 2 * C : C;
   TS_REQUIRE(static_cast<unsigned long long>(CO) * D * H * W * 4ull < (1ull << 32), TS_ERR_UNSUPPORTED,

@@ -393,6 +393,7 @@ extern "C" int ts_conv3d_hw_x6s_fwd(const float* x, const void* w6, const float*
     p.in_bytes = static_cast<unsigned>(in_b); p.out_bytes = static_cast<unsigned>(out_b); p.w_bytes = static_cast<unsigned>(w_b);
   }
   hipStream_t st = ts::as_stream(stream);
+  TS_REQUIRE(static_cast<long long>(B) * ((p.coutp + 15) / 16) <= 65535, TS_ERR_UNSUPPORTED, "conv3d_hw_x6s: batch x channel groups beyond the grid's z extent");
   if (mode == XS_S2) {
     p.tiles_x = (p.Wo + 31) / 32;
     const int tiles = ((p.Ho + 3) / 4) * p.tiles_x;

@@ -282,7 +282,8 @@ def main():
 
         # ---- everything below is outside the timed region
         # ------------------------------------------------------------------------
-        roofline = k1legs.run(k1, launched, runner, dev, a.batch, max(a.steps, 200), mode.startswith("native")) if rank == 0 else None
+        roofline = k1legs.run(k1, launched, runner, dev, a.batch, max(a.steps, 200), mode.startswith("native"),
+                              ceilings=not a.calibrate) if rank == 0 else None
         if a.calibrate and rank == 0:
             from temporalstereo_amd import _lib
             nbytes = 1 << 30

@@ -225,11 +225,13 @@ def roofline(times, launched, batch, iters, ceilings, b4, fused):
     return r
 
 
-def run(k1, launched, runner, dev, batch, iters, native):
-    """All K1 measurements of a bench run (rank 0, after the timed region) -> the `roofline` object."""
+def run(k1, launched, runner, dev, batch, iters, native, ceilings=True):
+    """All K1 measurements of a bench run (rank 0, after the timed region) -> the `roofline` object.
+    ceilings=False (bench.py --calibrate: a PMC pass): no fill / copy streams of other sizes, which the per-(kernel, grid) averages of
+    tools/k1_traffic.py would mix into its 1 GiB calibration launches."""
     times = k1.measure(iters)
     b4 = beyond_infinity_cache(k1, batch) if native else None
     fused = fused_first_layer(k1, runner, batch) if native else None
     out_bytes = 4 * batch * (4 * DIMS['precise']['in_planes'] + 3 * (2 * DIMS['precise']['in_planes'] // 8)) * 5 * (RUN_H // 4) * (RUN_W // 4)
-    ceilings = stream_ceilings(dev, sorted({out_bytes, out_bytes // batch * max(4, batch)}))      # this launch; the four-pair launch
+    ceilings = stream_ceilings(dev, sorted({out_bytes, out_bytes // batch * max(4, batch)})) if ceilings else {}   # this launch; the four-pair one
     return roofline(times, launched, batch, iters, ceilings, b4, fused)

@@ -102,6 +102,11 @@ int ts_block_cost_sampled_bwd(const float* left, const float* right, const float
                               const float* grad_out, float* grad_left, float* grad_right,
                               float* grad_disp, void* workspace,
                               int B, int C, int H, int W, int D, int scales, void* stream);
+/* ... of ts_block_cost_sampled_warped_fwd (ABI 9): grad_out [B, C + scales*C/8, D, H, W], the volume without its reference half */
+int ts_block_cost_sampled_warped_bwd(const float* left, const float* right, const float* disp,
+                                     const float* grad_out, float* grad_left, float* grad_right,
+                                     float* grad_disp, void* workspace,
+                                     int B, int C, int H, int W, int D, int scales, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (+ activation) of the convolution wrappers in TRAIN mode (layers/basic_layers.py:194-235: conv -> norm ->

@@ -38,6 +38,7 @@ SIGNATURES = {
     "ts_block_cost_bwd_workspace_bytes": (c_size, [c_int] * 6),
     "ts_block_cost_int_bwd": (c_int, [c_f32p] * 5 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_block_cost_sampled_bwd": (c_int, [c_f32p] * 7 + [c_ptr] + [c_int] * 6 + [c_ptr]),
+    "ts_block_cost_sampled_warped_bwd": (c_int, [c_f32p] * 7 + [c_ptr] + [c_int] * 6 + [c_ptr]),
     "ts_calib_stream": (c_int, [c_int, c_ptr, c_ptr, c_size, c_ptr]),
     "ts_candidates_in_range_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [c_ptr]),
     "ts_candidates_in_range_bwd": (c_int, [c_f32p] * 5 + [c_int] * 5 + [c_ptr]),

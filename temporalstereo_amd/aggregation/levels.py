@@ -52,9 +52,26 @@ def _candidates_in_range(low, high):
     return torch.cat([span * s + base for s in (0.0, 0.375, 0.5, 0.625, 1.0)], dim=1)
 
 
+import os as _os
+_SPLIT_FIRST = _os.environ.get("TS_SPLIT_FIRST_LAYER", "1") != "0"
+
+
 class _Level(nn.Module):
     def weight_init(self):
         _reference_init(self)
+
+    def _sampled_init3d(self, left, right, disp_sample):
+        """init3d(block_cost(left, right, disp_sample)) of the sampled levels (fine.py:96-103, precise.py:88-91).  On the HIP path the
+        first (1,3,3) layer takes the volume WITHOUT its D-fold repeat of `left` and that half's share as a per-pixel term
+        (functional.first_layer_split): same function, 42 % fewer channels through the volume, the layer, and their three backward
+        kernels.  TS_SPLIT_FIRST_LAYER=0: the materialised form."""
+        first = self.init3d[0].conv[0]
+        if _SPLIT_FIRST and left.is_cuda and left.dtype == torch.float32 and first.stride[1] == 1 and first._fusable() is not False \
+                and TF.conv3d_supported(tuple(first.weight.shape), first.stride, first.padding, first.dilation, first.groups) == "hw":
+            vol = TF.block_cost_warped_ag(left, right, disp_sample, self.block_cost_scale)
+            y = self.init3d[0].conv[1](TF.first_layer_split(first, left, vol))
+            return self.init3d[2](self.init3d[1](y))
+        return self.init3d(TF.block_cost(left, right, disp_sample, self.block_cost_scale))
 
     def predict_disp(self, cost, disp_sample, off, k=2):
         """coarse.py:69-75 -> (disp_map, topk_disp, topk_cost), on ts_topk_softargmax_*."""
@@ -156,8 +173,7 @@ class FineAggregation(_Level):
 
     def forward(self, left, right, low_disparity, high_disparity, prev_info: dict):
         disp_sample = self.generate_disparity_sample(low_disparity, high_disparity, self.num_sample, prev_info)
-        raw_cost = TF.block_cost(left, right, disp_sample, self.block_cost_scale)
-        init_cost = self.init3d(raw_cost)
+        init_cost = self._sampled_init3d(left, right, disp_sample)
         init_cost, disp_sample = self._merge_memory(init_cost, disp_sample, prev_info)
         if self.spatial_fusion:
             init_cost = self.fuse(init_cost)
@@ -187,8 +203,7 @@ class PreciseAggregation(_Level):
         (spx2l, spx4l), (_, spx4r) = self.refinement.encoder(left_image, right_image)
         left, right = torch.cat([left, spx4l], dim=1), torch.cat([right, spx4r], dim=1)
         disp_sample = self.generate_disparity_sample(low_disparity, high_disparity, self.num_sample)
-        raw_cost = TF.block_cost(left, right, disp_sample, self.block_cost_scale)
-        init_cost = self.init3d(raw_cost)
+        init_cost = self._sampled_init3d(left, right, disp_sample)
         final_cost, off = self.pred_heads(init_cost)
         disp, memory_sample, memory_volume = self.predict_disp(final_cost, disp_sample, off, k=self.topk)
         full_disp = self.refinement.decoder(disp, left, spx2l)

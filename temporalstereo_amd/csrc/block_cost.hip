@@ -1341,8 +1341,11 @@ block_cost_bwd_main(const float* __restrict__ L, const float* __restrict__ R, co
         if (y < H) {
           const size_t rowoff = static_cast<size_t>(y) * W;
           float dmain[4], dwarp[4] = {0.f, 0.f, 0.f, 0.f};
-          unpack(ld4<VEC>(dplane0 + chan * cstride + rowoff, x4, W), dmain);
-          if constexpr (SAMPLED) unpack(ld4<VEC>(dplane0 + (chan + C) * cstride + rowoff, x4, W), dwarp);
+          // omit_ref (the volume without its reference half, ts_block_cost_sampled_warped_*): no gradient arrives for it, the warped
+          // half starts at channel 0 (s.tch)
+          if (!s.omit_ref) unpack(ld4<VEC>(dplane0 + chan * cstride + rowoff, x4, W), dmain);
+          else { dmain[0] = dmain[1] = dmain[2] = dmain[3] = 0.f; }
+          if constexpr (SAMPLED) unpack(ld4<VEC>(dplane0 + (chan + s.tch) * cstride + rowoff, x4, W), dwarp);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int x = x4 + k;
@@ -1511,8 +1514,11 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
           float lv[4], dg0r[4], dmain[4], dwarp[4] = {0.f, 0.f, 0.f, 0.f};
           unpack(ld4<VEC>(Lg + c * HW + rowoff, x4, W), lv);
           unpack(ld4<VEC>(dplane0 + static_cast<size_t>(s.mainC + g) * cstride + rowoff, x4, W), dg0r);
-          unpack(ld4<VEC>(dplane0 + chan * cstride + rowoff, x4, W), dmain);
-          if constexpr (SAMPLED) unpack(ld4<VEC>(dplane0 + (chan + C) * cstride + rowoff, x4, W), dwarp);
+          // omit_ref (the volume without its reference half, ts_block_cost_sampled_warped_*): no gradient arrives for it, the warped
+          // half starts at channel 0 (s.tch)
+          if (!s.omit_ref) unpack(ld4<VEC>(dplane0 + chan * cstride + rowoff, x4, W), dmain);
+          else { dmain[0] = dmain[1] = dmain[2] = dmain[3] = 0.f; }
+          if constexpr (SAMPLED) unpack(ld4<VEC>(dplane0 + (chan + s.tch) * cstride + rowoff, x4, W), dwarp);
           int pend_a = -1;
           float pend_v = 0.f;
 #pragma unroll
@@ -1588,9 +1594,9 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
 template <bool SAMPLED>
 int launch_bwd(const float* left, const float* right, const float* disp, const float* grad_out,
                float* grad_left, float* grad_right, float* grad_disp, void* workspace,
-               int B, int C, int H, int W, int D, int scales, void* stream) {
+               int B, int C, int H, int W, int D, int scales, void* stream, int omit_ref = 0) {
   Shape s;
-  if (int rc = make_shape(s, SAMPLED, B, C, H, W, D, scales)) return rc;
+  if (int rc = make_shape(s, SAMPLED, B, C, H, W, D, scales, omit_ref)) return rc;
   TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(grad_out);
   if (SAMPLED) TS_REQUIRE_PTR(disp);
   if (scales > 1) TS_REQUIRE_PTR(workspace);
@@ -1733,6 +1739,16 @@ extern "C" int ts_block_cost_int_bwd(const float* left, const float* right, cons
                                      int B, int C, int H, int W, int D, int scales, void* stream) {
   return launch_bwd<false>(left, right, nullptr, grad_out, grad_left, grad_right, nullptr, workspace,
                            B, C, H, W, D, scales, stream);
+}
+
+// Backward of ts_block_cost_sampled_warped_fwd: grad_out [B, C + scales*C/8, D, H, W] (the volume without its reference half; round 5:
+// the first layer of a sampled level takes the D-invariant left half as a per-pixel term in training too, functional.first_layer_split)
+extern "C" int ts_block_cost_sampled_warped_bwd(const float* left, const float* right, const float* disp,
+                                                const float* grad_out, float* grad_left, float* grad_right,
+                                                float* grad_disp, void* workspace,
+                                                int B, int C, int H, int W, int D, int scales, void* stream) {
+  return launch_bwd<true>(left, right, disp, grad_out, grad_left, grad_right, grad_disp, workspace,
+                          B, C, H, W, D, scales, stream, 1);
 }
 
 extern "C" int ts_block_cost_sampled_bwd(const float* left, const float* right, const float* disp,

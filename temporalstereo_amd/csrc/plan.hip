@@ -96,6 +96,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_clip_rmsprop_step),       TS_PLAN_OP(ts_bn_sync_merge),
     TS_PLAN_OP(ts_bn_fold_many),
     TS_PLAN_OP(ts_conv_weight_layout_many2), TS_PLAN_OP(ts_conv_wgrad_finish_many), TS_PLAN_OP(ts_channel_sum_fwd),
+    TS_PLAN_OP(ts_block_cost_sampled_warped_bwd),
 };
 
 struct Call {

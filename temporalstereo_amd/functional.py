@@ -408,7 +408,7 @@ def _shift_vec(bias, n):
     return v
 
 
-def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, act=0):
+def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, act=0, addend=None):
     """Raw Conv3d (1,3,3) [padding == dilation] / ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1 (+ bias); with
     `fold` = (scale, shift) the epilogue applies act(y * scale + shift) (an eval-mode BatchNorm folded in, bias included)."""
     _require_gpu(x, weight)
@@ -427,9 +427,13 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, a
     wsb = _q("ts_conv3d_hw_workspace_bytes", B, Cin, Cout, D, H, W, stride, int(transposed))
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
     sc, sh = fold if fold is not None else (None, _shift_vec(bias, _cpad(Cout)))
+    if addend is not None:          # [B, Cout, 1, Ho, Wo] (or [B, Cout, Ho, Wo]): added to every depth plane's raw sum
+        addend = _lib.contiguous(addend)
+        if addend.numel() != B * Cout * Ho * Wo or transposed:
+            raise ValueError("conv addend: one [B, Cout, Ho, Wo] plane per batch item (stride-1 / stride-2 forms only)")
     rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(w_t), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, D, H, W, stride, dilation,
                             int(transposed), int(act), 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
-                            None, 0, _lib.ptr(ws), wsb, _stream())
+                            _lib.ptr(addend), (Cout * Ho * Wo) if addend is not None else 0, _lib.ptr(ws), wsb, _stream())
     _lib.check(rc, "ts_conv3d_hw_fwd")
     return x, y, (B, Cin, Cout, D, H, W, stride, dilation, transposed)
 
@@ -865,19 +869,23 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, family, geom, eps, momentum, act, training, group,
-                counter=None, may_fold=False):
+                counter=None, may_fold=False, addend=None):
+        # addend (family "hw" only): [B, Cout, 1, Ho, Wo], added to every depth plane of the raw convolution (first_layer_split)
+        ctx.has_addend = addend is not None
+        if addend is not None and family != "hw":
+            raise ValueError("conv_bn_act: an addend needs the (1,3,3) family")
         # may_fold is decided by conv_bn_act in the CALLER's grad mode (inside Function.forward grad mode is always off): the folded
         # path keeps nothing for backward, so it is for calls through which no gradient can flow
         if _FOLDS is not None and not training and may_fold and running_mean is not None:
             fold = _FOLDS.get(gamma, beta, running_mean, running_var, bias, eps, weight.shape[1] if (family == "dc" or geom[-1]) else weight.shape[0])
             if fold is not None:        # eval frame of a training step: conv -> BatchNorm -> activation in the convolution's epilogue
                 if family == "hw":
-                    return _hw_forward(x, weight, geom[0], geom[1], geom[2], None, fold, act)[1]
+                    return _hw_forward(x, weight, geom[0], geom[1], geom[2], None, fold, act, addend=addend)[1]
                 if family == "dc":
                     return _dc_forward(x, weight, None, fold, act)[1]
                 return _d_forward(x, weight, geom[0], geom[1], geom[2], geom[3], None, fold, act)[1]
         if family == "hw":
-            x, y, cg = _hw_forward(x, weight, geom[0], geom[1], geom[2], bias)
+            x, y, cg = _hw_forward(x, weight, geom[0], geom[1], geom[2], bias, addend=addend)
         elif family == "dc":
             x, y, cg = _dc_forward(x, weight, bias)
         else:
@@ -988,10 +996,13 @@ class _ConvBNAct(torch.autograd.Function):
         gbias = None
         if has_bias and ctx.needs_input_grad[2]:
             gbias = _channel_sum(dy)                               # == 0 up to rounding in train mode (BatchNorm removes the mean)
-        return dx, dw, gbias, gaffine[0], gaffine[1], None, None, None, None, None, None, None, None, None, None, None
+        gadd = None
+        if ctx.has_addend and ctx.needs_input_grad[16]:
+            gadd = dy.sum(dim=2, keepdim=True)                     # the D-invariant term reaches every depth plane
+        return dx, dw, gbias, gaffine[0], gaffine[1], None, None, None, None, None, None, None, None, None, None, None, gadd
 
 
-def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False):
+def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False, addend=None):
     """Fused wrapper forward (see _ConvBNAct).  `bn`: an nn.BatchNorm*d / dist.SyncBatchNorm module; `activation`: None | 'SiLU' |
     'ReLU'; family 'hw' geom (stride, dilation, transposed) / family 'd' geom (stride, dilation, padding, transposed)."""
     # parameters / buffers straight from the module's dictionaries: nn.Module.__getattr__ (the fallback every `bn.weight`,
@@ -1011,9 +1022,9 @@ def conv_bn_act(x, weight, bias, bn, activation, family, geom, transposed=False)
     counter = Bf.get("num_batches_tracked") if (training and d["track_running_stats"]) else None     # incremented by the statistics launch
     gamma, beta = P["weight"], P["bias"]
     may_fold = (not training) and (not torch.is_grad_enabled() or not any(
-        t is not None and t.requires_grad for t in (x, weight, bias, gamma, beta)))
+        t is not None and t.requires_grad for t in (x, weight, bias, gamma, beta, addend)))
     return _ConvBNAct.apply(x, weight, bias, gamma, beta, rmean, Bf.get("running_var"), family, geom, d["eps"], momentum,
-                            BN_ACT[activation], training, group, counter, may_fold)
+                            BN_ACT[activation], training, group, counter, may_fold, addend)
 
 
 def conv3d_supported(weight_shape, stride, padding, dilation, groups, transposed=False, output_padding=(0, 0, 0)):
@@ -1275,6 +1286,72 @@ def block_cost_warped(reference_fm, target_fm, disp_sample, block_cost_scale=3):
     rc = launch() if _k1_probe is None else _k1_probe((B, C, H, W, D, "warped"), launch)
     _lib.check(rc, "ts_block_cost_sampled_warped_fwd")
     return out
+
+
+class _BlockCostWarped(torch.autograd.Function):
+    """The sampled block_cost WITHOUT its first C channels (block_cost_warped) with autograd: ts_block_cost_sampled_warped_{fwd,bwd}.
+    The training path's first layer of a sampled level takes the D-invariant left half as a per-pixel term (first_layer_split)."""
+
+    @staticmethod
+    def forward(ctx, left, right, disp, scales):
+        out = block_cost_warped(left, right, disp, scales)
+        ctx.save_for_backward(_lib.contiguous(left), _lib.contiguous(right), _lib.contiguous(disp))
+        ctx.scales = int(scales)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        left, right, disp = ctx.saved_tensors
+        B, C, H, W = left.shape
+        D, scales = disp.shape[1], ctx.scales
+        L = _lib.lib()
+        grad_out = _lib.contiguous(grad_out)
+        gl = torch.empty_like(left) if ctx.needs_input_grad[0] else None
+        gr = torch.empty_like(right) if ctx.needs_input_grad[1] else None
+        gd = torch.empty_like(disp) if ctx.needs_input_grad[2] else None
+        ws = torch.empty(max(int(L.ts_block_cost_bwd_workspace_bytes(B, C, H, W, D, scales)), 256), device=left.device, dtype=torch.uint8)
+        _lib.check(L.ts_block_cost_sampled_warped_bwd(_lib.ptr(left), _lib.ptr(right), _lib.ptr(disp), _lib.ptr(grad_out), _lib.ptr(gl),
+                                                      _lib.ptr(gr), _lib.ptr(gd), _lib.ptr(ws), B, C, H, W, D, scales, _stream()),
+                   "ts_block_cost_sampled_warped_bwd")
+        return gl, gr, gd, None
+
+
+class _SplitWeight(torch.autograd.Function):
+    """weight [Cout, Cin, ...] -> (weight[:, :n], weight[:, n:]) as CONTIGUOUS tensors; backward: one concatenation."""
+
+    @staticmethod
+    def forward(ctx, weight, n):
+        ctx.n = int(n)
+        return weight[:, :n].contiguous(), weight[:, n:].contiguous()
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        return torch.cat([g1, g2], dim=1), None
+
+
+def first_layer_split(conv, left, volume):
+    """The (1,3,3) convolution + BatchNorm + activation over a sampled level's volume [left x D | warped right | corr]
+    (precise.py:88-91, fine.py:96-103 over block_cost.py:47-58) WITHOUT the left half in the volume: its channels are the left features
+    repeated over the D candidates (block_cost.py:51), so their share of the layer is a 2-D convolution of `left`, computed once per
+    pixel and added to every depth plane before the bias / BatchNorm -- in training as the inference engine has done since round 1.
+    `conv`: the layers.Conv3d wrapper (its weight covers all 2C + scales*C/8 input channels); `volume` = block_cost_warped_ag(...):
+    [B, C + scales*C/8, D, H, W].  The layer's forward reads 42 % fewer channels, its input gradient and weight gradient likewise, the
+    cost volume's backward receives no gradient for the half that is not there; the left term's own backward is two single-plane
+    launches on the sum over D of the layer's output gradient."""
+    C = left.shape[1]
+    w1, w2 = _SplitWeight.apply(conv._parameters["weight"], C)
+    dil = conv.dilation[1]
+    lt = _Conv3dHW.apply(left.unsqueeze(2), w1, 1, dil, False)                  # [B, Cout, 1, H, W], raw
+    act = conv._fusable()
+    if act is False or conv.stride[1] != 1:
+        raise NotImplementedError("first_layer_split: a stride-1 (1,3,3) convolution + BatchNorm (+ SiLU / ReLU)")
+    if _WGRAD_DEFER is not None:
+        _WGRAD_DEFER.used(w2)               # its gradient is concatenated with w1's DURING backward: never a deferred finish (counts as shared)
+    return conv_bn_act(volume, w2, conv._parameters["bias"], conv._modules["norm"], act, "hw", (1, dil, False), addend=lt)
+
+
+def block_cost_warped_ag(reference_fm, target_fm, disp_sample, block_cost_scale=3):
+    return _BlockCostWarped.apply(reference_fm, target_fm, disp_sample, int(block_cost_scale))
 
 
 def block_cost_corr(reference_fm, target_fm, disp_sample, block_cost_scale=3):

@@ -1250,6 +1250,27 @@ __device__ __forceinline__ void source_column(int x, int d, float dispv, int W, 
   }
 }
 
+// The same in two steps (round 5): the source POSITION of a pixel (the reference's normalise / un-normalise float sequence with its
+// one true division) depends on (candidate, pixel) only -- block_cost_bwd_tile computes it once per item instead of twice per channel
+// (32 divisions per thread and channel) and keeps it where it kept the candidate's disparity; column and fraction are a floor away.
+__device__ __forceinline__ float source_position(int x, float dispv, int W, float Wm1) {
+  const float xs = static_cast<float>(x) + (-dispv);
+  const float gx = (xs / Wm1 * 2.f) - 1.f;
+  const float ix = ((gx + 1.f) / 2.f) * Wm1;
+  return fminf(fmaxf(ix, -2.f), static_cast<float>(W) + 1.f);
+}
+template <bool SAMPLED>
+__device__ __forceinline__ void column_of(int x, int d, float pos, int& xi, float& f) {
+  if constexpr (SAMPLED) {
+    const float fl = floorf(pos);
+    f = pos - fl;
+    xi = static_cast<int>(fl);
+  } else {
+    xi = x - d;
+    f = 0.f;
+  }
+}
+
 template <bool SAMPLED, bool VEC, bool STAGE>
 __global__ void __launch_bounds__(256)
 block_cost_bwd_main(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
@@ -1433,7 +1454,7 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
   const size_t cstride = static_cast<size_t>(D) * HW;
   const size_t pbase = ((static_cast<size_t>(b) * s.G + g) * D + d);
 
-  float dvs[TR][4], gdacc[TR][4];       // candidates kept, tap positions recomputed (registers)
+  float dvs[TR][4], gdacc[TR][4];       // the items' tap positions (source_position), column / fraction re-derived per use (registers)
   float dp1[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
   float dp2 = 0.f;
 #pragma unroll
@@ -1444,7 +1465,7 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
       unpack(ld4<VEC>(disp + (static_cast<size_t>(b) * D + d) * HW + static_cast<size_t>(y) * W, x4, W), dv);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      dvs[r][k] = dv[k];
+      dvs[r][k] = SAMPLED ? source_position(x4 + k, dv[k], W, Wm1) : 0.f;        // the tap POSITION from here on
       gdacc[r][k] = 0.f;
     }
   }
@@ -1473,7 +1494,7 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
       // unconditional at a clamped index and masked afterwards (a read behind a condition becomes a branch
       // around a wait: 118 of them in the first version of this kernel)
       auto diff = [&](int r, int kk, float lval, bool ok, float& slope, int& a, float& f) {
-        source_column<SAMPLED>(x4 + kk, d, dvs[r][kk], W, Wm1, a, f);
+        column_of<SAMPLED>(x4 + kk, d, dvs[r][kk], a, f);
         const float* src = lds + static_cast<size_t>(c * TR + r) * 4 * s.Wqp;
         const int i0 = min(max(a, 0), W - 1), i1 = min(max(a + 1, 0), W - 1);
         // masked by multiplication: a select would be turned back into a load behind a branch
@@ -1505,7 +1526,8 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
 #pragma unroll
           for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(dvs[r][q]));
       }
-      // pass B: e again (cheaper than 16 more live registers), the gradients, LDS accumulation
+      // pass B: e again (keeping e and the slope from pass A costs 32 registers: 68 B of scratch at 4 waves, 350 us;
+      // 146 VGPRs at 3 waves, 395 us; recomputing: 337 us), the gradients, LDS accumulation
 #pragma unroll
       for (int r = 0; r < TR; ++r) {
         const int y = y0 + r;

@@ -636,6 +636,142 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
   }
 }
 
+// The correlation blocks alone (ts_block_cost_sampled_corr_fwd: what the pipeline launches since the first layer takes the
+// warped half in pre-contracted form), one lane = one ROW of a 4x4 block for ALL candidates.
+// block_cost_fast gives a lane one candidate and all four rows; with no main channels to store, what bounds it is LDS traffic and the
+// staging prologue (round 5 ablation at the 1/4 level: 20.3 us, of which 11.5 before the first tap and 2.4 each for loads and stores).
+// Here the eight left values of a lane's four pixels are loaded ONCE, straight into registers (no left rows in LDS, no half-time
+// swap and its two barriers, a third less LDS read traffic), the candidates are a loop, and the four rows of a block are the four
+// lanes of a quad: the 2x2 / 4x4 block means (block_cost.py:66-73) are two quad permutes (DPP, VALU rate) instead of registers
+// carried over rows.  Sums are formed in the order block_cost_fast forms them (a pair of rows, then the two pairs).
+// NRP: right-row staging items per lane (2 * TR * Wq float4-quads over the workgroup), all requested before the first is written.
+template <int NRP>
+__global__ void __launch_bounds__(256)
+block_cost_corr_rows(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
+                     float* __restrict__ out, float* __restrict__ P1, float* __restrict__ P2, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int by = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int y0 = by * TR;
+  const int H = s.H, W = s.W, D = s.D, C = s.C;
+  const unsigned HW = static_cast<unsigned>(H) * W;
+  const int Wq = s.Wq, Wqp = s.Wqp;
+  float4* ldsR4 = reinterpret_cast<float4*>(lds);                       // [2][TR][4][Wqp]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  constexpr unsigned OOR = 0x3ffffff0u;
+  const unsigned dHW = static_cast<unsigned>(D) * HW;
+  const __amdgpu_buffer_rsrc_t lrs = make_rsrc(L + (static_cast<size_t>(b) * C + g * GRP) * HW, static_cast<unsigned>(GRP) * HW * 4u);
+  const __amdgpu_buffer_rsrc_t rrs = make_rsrc(R + (static_cast<size_t>(b) * C + g * GRP) * HW, static_cast<unsigned>(GRP) * HW * 4u);
+  const __amdgpu_buffer_rsrc_t drs = make_rsrc(disp + static_cast<size_t>(b) * dHW, dHW * 4u);
+  const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + static_cast<size_t>(b) * s.Ctot * dHW, static_cast<unsigned>(s.Ctot) * dHW * 4u);
+
+  // this lane's row of this lane's block
+  const int r = tid & 3, bx = tid >> 2;
+  const int y = y0 + r, x4 = bx * 4;
+  const bool live = bx < s.nbx && y < H;
+  const unsigned poff = static_cast<unsigned>(y) * W + x4;               // element offset inside a plane
+
+  // ---- requests, oldest first in the order they are needed: right rows (staging), left values, first candidates ----
+  const int nR = 2 * TR * Wq;
+  float4 rq[NRP][4];
+#pragma unroll
+  for (int p = 0; p < NRP; ++p) {
+    const int i = tid + p * nthr;
+    const int j = i % Wq, hr = i / Wq;              // hr = h*TR + row
+    const int yy = y0 + (hr & (TR - 1)), h = hr >> 2;
+    const unsigned er = static_cast<unsigned>(h * 4) * HW + static_cast<unsigned>(yy) * W + 4u * j;
+    const bool ok = i < nR && yy < H;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) rq[p][cc] = bld4<true>(rrs, ok ? er + cc * HW : OOR, 4 * j, W);
+  }
+  float lv[GRP][4];
+#pragma unroll
+  for (int c = 0; c < GRP; ++c) unpack(bld4<true>(lrs, live ? static_cast<unsigned>(c) * HW + poff : OOR, x4, W), lv[c]);
+  float4 dnext = bld4<true>(drs, live ? poff : OOR, x4, W);
+#pragma unroll
+  for (int p = 0; p < NRP; ++p) {
+    const int i = tid + p * nthr;
+    if (i < nR) {
+      const int j = i % Wq, hr = i / Wq;
+      float a[4][4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) unpack(rq[p][cc], a[cc]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ldsR4[(hr * 4 + k) * Wqp + j] = make_float4(a[0][k], a[1][k], a[2][k], a[3][k]);
+    }
+  }
+  if (tid < 2 * TR) ldsR4[(tid * 4) * Wqp + Wq] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero slot of each row
+  __syncthreads();
+
+  const float Wm1 = static_cast<float>(W - 1);
+  const size_t pplane = (static_cast<size_t>(b) * s.G + g) * D;
+  const __amdgpu_buffer_rsrc_t p1rs = make_rsrc(P1 + pplane * s.H1 * s.W1, static_cast<unsigned>(D) * s.H1 * s.W1 * 4u);
+  const __amdgpu_buffer_rsrc_t p2rs = make_rsrc(P2 + pplane * s.H2 * s.W2, static_cast<unsigned>(D) * s.H2 * s.W2 * 4u);
+  const int py = 2 * by + (r >> 1);
+  const bool w1 = bx < s.nbx && (r & 1) == 0 && s.scales > 1 && py < s.H1;
+  const bool w2 = bx < s.nbx && r == 0 && s.scales > 2 && by < s.H2 && bx < s.W2;
+  unsigned p1o = static_cast<unsigned>(py) * s.W1 + 2u * bx, p2o = static_cast<unsigned>(by) * s.W2 + bx;
+  unsigned goff = static_cast<unsigned>(s.mainC + g) * dHW + poff;
+  const float4* row0 = ldsR4 + r * 4 * Wqp;
+  const float4* row1 = ldsR4 + (TR + r) * 4 * Wqp;
+  const float m = live ? 1.f : 0.f;
+
+#pragma unroll 1
+  for (int d = 0; d < D; ++d, goff += HW, p1o += s.H1 * s.W1, p2o += s.H2 * s.W2) {
+    float dv[4];
+    unpack(dnext, dv);
+    if (d + 1 < D) dnext = bld4<true>(drs, live ? static_cast<unsigned>(d + 1) * HW + poff : OOR, x4, W);
+    unsigned op[4];
+    float fr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tap4<true>(x4 + k, d, dv[k], W, Wm1, Wq, Wqp, op[k], fr[k]);
+    float g0[4] = {0.f, 0.f, 0.f, 0.f};
+    float sa[GRP], sb[GRP];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4* rrow = h ? row1 : row0;
+      float4 ta[4], tb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ta[k] = rrow[op[k] & 0xffffu];
+        tb[k] = rrow[op[k] >> 16];
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = h * 4 + cc;
+        float ev[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float t = (1.f - fr[k]) * comp(ta[k], cc) + fr[k] * comp(tb[k], cc);
+          ev[k] = (lv[c][k] - t) * m;
+          g0[k] += ev[k] * ev[k];
+        }
+        sa[c] = ev[0] + ev[1];
+        sb[c] = ev[2] + ev[3];
+      }
+    }
+    if (live) bst4<true>(orsrc, goff, 0u, x4, W, make_float4(-g0[0], -g0[1], -g0[2], -g0[3]));
+    // the other row of the pair (lane ^ 1), then the other pair (lane ^ 2): quad permutes
+    float a0 = 0.f, a1 = 0.f, acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < GRP; ++c) {
+      const float pa = sa[c] + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(sa[c]), 0xB1, 0xF, 0xF, true));
+      const float pb = sb[c] + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(sb[c]), 0xB1, 0xF, 0xF, true));
+      const float a = pa * 0.25f, e = pb * 0.25f;
+      a0 += a * a;
+      a1 += e * e;
+      const float q = pa + pb;
+      const float s2 = q + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(q), 0x4E, 0xF, 0xF, true));
+      const float mm = s2 * 0.0625f;
+      acc += mm * mm;
+    }
+    if (w1) {
+      if (2 * bx < s.W1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-a0), p1rs, p1o * 4u, 0, 0);
+      if (2 * bx + 1 < s.W1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-a1), p1rs, p1o * 4u + 4u, 0, 0);
+    }
+    if (w2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-acc), p2rs, p2o * 4u, 0, 0);
+  }
+}
+
 // trilinear(align_corners=True) expansion of the pooled maps (block_cost.py:74); the D axis maps
 // to itself, so it is a per-candidate bilinear interpolation, done separably: a workgroup owns a
 // band of RB output rows of one (b, g, d) plane, first interpolates the few pooled rows the band
@@ -1106,6 +1242,21 @@ int launch_fwd(const float* left, const float* right, const float* disp, float* 
   const dim3 grid(s.nby, s.G, B);
   hipStream_t st = ts::as_stream(stream);
 
+  // correlation blocks alone on aligned maps: one lane per block row, candidates as a loop (block_cost_corr_rows)
+  static const bool corr_rows = [] { const char* e = getenv("TS_K1_CORR_ROWS"); return !e || atoi(e) != 0; }();
+  bool done = false;
+  if (SAMPLED && omit_ref == 2 && vec && corr_rows && static_cast<unsigned long long>(s.Ctot) * D * H * W * 4ull < 0xffffff00ull) {
+    const int cthreads = static_cast<int>(ts::round_up(static_cast<size_t>(s.nbx) * 4, ts::kWave));
+    const int nrp = cthreads <= 1024 ? (2 * TR * s.Wq + cthreads - 1) / cthreads : 99;
+    const size_t clds = static_cast<size_t>(2) * TR * 4 * s.Wqp * 4 * sizeof(float);
+    if (cthreads <= 256 && nrp <= 2 && clds <= 64 * 1024) {
+      if (nrp == 1) hipLaunchKernelGGL((block_cost_corr_rows<1>), grid, dim3(cthreads), clds, st, left, right, disp, out, P1, P2, s);
+      else hipLaunchKernelGGL((block_cost_corr_rows<2>), grid, dim3(cthreads), clds, st, left, right, disp, out, P1, P2, s);
+      done = true;
+    }
+  }
+  if (done) {
+  } else
 #define TS_LAUNCH_FAST(V, N)                                                                        \
   do {                                                                                               \
     if (SAMPLED && omit_ref == 2)                                                                    \

@@ -42,11 +42,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from temporalstereo_amd import train as _ts_train  # noqa: E402
 try:
     _ts_train.enable_graph_replay()
-except RuntimeError:          # imported as a module by a process that already used the GPU: only the train-graph leg needs it
+# imported as a module by a process that already used the GPU: only the train-graph leg needs it
+except RuntimeError:
     pass
 
 from benchlegs import extras, k1 as k1legs, training as trainlegs  # noqa: E402
-from benchlegs.common import (CKPT, DIMS, HBM_PEAK, MAX_DISP, RUN_H, RUN_W, build_model, calibrate_batchnorm,  # noqa: E402,F401
+# noqa: E402,F401
+from benchlegs.common import (CKPT, DIMS, HBM_PEAK, MAX_DISP, RUN_H, RUN_W, build_model, calibrate_batchnorm,
                               k1_algorithmic_bytes, load_trained, make_inputs, make_planted_inputs, synth)
 from benchlegs.training import training_leg  # noqa: E402,F401  (tests and tools reach these through `bench`)
 from benchlegs.extras import sequence_leg  # noqa: E402,F401
@@ -59,37 +61,46 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step (config 2: 1)")
     ap.add_argument("--mode", default="native",
-                    choices=["native", "native-eager", "native-graph", "module", "module-graph", "module-hip", "train", "train-graph"],
-                    help="native: all-HIP inference path (aggregation.native) replayed from a recorded native launch plan; "
-                         "native-eager: the same, issued op by op from Python; module: nn.Module forward with the framework's own "
-                         "(MIOpen) convolutions; module-hip: nn.Module forward with the HIP convolution Functions (unfused BatchNorm / "
-                         "activation); -graph: replayed as one hipGraph; train / train-graph: the training step (benchlegs/training.py)")
+                    choices=["native", "native-eager", "native-graph", "module", "module-graph", "module-hip", "train",
+                             "train-graph"],
+                    help="native: all-HIP inference path (aggregation.native) replayed from a recorded native launch "
+                         "plan; native-eager: the same, issued op by op from Python; module: nn.Module forward with "
+                         "the framework's own (MIOpen) convolutions; module-hip: nn.Module forward with the HIP "
+                         "convolution Functions (unfused BatchNorm / activation); -graph: replayed as one hipGraph; "
+                         "train / train-graph: the training step (benchlegs/training.py)")
     ap.add_argument("--condition-s", type=float, default=1.5,
-                    help="upper bound (seconds) of the untimed device-conditioning phase in front of the warm-up steps: the same pass "
-                         "repeated in batches of 10 until two consecutive batches agree to 1 %% (at least 0.3 s), so that the timed "
-                         "region does not start on a GPU that is still ramping its clocks; reported as `conditioning`; 0 switches it off")
+                    help="upper bound (seconds) of the untimed device-conditioning phase in front of the warm-up "
+                         "steps: the same pass repeated in batches of 10 until two consecutive batches agree to 1 %% "
+                         "(at least 0.3 s), so that the timed region does not start on a GPU that is still ramping its "
+                         "clocks; reported as `conditioning`; 0 switches it off")
     ap.add_argument("--random-weights", action="store_true",
-                    help="rounds 1-2 protocol: random weights with calibrated BatchNorm statistics on independent smooth-noise features "
-                         "instead of the committed trained checkpoint on a planted-disparity scene (same shapes, kernels and speed)")
+                    help="rounds 1-2 protocol: random weights with calibrated BatchNorm statistics on independent "
+                         "smooth-noise features instead of the committed trained checkpoint on a planted-disparity "
+                         "scene (same shapes, kernels and speed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-all-cores", action="store_true", help="cpu_baseline: also one pass on ALL host threads (slow: oversubscribed)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the `training` and `sequence` objects of the default line")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="cpu_baseline: also one pass on ALL host threads (slow: oversubscribed)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `training` and `sequence` objects of the default line")
     ap.add_argument("--calibrate", action="store_true",
-                    help="also launch the known-size read / fill / copy streams of csrc/calib.hip (1 GiB each) once, so that a PMC "
-                         "pass of this command carries its own FETCH_SIZE / WRITE_SIZE calibration (tools/k1_traffic.py)")
+                    help="also launch the known-size read / fill / copy streams of csrc/calib.hip (1 GiB each) once, "
+                         "so that a PMC pass of this command carries its own FETCH_SIZE / WRITE_SIZE calibration "
+                         "(tools/k1_traffic.py)")
     ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3),
-                    help="native mode: N > 1 = the engine keeps N independent passes in flight on N sets of launch-plan buffers, each "
-                         "pass a three-stage pipeline over the engine's streams; 1 = one pass at a time")
+                    help="native mode: N > 1 = the engine keeps N independent passes in flight on N sets of "
+                         "launch-plan buffers, each pass a three-stage pipeline over the engine's streams; 1 = one "
+                         "pass at a time")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="extra measurement (does not change `value`): pairs/s with this many independent pairs in flight per GPU, "
-                         "each a batch-1 pass on its own streams; 0/1 skips it")
+                    help="extra measurement (does not change `value`): pairs/s with this many independent pairs in "
+                         "flight per GPU, each a batch-1 pass on its own streams; 0/1 skips it")
     return ap.parse_args()
 
 
 def init_ranks(a):
-    """-> (rank, world, device, dist | None).  Plain `python bench.py --gpus N` becomes the launcher: one rank per GPU under
-    torch.distributed.run (RCCL rendezvous on 127.0.0.1), same arguments; rank 0's JSON line is passed through."""
-    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    """-> (rank, world, device, dist | None).  Plain `python bench.py --gpus N` becomes the launcher: one rank per GPU
+    under torch.distributed.run (RCCL rendezvous on 127.0.0.1), same arguments; rank 0's JSON line is passed through."""
+    env = os.environ
+    world, rank, local = int(env.get("WORLD_SIZE", "1")), int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and "RANK" not in os.environ:
         import socket
         import subprocess
@@ -121,8 +132,9 @@ def init_ranks(a):
 
 
 def condition_device(step, bound_s):
-    """Untimed, bounded, reported: a fresh process reaches its first timed step ~10 passes after start-up, on a
-    device that is still leaving its idle power state.  Batches of 10 passes until two consecutive batches agree to 1 % (>= 0.3 s)."""
+    """Untimed, bounded, reported: a fresh process reaches its first timed step ~10 passes after
+    start-up, on a device that is still leaving its idle power state.  Batches of 10 passes until two consecutive
+    batches agree to 1 % (>= 0.3 s)."""
     tc0 = time.perf_counter()
     trace, n = [], 0
     while True:
@@ -166,8 +178,9 @@ def timed_steps(step, warmup, steps, dist, dev):
 
 
 def cpu_baseline(sd, inputs_cpu, budget_s=20.0, all_cores=False):
-    """The oracle aggregation (torch CPU ops, oracle/: test infrastructure, here as the reported CPU baseline and the parity
-    reference) with the bench's own weights on the bench's own (buffer set 0) inputs.  -> (cpu_baseline object, oracle outputs)."""
+    """The oracle aggregation (torch CPU ops, oracle/: test infrastructure, here as the reported CPU baseline and the
+    parity reference) with the bench's own weights on the bench's own (buffer set 0) inputs.  -> (cpu_baseline object,
+    oracle outputs)."""
     from oracle import aggregation as oagg
     # more threads than ~16 only adds oversubscription on these small tensors (256-thread runs of this workload
     # measured 76 s/pass on the GPU box's host); the count used is reported as `cores`
@@ -187,41 +200,46 @@ def cpu_baseline(sd, inputs_cpu, budget_s=20.0, all_cores=False):
             n += 1
     extra = {}
     if all_cores and (os.cpu_count() or 1) > cores:
-        torch.set_num_threads(os.cpu_count())       # once, for the record: every thread beyond ~16 only adds synchronisation here
+        # once, for the record: every thread beyond ~16 only adds synchronisation here
+        torch.set_num_threads(os.cpu_count())
         with torch.no_grad():
             t0 = time.perf_counter()
             oagg.aggregate(sd, lf, rf, il, ir, {}, cfg=cfg)
             ta = time.perf_counter() - t0
         torch.set_num_threads(cores)
         extra = dict(all_host_threads=dict(cores=os.cpu_count(), value=1.0 / ta, unit="pairs/s", sample="1 pass"))
-    sample = ("%d forward passes of the config-2 aggregation (544x960, D=192, B=%d) through oracle/ (torch %s CPU kernels, %d threads; "
-              "first pass %.2fs excluded)" % (n, lf[0].shape[0], torch.__version__, cores, first))
+    sample = ("%d forward passes of the config-2 aggregation (544x960, D=192, B=%d) through oracle/ (torch %s CPU "
+              "kernels, %d threads; first pass %.2fs excluded)" % (n, lf[0].shape[0], torch.__version__, cores, first))
     return dict(value=n / t_acc, unit="pairs/s", cores=cores, kind="port", sample=sample, **extra), out
 
 
 def parity_block(out, ref, gt0, seed):
-    """EPE of the product path and of the oracle against the ground truth (data/evaluation/pixel_error.py:33-63), |dEPE| < 1e-3 px."""
+    """EPE of the product path and of the oracle against the ground truth (data/evaluation/pixel_error.py:33-63),
+    |dEPE| < 1e-3 px."""
     full, rfull = out[0][0].detach().cpu().double(), ref[0][0].double()
     if gt0 is not None:
         gt, gt_name = gt0.double(), "planted disparity of the synthetic scene"
-    else:       # noise inputs have no ground truth: gt* = reference output + N(0,1) clipped to (0, MAX_DISP) (SURVEY.md 8(d))
+    else:
+        # noise inputs have no ground truth: gt* = reference output + N(0,1) clipped to (0, MAX_DISP) (SURVEY.md 8(d))
         gen = torch.Generator().manual_seed(seed)
         gt = (rfull + torch.randn(rfull.shape, generator=gen, dtype=torch.float64)).clamp(0, MAX_DISP)
         gt_name = "reference output + N(0,1)"
     valid = (gt > 0) & (gt < MAX_DISP)
     e_ours, e_ref = float((full - gt).abs()[valid].mean()), float((rfull - gt).abs()[valid].mean())
     d = (full - rfull).abs()
-    return dict(delta_epe_px=abs(e_ours - e_ref), epe_px=e_ours, epe_reference_px=e_ref, mean_abs_diff_px=float(d.mean()),
-                max_abs_diff_px=float(d.max()), frac_pixels_off_by_0p01=float((d > 0.01).double().mean()), tolerance_px=1e-3,
-                ground_truth=gt_name,
-                reference="oracle/ (CPU port pinned to the reference's golden vectors, incl. full-size runs of the reference with this checkpoint)")
+    return dict(delta_epe_px=abs(e_ours - e_ref), epe_px=e_ours, epe_reference_px=e_ref,
+                mean_abs_diff_px=float(d.mean()), max_abs_diff_px=float(d.max()),
+                frac_pixels_off_by_0p01=float((d > 0.01).double().mean()), tolerance_px=1e-3, ground_truth=gt_name,
+                reference="oracle/ (CPU port pinned to the reference's golden vectors, incl. full-size runs of the "
+                          "reference with this checkpoint)")
 
 
 _CONV_ARITHMETIC = (
-    "fp32 everywhere; stride-1 (1,3,3) layers with Cin >= 16, Cout > 8 -- and, on grids of 256+ workgroups, the stride-2 (1,3,3) layers "
-    "and the 4x4 deconvolutions (x6s) -- form each fp32 product from six bf16 MFMA products with fp32 accumulation (x6: dropped terms "
-    "<= 2^-24 of a product, chunks summed apart; measured max error vs fp64 0.15e-6-0.26e-6 of the output magnitude, the f32-input MFMA "
-    "kernel 0.3e-6-0.7e-6); f32_mfma_only = this engine with that switched off")
+    "fp32 everywhere; stride-1 (1,3,3) layers with Cin >= 16, Cout > 8 -- and, on grids of 256+ workgroups, the "
+    "stride-2 (1,3,3) layers and the 4x4 deconvolutions (x6s) -- form each fp32 product from six bf16 MFMA products "
+    "with fp32 accumulation (x6: dropped terms <= 2^-24 of a product, chunks summed apart; measured max error vs fp64 "
+    "0.15e-6-0.26e-6 of the output magnitude, the f32-input MFMA kernel 0.3e-6-0.7e-6); f32_mfma_only = this engine "
+    "with that switched off")
 
 
 def main():
@@ -242,11 +260,15 @@ def main():
     else:
         inputs = make_inputs(dev, seed + rank, a.batch)
         calibrate_batchnorm(net, inputs)
-    more_inputs = (lambda s: make_planted_inputs(dev, s, a.batch)[0]) if planted else (lambda s: make_inputs(dev, s, a.batch))
+    if planted:
+        more_inputs = lambda s: make_planted_inputs(dev, s, a.batch)[0]          # noqa: E731
+    else:
+        more_inputs = lambda s: make_inputs(dev, s, a.batch)                     # noqa: E731
 
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     mode = a.mode
-    replay = {"native": "plan", "native-eager": "eager", "native-graph": "graph", "module": "eager", "module-graph": "graph",
+    replay = {"native": "plan", "native-eager": "eager", "native-graph": "graph", "module": "eager",
+              "module-graph": "graph",
               "module-hip": "eager"}[mode]
     if mode in ("module", "module-graph"):
         from temporalstereo_amd import layers
@@ -269,12 +291,14 @@ def main():
     # ---- set-up, conditioning, THE TIMED REGION
     # ----------------------------------------------------------------------------------
     with k1legs.K1Probe() as k1:
-        for _ in range(depth):          # set-up, not benchmark steps: record the launch plan of every buffer set / capture the graph
+        # set-up, not benchmark steps: record the launch plan of every buffer set / capture the graph
+        for _ in range(depth):
             step()
         torch.cuda.synchronize()
         conditioning = condition_device(step, a.condition_s) if a.condition_s > 0 else None
         elapsed = timed_steps(step, a.warmup, a.steps, dist, dev)
-        while calls[0] % depth != 0:     # (not timed) `out` below = the pass on buffer set 0, the frame the oracle is run on
+        # (not timed) `out` below = the pass on buffer set 0, the frame the oracle is run on
+        while calls[0] % depth != 0:
             step()
         out = step()
         torch.cuda.synchronize()
@@ -299,10 +323,12 @@ def main():
     f32_only = extras.f32_mfma_only(net, inputs, a.steps, a.batch, depth) if (native_extras and rank == 0) else None
     concurrent = None
     if a.inflight > 1 and mode == "native":
-        concurrent = extras.concurrent_lanes(net, dev, dist, world, more_inputs, seed, rank, a.inflight, a.steps, a.batch)
+        concurrent = extras.concurrent_lanes(net, dev, dist, world, more_inputs, seed, rank, a.inflight, a.steps,
+                                             a.batch)
     sequence = None
     if world == 1 and native_extras:
-        try:        # before the training legs: their graph capture leaves a private memory pool and extra streams behind
+        # before the training legs: their graph capture leaves a private memory pool and extra streams behind
+        try:
             sequence = extras.sequence_leg(20)
         except Exception as e:
             sequence = dict(error="%s: %s" % (type(e).__name__, e))
@@ -310,20 +336,21 @@ def main():
     # rank that fails inside them; rank 0 runs `bench.py --mode train --gpus N` as its own job below)
     training = trainlegs.single_gpu_training(dev, seed) if (native_extras and world == 1) else None
 
-    # ---- the line
-    # --------------------------------------------------------------------------------------------------------------------
+    # ---- the line ------------------------------------------------------------------------------------------------
     result = None
     if rank == 0:
-        weights = ("trained checkpoint tests/golden/ckpt_planted.npz on planted-disparity scenes (tests/synth.stereo_sequence)" if planted
+        weights = ("trained checkpoint tests/golden/ckpt_planted.npz on planted-disparity scenes "
+                   "(tests/synth.stereo_sequence)" if planted
                    else "random weights, calibrated BatchNorm, smooth-noise features (--random-weights)")
         result = dict(metric="stereo pairs/sec, FlyingThings3D 540x960 D=192 (aggregation hot path)",
-                      value=world * a.batch * a.steps / elapsed, unit="pairs/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                      ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
-                      data="synthetic",
-                      config=dict(workload="BASELINE configs[1]: FlyingThings3D 540x960 (run 544x960) D=192 single-frame aggregation, "
-                                           "batch %d/GPU, eval" % a.batch,
-                                  run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch, parallelism="replicas x%d" % world,
-                                  exec_mode=mode, frames_in_flight=depth, input_buffer_sets=depth, weights_and_inputs=weights,
+                      value=world * a.batch * a.steps / elapsed, unit="pairs/s", n_gpus=world, steps=a.steps,
+                      warmup=a.warmup, ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling="weak",
+                      vs_baseline=None, dtype="f32", data="synthetic",
+                      config=dict(workload="BASELINE configs[1]: FlyingThings3D 540x960 (run 544x960) D=192 "
+                                           "single-frame aggregation, batch %d/GPU, eval" % a.batch,
+                                  run_hw=[RUN_H, RUN_W], max_disp=MAX_DISP, batch_per_gpu=a.batch,
+                                  parallelism="replicas x%d" % world, exec_mode=mode, frames_in_flight=depth,
+                                  input_buffer_sets=depth, weights_and_inputs=weights,
                                   conv_arithmetic=_CONV_ARITHMETIC),
                       roofline=roofline)
         for key, val in (("conditioning", conditioning), ("one_pass_at_a_time", one), ("f32_mfma_only", f32_only),

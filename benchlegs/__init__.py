@@ -1,5 +1,6 @@
-"""Measurement legs of bench.py (repo root).  bench.py itself holds the argument parsing, the headline's timed region, the CPU
-baseline / parity leg (the only place outside tests/ that runs oracle/) and the JSON line; everything else is here:
+"""Measurement legs of bench.py (repo root).  bench.py itself holds the argument parsing, the headline's timed region,
+the CPU baseline / parity leg (the only place outside tests/ that runs oracle/) and the JSON line; everything else is
+here:
 
     common.py    workload constants (BASELINE configs[1]), model / input construction shared with the tests
     k1.py        roofline probes of the cost-volume build: HIP-event timing of the C-ABI launches, the same-run fill /

@@ -21,8 +21,8 @@ CKPT = os.path.join(ROOT, "tests", "golden", "ckpt_planted.npz")
 
 
 def k1_algorithmic_bytes(B, C, H, W, D, sampled):
-    """inputs once + output once, fp32.  sampled == "warped": the inference form that leaves out the D-fold
-    repeat of the left features (ts_block_cost_sampled_warped_fwd); "corr": the correlation blocks alone."""
+    """inputs once + output once, fp32.  sampled == "warped": the inference form that leaves out
+    the D-fold repeat of the left features (ts_block_cost_sampled_warped_fwd); "corr": the correlation blocks alone."""
     if sampled == "warped":
         return 4 * B * H * W * (2 * C + D + (C + 3 * C // 8) * D)
     if sampled == "corr":
@@ -35,7 +35,8 @@ def k1_algorithmic_bytes(B, C, H, W, D, sampled):
 def build_model(dev, seed, num_sample=None):
     import temporalstereo_amd as ts
     net = ts.TEMPORALSTEREO(
-        coarse=ts.CoarseAggregation(DIMS['coarse']['in_planes'], DIMS['coarse']['C'], num_sample or DIMS['coarse']['num_sample']),
+        coarse=ts.CoarseAggregation(DIMS['coarse']['in_planes'], DIMS['coarse']['C'],
+                                    num_sample or DIMS['coarse']['num_sample']),
         fine=ts.FineAggregation(DIMS['fine']['in_planes'], DIMS['fine']['C'], 5),
         precise=ts.PreciseAggregation(DIMS['precise']['in_planes'], DIMS['precise']['C'], 5))
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
@@ -71,8 +72,9 @@ def make_planted_inputs(dev, seed, B, hw=None):
 
 
 def calibrate_batchnorm(net, inputs, prev_info=None):
-    """One train-mode pass with momentum 1: running statistics := this input's batch statistics, so the random-weight network is
-    conditioned like a trained one (same protocol as tools/gen_golden.py).  prev_info: temporal state of the frame."""
+    """One train-mode pass with momentum 1: running statistics := this input's batch statistics, so the random-weight
+    network is conditioned like a trained one (same protocol as tools/gen_golden.py).  prev_info: temporal state of the
+    frame."""
     bns = [m for m in net.modules() if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))]
     for m in bns:
         m.momentum = 1.0
@@ -85,8 +87,8 @@ def calibrate_batchnorm(net, inputs, prev_info=None):
 
 
 def timed_us(fn, n=100, warm=10):
-    """Mean duration (us) of `fn`, n calls back to back between ONE pair of HIP events on the current stream (the queue stays full:
-    the events see kernel time, not the host gap in front of every launch)."""
+    """Mean duration (us) of `fn`, n calls back to back between ONE pair of HIP events on the current stream (the queue
+    stays full: the events see kernel time, not the host gap in front of every launch)."""
     with torch.no_grad():
         for _ in range(warm):
             fn()

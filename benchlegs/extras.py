@@ -1,5 +1,5 @@
-"""Measurements next to the headline (none of them changes `value`): what one caller sees, the engine without the bf16-split
-convolutions, independent lanes, temporal sequences."""
+"""Measurements next to the headline (none of them changes `value`): what one caller sees, the engine without the
+bf16-split convolutions, independent lanes, temporal sequences."""
 import os
 import sys
 import time
@@ -10,7 +10,8 @@ from .common import ROOT
 
 
 def one_pass_at_a_time(net, inputs, steps, batch):
-    """The same engine with one pass in flight: every pass waits for the previous one (what a latency-bound caller sees)."""
+    """The same engine with one pass in flight: every pass waits for the previous one (what a latency-bound caller
+    sees)."""
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     single = InferenceEngine(net, backend="native", replay="plan", inputs="bind")
     with torch.no_grad():
@@ -27,8 +28,9 @@ def one_pass_at_a_time(net, inputs, steps, batch):
 
 
 def f32_mfma_only(net, inputs, steps, batch, depth):
-    """The pipelined engine with every convolution on the f32-input MFMA kernel (TS_CONV_X6=0 semantics), measured in this run: the
-    headline uses ts_conv3d_hw_x6_fwd / _x6s_fwd where a layer allows it (fp32 products from six bf16 MFMA products)."""
+    """The pipelined engine with every convolution on the f32-input MFMA kernel (TS_CONV_X6=0 semantics), measured in
+    this run: the headline uses ts_conv3d_hw_x6_fwd / _x6s_fwd where a layer allows it (fp32 products from six bf16 MFMA
+    products)."""
     from temporalstereo_amd.aggregation import native as _N
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     if not _N.X6:
@@ -51,7 +53,8 @@ def f32_mfma_only(net, inputs, steps, batch, depth):
 
 
 def concurrent_lanes(net, dev, dist, world, more_inputs, seed, rank, inflight, steps, batch):
-    """Serving-style concurrency: N independent batch-1 passes in flight on one GPU (each its own plan, buffers and streams)."""
+    """Serving-style concurrency: N independent batch-1 passes in flight on one GPU (each its own plan, buffers and
+    streams)."""
     from temporalstereo_amd.aggregation.engine import InferenceEngine
     lanes = []
     for i in range(inflight):
@@ -83,8 +86,8 @@ def concurrent_lanes(net, dev, dist, world, more_inputs, seed, rank, inflight, s
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     return dict(inflight=inflight, value=world * batch * steps / el, unit="pairs/s", ms_per_step=el / steps * 1e3,
-                note="%d independent batch-1 passes in flight per GPU (own launch plan, buffers and streams each); not the "
-                     "headline value" % inflight)
+                note="%d independent batch-1 passes in flight per GPU (own launch plan, buffers and streams each); not "
+                     "the headline value" % inflight)
 
 
 def sequence_leg(iters=10):

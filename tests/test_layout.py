@@ -44,3 +44,13 @@ def test_oracle_headers_say_test_infrastructure():
     for path in _sources(os.path.join(ROOT, "oracle"), (".py",)):
         head = open(path).read(600).lower()
         assert "test infrastructure" in head, path
+
+
+def test_bench_lines_fit_120_columns():
+    """bench.py and its legs stay readable in a review pane."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in [os.path.join(root, "bench.py")] + sorted(glob.glob(os.path.join(root, "benchlegs", "*.py"))):
+        with open(path) as f:
+            long = [(n, len(line.rstrip("\n"))) for n, line in enumerate(f, 1) if len(line.rstrip("\n")) > 120]
+        assert not long, "%s: lines over 120 columns: %s" % (os.path.relpath(path, root), long[:5])

@@ -46,7 +46,7 @@ def main(fetch_db, write_db):
     for name, sub, grid in (("main (reference half + warped half + scale-0 correlation + pooled maps)", "block_cost_fast<true, true, 3, true, true>", (34, 16, 1)),
                             ("expansion of the pooled maps", "block_cost_upsample_rows<true, 4>", (8, 80, 1)),
                             ("round 1-3 pipeline: main without the reference half", "block_cost_fast<true, true, 3, false, true>", (34, 16, 1)),
-                            ("round 4 pipeline: the correlation planes alone", "block_cost_fast<true, true, 3, false, false>", (34, 16, 1))):
+                            ("round 4-5 pipeline: the correlation planes alone", "block_cost_corr_rows<2>", (34, 16, 1))):
         f, w = find(F, sub, grid) * kib, find(W, sub, grid) * kib
         rows[name] = dict(fetch_size_bytes_raw=f, write_size_bytes_raw=w, hbm_bytes=f * fx + w * wx)
     main_b = rows["main (reference half + warped half + scale-0 correlation + pooled maps)"]["hbm_bytes"]
@@ -60,8 +60,8 @@ def main(fetch_db, write_db):
                           warped_variant=dict(launch="ts_block_cost_sampled_warped_fwd (rounds 1-3)",
                                               hbm_bytes_per_launch=rows["round 1-3 pipeline: main without the reference half"]["hbm_bytes"] + up_b,
                                               algorithmic_bytes=148968960),
-                          pipeline_variant=dict(launch="ts_block_cost_sampled_corr_fwd (round 4: what the pipeline launches)",
-                                                hbm_bytes_per_launch=rows["round 4 pipeline: the correlation planes alone"]["hbm_bytes"] + up_b,
+                          pipeline_variant=dict(launch="ts_block_cost_sampled_corr_fwd (block_cost_corr_rows + expansion: what the pipeline launches)",
+                                                hbm_bytes_per_launch=rows["round 4-5 pipeline: the correlation planes alone"]["hbm_bytes"] + up_b,
                                                 algorithmic_bytes=65410560)), indent=1))
 
 

@@ -1235,7 +1235,10 @@ int launch_fwd(const float* left, const float* right, const float* disp, float* 
   if (threads > 512) threads = 512;
   // LDS: 4 right rows (de-interleaved, padded) + 2 left rows, per channel of the group
   const int np = (GRP * 2 * s.Wq + threads - 1) / threads;     // left float4s per thread and row pair
-  const size_t lds_bytes = static_cast<size_t>(GRP) * (TR * 4 * s.Wqp + (np <= 3 ? 2 : 4) * 4 * s.Wq) * sizeof(float);   // R4 + Lx
+  // the NP the dispatch below INSTANTIATES (ragged widths have no NP = 3 form: np = 3 runs as NP = 4, which keeps all four left rows in
+  // LDS -- sizing that case for two rows put rows 2, 3 outside the allocation: every correlation plane wrong for e.g. W = 38, D = 5)
+  const int np_inst = np <= 2 ? 2 : ((vec && np == 3) ? 3 : (np <= 4 ? 4 : 8));
+  const size_t lds_bytes = static_cast<size_t>(GRP) * (TR * 4 * s.Wqp + (np_inst <= 3 ? 2 : 4) * 4 * s.Wq) * sizeof(float);   // R4 + Lx
   // the fast path addresses one batch item's output slab through a 32-bit buffer descriptor
   const bool stage = lds_bytes <= 64 * 1024 && passes == 1 && np <= 8 &&
                      static_cast<unsigned long long>(s.Ctot) * D * H * W * 4ull < 0xffffff00ull;

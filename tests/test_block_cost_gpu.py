@@ -71,6 +71,8 @@ SHAPES = [  # B, C, H, W, D  -- levels of the BASELINE configs at reduced batch/
     (1, 8, 7, 9, 3),         # tiny ragged
     (1, 8, 4, 4, 2),         # minimum
     (1, 8, 12, 600, 3),      # row wider than the LDS staging limit -> global gather path
+    (1, 16, 12, 38, 5),      # ragged width with THREE left quads per thread and row pair: runs as the four-row form (round 5: its LDS was
+    (1, 16, 12, 78, 3),      # sized for the two-row form and every correlation plane came out wrong; no BASELINE geometry is ragged)
 ]
 
 
@@ -163,3 +165,28 @@ def test_backward_vs_oracle_autograd(shape, sampled):
     close(rg.grad, rc.grad, "grad_right")
     if sampled:
         close(dg.grad, dc.grad, "grad_disp")
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 20, 36, 5), (2, 32, 34, 60, 7), (1, 128, 68, 120, 5), (1, 64, 135, 240, 5),
+                                   (3, 8, 9, 256, 3), (1, 16, 12, 260, 5), (1, 16, 12, 38, 5), (1, 8, 4, 4, 2)])
+@pytest.mark.parametrize("scales", [3, 2])
+def test_correlation_blocks_alone_equal_the_full_op(shape, scales):
+    """ts_block_cost_sampled_corr_fwd (what the pipeline launches: block_cost_corr_rows on aligned maps of up to 256 columns,
+    block_cost_fast<corr only> otherwise -- W = 260 and the ragged W = 38 here) against the complete op's correlation channels
+    (block_cost.py:66-81) and against the oracle, within the op's tolerance.  Candidates reach outside the row on both
+    sides; H is not always a multiple of 4."""
+    import temporalstereo_amd as ts
+    import temporalstereo_amd.functional as TF
+    dev = _dev()
+    B, C, H, W, D = shape
+    L = t(synth.normal(11, "L", (B, C, H, W)), dev)
+    R = t(synth.normal(11, "R", (B, C, H, W)), dev)
+    disp = t(synth.uniform(11, "d", (B, D, H, W), -3.0, 0.6 * W), dev)
+    corr = TF.block_cost_corr(L, R, disp, scales)
+    full = ts.block_cost(L, R, disp, scales)
+    assert corr.shape == (B, scales * (C // 8), D, H, W)
+    # (the two launches are different instantiations: contraction of multiply-adds may differ in the last bits; bit-identity of
+    # block_cost_corr_rows with block_cost_fast<corr only> is recorded in profiles/r05_k1_corr_rows.txt)
+    np.testing.assert_allclose(corr.cpu().numpy(), full[:, 2 * C:].cpu().numpy(), rtol=1e-5, atol=ATOL)
+    exp = oracle.block_cost(L.cpu(), R.cpu(), disp.cpu(), scales)[:, 2 * C:]
+    np.testing.assert_allclose(corr.cpu().numpy(), exp.numpy(), rtol=5e-5, atol=ATOL * max(1.0, C / 16.0))

@@ -1183,8 +1183,10 @@ int make_shape(Shape& s, bool sampled, int B, int C, int H, int W, int D, int sc
   TS_REQUIRE(C % GRP == 0, TS_ERR_SHAPE, "block_cost: C=%d is not a multiple of 8 (block_cost.py:9)", C);
   TS_REQUIRE(scales >= 1 && scales <= 3, TS_ERR_UNSUPPORTED, "block_cost: scales=%d outside 1..3", scales);
   TS_REQUIRE(H >= min_hw && W >= min_hw, TS_ERR_UNSUPPORTED, "block_cost: H,W must be >= %d (got %dx%d)", min_hw, H, W);
-  // D==1 divides by zero in the reference's coordinate normalisation (inverse_warp_3d.py:45)
+  // D == 1 (and H == 1, W == 1) divide by zero in the reference's coordinate normalisation (inverse_warp_3d.py:45-47): its output is
+  // whatever grid_sample makes of NaN coordinates
   TS_REQUIRE(!sampled || D >= 2, TS_ERR_UNSUPPORTED, "block_cost: sampled path needs D >= 2");
+  TS_REQUIRE(!sampled || (H >= 2 && W >= 2), TS_ERR_UNSUPPORTED, "block_cost: sampled path needs H, W >= 2 (got %dx%d)", H, W);
   TS_REQUIRE(B <= 65535 && C / GRP <= 65535, TS_ERR_UNSUPPORTED, "block_cost: grid too large");
   s.B = B; s.C = C; s.H = H; s.W = W; s.D = D; s.scales = scales;
   s.G = C / GRP;

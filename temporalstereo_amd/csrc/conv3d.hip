@@ -1888,7 +1888,8 @@ extern "C" int ts_conv3d_d_bwd_weight(const float* x, const float* dy, float* dw
 }
 
 // ConvTranspose2d(kernel 4, stride 2, padding 1) of UNet (module.py:453-457): x [B,Cin,H,W] -> y [B,Cout,2H,2W]
-// (y may be a channel slice: out_bstride in elements); w_t [Cin][4][4][CoutPad], CoutPad = 16 | 32.
+// (y may be a channel slice: out_bstride in elements); w_t [Cin][4][4][CoutPad], CoutPad = ts_conv_cout_pad(Cout) = 8 | 16 | 32
+// (round 5: this entry assumed 16 for Cout <= 8 while every caller lays weights out with ts_conv_cout_pad: wrong outputs for Cout <= 8).
 extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const float* scale, const float* shift, float* y,
                                     int B, int Cin, int Cout, int H, int W, int act, long long out_bstride, void* stream) {
   TS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "deconv2d: non-positive size");
@@ -1896,7 +1897,7 @@ extern "C" int ts_deconv2d_k4s2_fwd(const float* x, const float* w_t, const floa
   TS_REQUIRE(act >= 0 && act <= 2, TS_ERR_SHAPE, "deconv2d: unknown activation");
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(w_t); TS_REQUIRE_PTR(scale); TS_REQUIRE_PTR(shift); TS_REQUIRE_PTR(y);
   IG p;
-  p.Cin = Cin; p.Cout = Cout; p.coutp = Cout <= 16 ? 16 : 32; p.D = 1; p.H = H; p.W = W; p.Do = 1; p.Ho = 2 * H; p.Wo = 2 * W;
+  p.Cin = Cin; p.Cout = Cout; p.coutp = cout_bucket(Cout); p.D = 1; p.H = H; p.W = W; p.Do = 1; p.Ho = 2 * H; p.Wo = 2 * W;
   p.stride = 2; p.dil = 1; p.pad = 1; p.k = 4; p.transposed = 1; p.act = act; p.act_param = 0.f;
   p.in_bstride = static_cast<long long>(Cin) * H * W; p.in_cstride = static_cast<long long>(H) * W;
   p.out_bstride = out_bstride; p.out_cstride = 4ll * H * W;

@@ -83,7 +83,7 @@ offset_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
 
 // z [B][4C][H][W] from x [B][C][2H][2W]; one lane = 4 consecutive z pixels of one (parity, channel) plane <- 8 consecutive x pixels
 __global__ void __launch_bounds__(256)
-space_to_depth2_kernel(const float* __restrict__ x, float* __restrict__ z, int B, int C, int H, int W) {
+space_to_depth2_kernel(const float* __restrict__ x, float* __restrict__ z, int B, int C, int H, int W, int vec) {
   const int Wq = (W + 3) / 4;
   const long long n = static_cast<long long>(B) * C * 2 * H * Wq;         // (b, c, row of x = 2y+py, quad)
   for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
@@ -95,7 +95,7 @@ space_to_depth2_kernel(const float* __restrict__ x, float* __restrict__ z, int B
     const int y = ry >> 1, py = ry & 1;
     const float* src = x + ((static_cast<size_t>(b) * C + c) * 2 * H + ry) * 2 * W + 8 * q;
     float v[8];
-    if (8 * q + 8 <= 2 * W) {
+    if (vec && 8 * q + 8 <= 2 * W) {         // vec: rows of x start on 16 bytes (2W a multiple of 4; odd W takes the scalar form)
       const float4 a = *reinterpret_cast<const float4*>(src), bb = *reinterpret_cast<const float4*>(src + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bb.x; v[5] = bb.y; v[6] = bb.z; v[7] = bb.w;
     } else {
@@ -261,9 +261,9 @@ extern "C" int ts_space_to_depth2_fwd(const float* x, float* z, int B, int C, in
   TS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, TS_ERR_SHAPE, "space_to_depth2: non-positive size");
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(z);
   TS_REQUIRE_ALIGNED(x);
-  TS_REQUIRE((2 * W) % 4 == 0, TS_ERR_UNSUPPORTED, "space_to_depth2: row length %d of x is not a multiple of 4", 2 * W);
   const long long n = static_cast<long long>(B) * C * 2 * H * ((W + 3) / 4);
-  hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, ts::as_stream(stream), x, z, B, C, H, W);
+  hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, ts::as_stream(stream), x, z, B, C, H, W,
+                     (2 * W) % 4 == 0 ? 1 : 0);
   return ts::launched("space_to_depth2_kernel");
 }
 

@@ -274,7 +274,7 @@ class Folded:
         taps = w.shape[2:].numel()
         self.cin, self.cout, self.kind, self.act = cin, cout, kind, act
         self.kshape = tuple(w.shape[2:])
-        pad = 16 if (kind == "deconv2d" and cout <= 16) else (32 if kind == "deconv2d" else int(_lib.lib().ts_conv_cout_pad(cout)))
+        pad = int(_lib.lib().ts_conv_cout_pad(cout))      # every entry, ts_deconv2d_k4s2_fwd included, takes this pitch (8 | 16 | 32 | 64 ...)
         if pad < cout:
             raise NotImplementedError("Cout=%d has no kernel bucket" % cout)
         wt = torch.zeros(cin, taps, pad, device=w.device, dtype=torch.float32)

@@ -11,10 +11,20 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("op", ["conv3d", "deconv2d", "block_cost", "dense", "pool_resize", "regress", "upsample", "topk", "correlation",
-                                "sort_gather", "conv_bn_act"])
+                                "sort_gather", "conv_bn_act", "splat", "losses"])
 def test_random_shapes(op):
     import fuzz_ops
     found = fuzz_ops.sweep(op, 30, seed=0)
+    assert not found, "\n".join(" ".join(map(str, f)) for f in found)
+
+
+@pytest.mark.parametrize("family", ["hw", "d", "deconv"])
+def test_random_shapes_inference_forms(family):
+    """tests/fuzz_native.py: the inference forms over the C ABI with every kernel family forced where its `supported` query allows it
+    (f32-input MFMA, bf16-split x6 incl. split-K, x6s stride 2 / transposed / 4x4 deconvolution, the (k,1,1) family), folded scale /
+    shift, activation, per-plane addend."""
+    import fuzz_native
+    found = fuzz_native.sweep(family, 40, seed=0)
     assert not found, "\n".join(" ".join(map(str, f)) for f in found)
 
 

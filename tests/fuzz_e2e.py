@@ -1,0 +1,154 @@
+"""Random-geometry sweep of the WHOLE inference path: InferenceEngine (launch-plan replay, the product path) against the oracle
+aggregation on the CPU, frame by frame, on planted-disparity scenes with the committed trained checkpoint -- image sizes that are
+multiples of 16 but of nothing more (so the 1/16 ... 1/64 hourglass levels are odd-sized and the tile edges of every kernel fall
+inside the image), 4-12 coarse candidates, batch 1-2, 1-3 frames with 0-3 local-map candidates.  The bar is the fixtures' own:
+|EPE(ours) - EPE(oracle)| < 1e-3 px per frame against the planted ground truth (data/evaluation/pixel_error.py:33-63)."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+
+
+def _clone(x):
+    if isinstance(x, dict):
+        return {k: _clone(v) for k, v in x.items()}
+    return x.detach().clone() if torch.is_tensor(x) else x
+
+
+def one_case(r, dev, log=None):
+    import parity_tools as PT
+    import synth
+    from temporalstereo_amd.aggregation.engine import InferenceEngine
+    frames = r.choice([1, 1, 2, 3])
+    # (>= 80 pixels: the 1/16 level must hold PyramidFusion's 5^3 pools, which torch -- and so the reference -- refuses below 5)
+    c = dict(H=16 * r.randint(5, 14), W=16 * r.randint(6, 24), num_sample=r.choice([4, 6, 8, 12]), B=r.randint(1, 2), frames=frames,
+             n_local=0 if frames == 1 else r.choice([1, 3]), fx=r.uniform(300.0, 1100.0), baseline=r.choice([0.25, 0.54, 1.0]))
+    seed = synth.SEED0 + r.randint(0, 10000)
+    desc = "%dx%d D=%d B=%d T=%d local=%d seed=%d" % (c["H"], c["W"], 16 * c["num_sample"], c["B"], frames, c["n_local"], seed)
+    found = []
+    try:
+        case = PT.PlantedCase(c, seed, dev)
+        eng = InferenceEngine(case.net, backend="native", replay=r.choice(["plan", "eager"]))
+        info, io = {}, {}
+        for t in range(frames):
+            o32 = case.oracle_frame(t, io)[0]
+            io = o32[5]
+            if t > 0:
+                info = case.native_update(t, info)
+            on = eng(*case.frames_gpu[t], dict(info))
+            info = _clone(on[5])
+            gt = case.gt[t].double()
+            valid = (gt > 0) & (gt < case.max_disp)
+            ours, ref = on[0][0].detach().cpu().double(), o32[0][0].double()
+            if ours.shape != ref.shape:
+                found.append(("e2e", desc, "frame %d: shape %s vs %s" % (t, tuple(ours.shape), tuple(ref.shape))))
+                break
+            e_o, e_r = float((ours - gt).abs()[valid].mean()), float((ref - gt).abs()[valid].mean())
+            mad = float((ours - ref).abs().mean())
+            if log is not None:
+                log.append("%s frame %d: EPE %.5f (oracle %.5f), mean |d| %.2e" % (desc, t, e_o, e_r, mad))
+            if not (abs(e_o - e_r) < 1e-3) or not torch.isfinite(ours).all():
+                found.append(("e2e", desc, "frame %d: EPE %.5f vs oracle %.5f (mean |d| %.3g)" % (t, e_o, e_r, mad)))
+    except Exception as e:
+        found.append(("e2e", desc, "raised %s: %s" % (type(e).__name__, str(e)[:300])))
+    return found
+
+
+def sweep(n, seed, log=None):
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    r = random.Random(seed)
+    found = []
+    for _ in range(n):
+        found += one_case(r, dev, log)
+    return found
+
+
+def one_train_case(r, dev, log=None):
+    """Train mode (batch statistics), one frame: loss and ALL parameter / feature gradients of the module path (HIP autograd
+    Functions behind the reference's module interfaces + the loss kernels) against the float64 oracle under the reference's
+    objective (the composition tests/test_backward_stagewise_gpu.py takes apart, here at random geometry)."""
+    import bench
+    import parity_tools as PT
+    import synth
+    from oracle import aggregation as oagg
+    from oracle import losses as olo
+    from temporalstereo_amd import losses as TL
+    B, H, W, ns = r.randint(1, 2), 16 * r.randint(5, 10), 16 * r.randint(6, 14), r.choice([4, 6, 8])
+    max_disp, seed = 16 * ns, synth.SEED0 + r.randint(0, 10000)
+    desc = "train %dx%d D=%d B=%d seed=%d" % (H, W, max_disp, B, seed)
+    found = []
+    try:
+        sc = synth.stereo_sequence(seed, B, H, W, frames=1, max_disp=max_disp, fx=r.uniform(300.0, 1100.0))
+        T64 = lambda a: torch.from_numpy(a).double()
+        lf, rf, il, ir = sc["frames"][0]
+        gt = T64(sc["gt"][0])
+        ck = PT.load_checkpoint()
+        sd = {k: (v.double().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else
+                  (v.double() if v.is_floating_point() else v)) for k, v in ck.items()}
+        lf64, rf64 = [T64(x).requires_grad_(True) for x in lf], [T64(x).requires_grad_(True) for x in rf]
+        out = oagg.aggregate(sd, lf64, rf64, T64(il), T64(ir), {}, cfg=dict(coarse=dict(num_sample=ns)), training=True)
+        W4 = (2.0, 1.0, 0.7, 0.5)
+        tot = sum(w * olo.smooth_l1_loss_per_level(olo.rescale_to_full(d, (H, W)), gt, max_disp) for w, d in zip(W4, out[0]))
+        tot = tot + 2.0 * sum(w * olo.wasserstein_loss_per_level(c, o, s, gt, max_disp) for w, c, o, s in zip((1.0, 0.7, 0.5), out[1], out[3], out[2]))
+        tot.backward()
+
+        net = bench.build_model(dev, seed, ns)
+        net.load_state_dict(ck, strict=True)
+        net.train()
+        to = lambda a: torch.from_numpy(a).to(dev)
+        lg, rg = [to(x).requires_grad_(True) for x in lf], [to(x).requires_grad_(True) for x in rf]
+        o = net(lg, rg, to(il), to(ir), {})
+        gtd = gt.float().to(dev)
+        mine = sum(w * TL.smooth_l1_loss_per_level(d, gtd, max_disp, 0) for w, d in zip(W4, o[0]))
+        mine = mine + 2.0 * sum(w * TL.wasserstein_loss_per_level(c, of, s, gtd, max_disp, 0, False) for w, c, of, s in zip((1.0, 0.7, 0.5), o[1], o[3], o[2]))
+        mine.backward()
+        num = den = 0.0
+        worst = (0.0, "")
+        for n, p in net.named_parameters():
+            ref = sd[n].grad
+            if ref is None and p.grad is None:
+                continue
+            a = p.grad.detach().double().cpu() if p.grad is not None else torch.zeros_like(sd[n])
+            b = ref if ref is not None else torch.zeros_like(sd[n])
+            num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
+        rel = (num / max(den, 1e-300)) ** 0.5
+        frel = max(float((a.grad.double().cpu() - b.grad).norm() / b.grad.norm().clamp_min(1e-30)) for a, b in zip(lg + rg, lf64 + rf64))
+        dl = abs(float(mine.detach()) - float(tot.detach())) / abs(float(tot.detach()))
+        if log is not None:
+            log.append("%s: loss %.6f (oracle %.6f), parameter gradient rel. L2 %.2e, worst feature gradient %.2e" % (desc, float(mine.detach()), float(tot.detach()), rel, frel))
+        if not (dl < 1e-4 and rel < 1e-3 and frel < 1e-3):
+            found.append(("train", desc, "loss %.6f vs %.6f, parameter gradient rel. L2 %.3g, feature gradient %.3g" % (float(mine.detach()), float(tot.detach()), rel, frel)))
+    except Exception as e:
+        found.append(("train", desc, "raised %s: %s" % (type(e).__name__, str(e)[:300])))
+    return found
+
+
+def sweep_train(n, seed, log=None):
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    r = random.Random(seed + 77)
+    found = []
+    for _ in range(n):
+        found += one_train_case(r, dev, log)
+    return found
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    ap_train = os.environ.get("TS_FUZZ_TRAIN", "0") != "0"
+    log = []
+    bad = sweep_train(a.n, a.seed, log) if ap_train else sweep(a.n, a.seed, log)
+    print("\n".join(log))
+    print("e2e %d cases, %d findings" % (a.n, len(bad)))
+    for f in bad:
+        print("FINDING", *f)
+    sys.exit(1 if bad else 0)

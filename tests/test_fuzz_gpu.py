@@ -28,6 +28,39 @@ def test_random_shapes_inference_forms(family):
     assert not found, "\n".join(" ".join(map(str, f)) for f in found)
 
 
+def test_random_geometries_end_to_end():
+    """tests/fuzz_e2e.py: the launch-plan engine against the oracle aggregation, frame by frame, on planted scenes of random size
+    (multiples of 16 only), candidate count, batch, sequence length and local-map size: |dEPE| < 1e-3 px per frame."""
+    import fuzz_e2e
+    log = []
+    found = fuzz_e2e.sweep(8, seed=0, log=log)
+    _dump("parity_random_geometries_inference.txt", log)
+    assert not found, "\n".join(" ".join(map(str, f)) for f in found)
+    assert len(log) >= 8
+
+
+def test_random_geometries_train_mode_loss_and_all_gradients():
+    """tests/fuzz_e2e.py (train): batch-statistics forward, the reference's objective and the backward of the WHOLE module path
+    against the float64 oracle at random geometry: loss to 1e-4, the full parameter-gradient vector and every feature gradient to
+    1e-3 in the relative L2 sense (measured 1e-6 ... 5e-5)."""
+    import fuzz_e2e
+    log = []
+    found = fuzz_e2e.sweep_train(5, seed=0, log=log)
+    _dump("parity_random_geometries_train.txt", log)
+    assert not found, "\n".join(" ".join(map(str, f)) for f in found)
+
+
+def _dump(name, lines):
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(root, exist_ok=True)
+        with open(os.path.join(root, name), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+
+
 @pytest.mark.parametrize("shape", [(1, 13, 8, 23, 54), (2, 27, 2, 34, 49), (1, 2, 4, 35, 7), (1, 24, 7, 4, 39), (2, 33, 16, 5, 13)])
 def test_deconv2d_k4s2_few_output_channels_and_odd_widths(shape):
     """ConvTranspose2d(4, 2, 1) (module.py:453-457) with Cout <= 8 (the entry assumed a 16-wide weight pitch where its callers lay

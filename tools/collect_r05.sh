@@ -13,6 +13,7 @@ cp $O/k1_bench.txt $P/r05_k1_bench.txt; cp $O/k1_bench_backward.txt $P/r05_k1_be
 cp $O/mfma_util_b4.txt $P/r05_k3_mfma_util_pmc.txt; cp $O/sequence.jsonl $P/r05_sequence_bench.jsonl; cp $O/stress_bench.txt $P/r05_stress_bench.txt
 cp $O/train_graph_kernels_by_family.txt $P/r05_train_graph_kernels_by_family.txt; cp $O/train_graph_kernels_by_grid.txt $P/r05_train_graph_kernels_by_grid.txt
 python tools/parity_planted_summary.py gpurun_out > $P/r05_parity_planted.txt 2>&1
+(echo '# tests/test_fuzz_gpu.py: tests/fuzz_e2e.py sweeps, launch-plan engine vs the oracle per frame / train-mode module path vs the float64 oracle'; cat gpurun_out/parity_random_geometries_inference.txt gpurun_out/parity_random_geometries_train.txt) > $P/r05_parity_random_geometries.txt
 python tools/parity_stagewise_summary.py > $P/r05_parity_stagewise.txt 2>&1
 cp $O/x6s_bench.txt $P/r05_x6s_bench.txt; cp $O/layer_table_b1.txt $P/r05_layer_table_batch1.txt; cp $O/layer_table_b4.txt $P/r05_layer_table_batch4.txt
 cp $O/bench_train_2ranks_one_device.json $P/r05_bench_train_2ranks_one_device.json

@@ -78,20 +78,34 @@ def one_train_case(r, dev, log=None):
     from oracle import aggregation as oagg
     from oracle import losses as olo
     from temporalstereo_amd import losses as TL
+    from oracle import temporal as otemp
+    from temporalstereo_amd import temporal
     B, H, W, ns = r.randint(1, 2), 16 * r.randint(5, 10), 16 * r.randint(6, 14), r.choice([4, 6, 8])
+    frames = r.choice([1, 2])                    # 2: an eval / no_grad previous frame and update_map in front (TemporalStereo.py:250-280)
+    n_local = 0 if frames == 1 else r.choice([1, 3])
+    baseline = r.choice([0.25, 0.54, 1.0])
     max_disp, seed = 16 * ns, synth.SEED0 + r.randint(0, 10000)
-    desc = "train %dx%d D=%d B=%d seed=%d" % (H, W, max_disp, B, seed)
+    desc = "train %dx%d D=%d B=%d T=%d local=%d seed=%d" % (H, W, max_disp, B, frames, n_local, seed)
     found = []
     try:
-        sc = synth.stereo_sequence(seed, B, H, W, frames=1, max_disp=max_disp, fx=r.uniform(300.0, 1100.0))
+        sc = synth.stereo_sequence(seed, B, H, W, frames=frames, max_disp=max_disp, fx=r.uniform(300.0, 1100.0), baseline=baseline)
         T64 = lambda a: torch.from_numpy(a).double()
-        lf, rf, il, ir = sc["frames"][0]
-        gt = T64(sc["gt"][0])
+        lf, rf, il, ir = sc["frames"][-1]
+        gt = T64(sc["gt"][-1])
         ck = PT.load_checkpoint()
         sd = {k: (v.double().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else
                   (v.double() if v.is_floating_point() else v)) for k, v in ck.items()}
         lf64, rf64 = [T64(x).requires_grad_(True) for x in lf], [T64(x).requires_grad_(True) for x in rf]
-        out = oagg.aggregate(sd, lf64, rf64, T64(il), T64(ir), {}, cfg=dict(coarse=dict(num_sample=ns)), training=True)
+        prev64, prev_g = {}, {}
+        eye = torch.eye(4).expand(B, 4, 4).contiguous()
+        if frames == 2:
+            l0, r0, i0, j0 = sc["frames"][0]
+            with torch.no_grad():
+                o0 = oagg.aggregate({k: v.detach() for k, v in sd.items()}, [T64(x) for x in l0], [T64(x) for x in r0], T64(i0), T64(j0), {},
+                                    cfg=dict(coarse=dict(num_sample=ns)), training=False)
+            prev64 = otemp.update_map(dict(o0[5]), T64(sc["K"]), T64(sc["T"][1]), eye.double(), baseline, H, W, use_past_cost=True,
+                                      local_map_size=n_local)
+        out = oagg.aggregate(sd, lf64, rf64, T64(il), T64(ir), prev64, cfg=dict(coarse=dict(num_sample=ns)), training=True)
         W4 = (2.0, 1.0, 0.7, 0.5)
         tot = sum(w * olo.smooth_l1_loss_per_level(olo.rescale_to_full(d, (H, W)), gt, max_disp) for w, d in zip(W4, out[0]))
         tot = tot + 2.0 * sum(w * olo.wasserstein_loss_per_level(c, o, s, gt, max_disp) for w, c, o, s in zip((1.0, 0.7, 0.5), out[1], out[3], out[2]))
@@ -99,10 +113,16 @@ def one_train_case(r, dev, log=None):
 
         net = bench.build_model(dev, seed, ns)
         net.load_state_dict(ck, strict=True)
-        net.train()
         to = lambda a: torch.from_numpy(a).to(dev)
+        if frames == 2:
+            net.eval()
+            with torch.no_grad():
+                p0 = net([to(x) for x in l0], [to(x) for x in r0], to(i0), to(j0), {})
+            prev_g = temporal.update_map(dict(p0[5]), to(sc["K"]), to(sc["T"][1]), eye.to(dev), baseline, H, W, use_past_cost=True,
+                                         local_map_size=n_local)
+        net.train()
         lg, rg = [to(x).requires_grad_(True) for x in lf], [to(x).requires_grad_(True) for x in rf]
-        o = net(lg, rg, to(il), to(ir), {})
+        o = net(lg, rg, to(il), to(ir), prev_g)
         gtd = gt.float().to(dev)
         mine = sum(w * TL.smooth_l1_loss_per_level(d, gtd, max_disp, 0) for w, d in zip(W4, o[0]))
         mine = mine + 2.0 * sum(w * TL.wasserstein_loss_per_level(c, of, s, gtd, max_disp, 0, False) for w, c, of, s in zip((1.0, 0.7, 0.5), o[1], o[3], o[2]))

@@ -101,3 +101,18 @@ def test_x6_split_k_choice_without_gpu(built_lib):
     # without a workspace the entry point runs unsplit; its argument checks come first either way
     rc = L.ts_conv3d_hw_x6_fwd(None, None, None, None, None, 1, 352, 32, 12, 34, 60, 1, 0, 0.0, 0, 0, 0, 0, None, 0, None, 0, None)
     assert rc == -1 and b"NULL" in L.ts_last_error_string()
+
+
+def test_every_launching_entry_refuses_empty_arguments(built_lib):
+    """Error behaviour of the boundary (include/ts_hip.h: status ints + ts_last_error_string): every launching entry called with null
+    pointers and zero sizes returns a non-zero status -- none dereferences, none launches, none answers TS_OK.  Run in a child
+    process: a missing check would be a crash."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "abi_null_worker.py")
+    p = subprocess.run([sys.executable, worker], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    lines = [l.split() for l in p.stdout.strip().splitlines()]
+    assert p.returncode == 0 and lines and lines[-1] == ["done"], "worker died after %s\n%s" % (lines[-1] if lines else "-", p.stderr[-2000:])
+    accepted = [n for n, rc in lines[:-1] if int(rc) == 0]
+    assert not accepted, "entries that answered TS_OK to empty arguments: %s" % accepted
+    assert len(lines) > 80

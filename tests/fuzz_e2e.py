@@ -32,14 +32,32 @@ def one_case(r, dev, log=None):
     found = []
     try:
         case = PT.PlantedCase(c, seed, dev)
-        eng = InferenceEngine(case.net, backend="native", replay=r.choice(["plan", "eager"]))
+        # the forms bench.py times, too: three passes in flight on bound inputs (single frames), the two-phase begin / finish schedule
+        form = r.choice(["plan", "eager", "pipeline3"] if frames == 1 else ["plan", "eager", "two-phase"])
+        desc += " " + form
+        if form == "pipeline3":
+            eng = InferenceEngine(case.net, backend="native", replay="plan", inputs="bind", pipeline=3)
+        elif form == "two-phase":
+            eng = InferenceEngine(case.net, backend="native", replay="plan", inputs="bind")
+        else:
+            eng = InferenceEngine(case.net, backend="native", replay=form)
         info, io = {}, {}
         for t in range(frames):
             o32 = case.oracle_frame(t, io)[0]
             io = o32[5]
+            if form == "two-phase":
+                h = eng.begin(*case.frames_gpu[t])             # issued BEFORE the state update, as the timed schedule does
             if t > 0:
                 info = case.native_update(t, info)
-            on = eng(*case.frames_gpu[t], dict(info))
+            if form == "two-phase":
+                on = eng.finish(h, dict(info))
+            elif form == "pipeline3":
+                for _ in range(3):                             # every buffer set once ...
+                    eng(*case.frames_gpu[t], {})
+                on = eng(*case.frames_gpu[t], {})              # ... and the first one again
+                torch.cuda.synchronize()
+            else:
+                on = eng(*case.frames_gpu[t], dict(info))
             info = _clone(on[5])
             gt = case.gt[t].double()
             valid = (gt > 0) & (gt < case.max_disp)

@@ -329,9 +329,38 @@ def fuzz_losses(r, g):
         lambda a: ol.smooth_l1_loss_per_level(ol.rescale_to_full(a, (H, W)), gt, md, 0), [e], tol=3e-4, ref_dtype=torch.float32)
 
 
+
+def fuzz_glue(r, g):
+    """The element-wise glue of the levels: the five range candidates behind the resized local map (fine.py:82-93), the offset head
+    (module.py:384-390), argmin selection."""
+    B, H, W = r.randint(1, 3), r.randint(1, 30), r.randint(1, 60)
+    low = torch.rand(B, 1, H, W, generator=g, dtype=torch.float64) * 40 - 4
+    high = low + torch.rand(B, 1, H, W, generator=g, dtype=torch.float64) * 16 - 2        # (high < low happens: |high - low| and min)
+    nl = r.choice([0, 1, 3])
+    lm = None
+    if nl:
+        h, w = r.randint(1, 30), r.randint(2, 60)
+        lm = torch.rand(B, nl, h, w, generator=g, dtype=torch.float64) * 30
+
+    def ref(lo, hi):
+        c = [torch.abs(hi - lo) * k / 8.0 + torch.minimum(lo, hi) for k in (0, 3, 4, 5, 8)]
+        out = torch.cat(c, dim=1)
+        if lm is not None:
+            m = F.interpolate(lm.to(lo.dtype) * W / lm.shape[-1], size=(H, W), mode="bilinear", align_corners=True)
+            out = torch.cat([m, out], dim=1)
+        return out
+    lmg = lm.float().to(dev) if lm is not None else None
+    run("candidates_in_range", "B%d %dx%d local=%d" % (B, H, W, nl), lambda lo, hi: TF.candidates_in_range(lo, hi, lmg), ref, [low, high],
+        ref_dtype=torch.float32)
+    x = rnd(g, B, r.randint(1, 14), H, W, scale=r.choice([1.0, 50.0, 300.0]))
+    delta = r.choice([1.0, 0.5, 2.0])
+    run("offset_head", "B%d %dx%d delta=%g" % (B, H, W, delta), lambda a: TF.offset_head(a, delta),
+        lambda a: torch.tanh(a / 100.0).clamp(-1, 1) * delta, [x])
+
+
 OPS = dict(conv3d=fuzz_conv3d, deconv2d=fuzz_deconv2d, block_cost=fuzz_block_cost, dense=fuzz_dense, pool_resize=fuzz_pool_resize,
            regress=fuzz_regress, upsample=fuzz_upsample, topk=fuzz_topk, correlation=fuzz_correlation, sort_gather=fuzz_sort_gather,
-           conv_bn_act=fuzz_conv_bn_act, splat=fuzz_splat, losses=fuzz_losses)
+           conv_bn_act=fuzz_conv_bn_act, splat=fuzz_splat, losses=fuzz_losses, glue=fuzz_glue)
 
 def sweep(name, n, seed):
     """-> the findings of `n` seeded cases of op family `name`."""

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("op", ["conv3d", "deconv2d", "block_cost", "dense", "pool_resize", "regress", "upsample", "topk", "correlation",
-                                "sort_gather", "conv_bn_act", "splat", "losses"])
+                                "sort_gather", "conv_bn_act", "splat", "losses", "glue"])
 def test_random_shapes(op):
     import fuzz_ops
     found = fuzz_ops.sweep(op, 30, seed=0)

@@ -408,6 +408,36 @@ def _shift_vec(bias, n):
     return v
 
 
+# Train-mode (1,3,3) stride-1 layers on the bf16-split matrix form (csrc/conv3d.hip ig_conv_x6_kernel; fp32 products from six bf16
+# products, error below the f32-input MFMA chain's: tests/test_conv_x6_gpu.py), forward and input gradient, where the inference
+# engine would choose it too: >= 16 input channels, more than 8 output channels, a grid that fills the chip.  The split copy of the
+# weights is made per call from the kernel layout (the parameters move every step).  TS_TRAIN_X6=0 for the A/B.
+_TRAIN_X6 = __import__("os").environ.get("TS_TRAIN_X6", "1") != "0"
+_TRAIN_X6_MIN_GRID = int(__import__("os").environ.get("TS_TRAIN_X6_MIN_GRID", "256"))
+
+
+def _x6_conv(x, w_t, y, B, Cin, Cout, D, H, W, dilation, shift=None, scale=None, act=0, addend=None):
+    """y = act(scale * conv(x) + shift) through ts_conv3d_hw_x6_fwd when the shape qualifies; False when it does not."""
+    if not _TRAIN_X6 or Cin < 32:
+        return False
+    L = _lib.lib()
+    if not L.ts_conv3d_hw_x6_supported(Cin, Cout, W, 1, dilation, 0):
+        return False
+    grid = ((H + 7) // 8) * ((W + 31) // 32) * D * B * ((Cout + 31) // 32)
+    wsb = _q("ts_conv3d_hw_x6_workspace_bytes", B, Cin, Cout, D, H, W)
+    if grid < _TRAIN_X6_MIN_GRID and not wsb:
+        return False
+    w6 = torch.empty(_q("ts_conv3d_hw_x6_weight_bytes", Cin, Cout), device=x.device, dtype=torch.uint8)
+    _lib.check(L.ts_conv3d_hw_x6_weight_split(_lib.ptr(w_t), _lib.ptr(w6), Cin, Cout, _stream()), "ts_conv3d_hw_x6_weight_split")
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
+    Ho, Wo = H, W
+    rc = L.ts_conv3d_hw_x6_fwd(_lib.ptr(x), _lib.ptr(w6), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), B, Cin, Cout, D, H, W, dilation,
+                               int(act), 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1), _lib.ptr(addend),
+                               (Cout * Ho * Wo) if addend is not None else 0, _lib.ptr(ws), wsb, _stream())
+    _lib.check(rc, "ts_conv3d_hw_x6_fwd")
+    return True
+
+
 def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, act=0, addend=None):
     """Raw Conv3d (1,3,3) [padding == dilation] / ConvTranspose3d (1,3,3) stride 2, padding 1, output_padding 1 (+ bias); with
     `fold` = (scale, shift) the epilogue applies act(y * scale + shift) (an eval-mode BatchNorm folded in, bias included)."""
@@ -431,6 +461,8 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, a
         addend = _lib.contiguous(addend)
         if addend.numel() != B * Cout * Ho * Wo or transposed:
             raise ValueError("conv addend: one [B, Cout, Ho, Wo] plane per batch item (stride-1 / stride-2 forms only)")
+    if stride == 1 and not transposed and _x6_conv(x, w_t, y, B, Cin, Cout, D, H, W, dilation, sh, sc, act, addend):
+        return x, y, (B, Cin, Cout, D, H, W, stride, dilation, transposed)
     rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(w_t), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, D, H, W, stride, dilation,
                             int(transposed), int(act), 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
                             _lib.ptr(addend), (Cout * Ho * Wo) if addend is not None else 0, _lib.ptr(ws), wsb, _stream())
@@ -536,9 +568,11 @@ def _hw_backward(x, weight, dy, geom, need_x, need_w):
         else:
             w_b = _layout(weight, 0, 1, flip=True)                               # taps flipped
         dx = torch.empty_like(x)
-        rc = L.ts_conv3d_hw_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, D, H, W, stride, dilation,
-                                     int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
-        _lib.check(rc, "ts_conv3d_hw_bwd_data")
+        # stride 1: the input gradient is the same convolution of dy with the flipped taps, Cout -> Cin channels
+        if not (stride == 1 and not transposed and _x6_conv(dy, w_b, dx, B, Cout, Cin, D, H, W, dilation)):
+            rc = L.ts_conv3d_hw_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, D, H, W, stride, dilation,
+                                         int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
+            _lib.check(rc, "ts_conv3d_hw_bwd_data")
     if need_w:
         dw = torch.empty_like(weight)
         ws, nws = _wgrad_workspace(Cin, Cout, 9, x.device)

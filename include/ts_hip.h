@@ -458,7 +458,9 @@ int ts_merge_candidates_fwd(const float* volume, const float* sample, const floa
                             long long out_cstride, void* stream);
 /* K5 upsamplers: ConvexUpsample.forward module.py:336-353 (mask [B,9*f*f,H,W]); UNet.upsample :468-482
  * (mask [B,9,Ho,Wo]); ConvTranspose2d(4, stride 2, padding 1) of UNet :453-457 (w_t [Cin][4][4][CoutPad],
- * CoutPad = 16 or 32); bilinear align_corners resize with a value scale. */
+ * CoutPad = ts_conv_cout_pad(Cout) = 8 | 16 | 32 as for every other convolution entry since ABI 9; up to ABI 8 this entry
+ * alone wanted 16 | 32, which its own training-side caller did not honour for Cout <= 8); bilinear align_corners resize
+ * with a value scale. */
 int ts_convex_upsample_fwd(const float* mask, const float* disp, float* out, int B, int H, int W, int factor,
                            float disp_scale, void* stream);
 /* ts_convex_upsample_fwd + ts_range_candidates_fwd (on the upsampled map) as one launch */

@@ -8,6 +8,7 @@ cp $O/bench_native_b4.json $P/r05_bench_native_batch4.json; cp $O/bench_native_b
 cp $O/kernel_stats.csv $P/r05_bench_native_kernel_stats.csv; cp $O/kernels_by_grid.txt $P/r05_bench_native_kernels_by_grid.txt
 cp $O/bench_under_rocprof.json $P/r05_bench_native_under_rocprof.json
 cp $O/bench_train.json $P/r05_bench_train.json; cp $O/bench_train_graph.json $P/r05_bench_train_graph.json
+[ -f $O/bench_train_graph_b4.json ] && cp $O/bench_train_graph_b4.json $P/r05_bench_train_graph_batch4.json
 cp $O/k1_bench.txt $P/r05_k1_bench.txt; cp $O/k1_bench_backward.txt $P/r05_k1_bench_backward.txt; cp $O/k1_corr_rows.txt $P/r05_k1_corr_rows.txt; cp $O/r05_k1_hbm_traffic_pmc.json $P/r05_k1_hbm_traffic_pmc.json
 (cat $O/pmc_fetch_k1.txt; cat $O/pmc_write_k1.txt) > $P/r05_k1_hbm_traffic_pmc.txt
 cp $O/mfma_util_b4.txt $P/r05_k3_mfma_util_pmc.txt; cp $O/sequence.jsonl $P/r05_sequence_bench.jsonl; cp $O/stress_bench.txt $P/r05_stress_bench.txt

@@ -35,6 +35,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-all-cores > $O/bench_native
 python bench.py --steps 200 --warmup 20 --no-extras --no-cpu-baseline > $O/bench_native_200.json 2>/dev/null
 python bench.py --batch 4 --no-cpu-baseline --no-extras > $O/bench_native_b4.json 2>/dev/null; python bench.py --batch 8 --no-cpu-baseline --no-extras > $O/bench_native_b8.json 2>/dev/null
 python bench.py --mode train --steps 30 --warmup 5 > $O/bench_train.json 2>/dev/null; python bench.py --mode train-graph --steps 30 --warmup 5 > $O/bench_train_graph.json 2>/dev/null
+python bench.py --mode train-graph --batch 4 --steps 20 --warmup 4 > $O/bench_train_graph_b4.json 2>/dev/null      # BASELINE configs[2]: T=2, batch 4
 python tools/k1_bench.py > $O/k1_bench.txt 2>&1; python tools/k1_bench.py --backward 2>&1 | grep '^K1' > $O/k1_bench_backward.txt
 python tools/exp/k1_corr_ablate.py 2>&1 | grep -v amdgpu.ids > $O/k1_corr_rows.txt
 python tools/stress_bench.py > $O/stress_bench.txt 2>&1

@@ -1589,9 +1589,10 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
   const float* Rg = R + goff;
   const int Wl = 4 * s.Wq;
   float* accL = lds + static_cast<size_t>(GRP) * TR * 4 * s.Wqp;       // [TR][Wl]
-  float* accR = accL + TR * Wl;                                        // [TR][Wl]
+  // gR in DOUBLE: an LDS float atomic add is 22x the cost of ds_add_f64 on gfx950 (block_cost_bwd_rows, tools/exp/lds_atomic_rate.hip)
+  double* accR = reinterpret_cast<double*>(accL + TR * Wl);            // [TR][Wl] (8-byte aligned: every term above is a multiple of 4 floats)
   const int tid = threadIdx.x, nthr = blockDim.x;
-  for (int i = tid; i < 2 * TR * Wl; i += nthr) accL[i] = 0.f;
+  for (int i = tid; i < TR * Wl; i += nthr) { accL[i] = 0.f; accR[i] = 0.0; }
   stage_right_rows<VEC>(lds, Rg, y0, H, W, HW, s.Wq, s.Wqp);           // ends with a barrier
 
   const float Wm1 = static_cast<float>(W - 1);
@@ -1635,7 +1636,7 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
       }
     if (s.scales > 2 && by < s.H2 && bx < s.W2) dp2 = dP2[(pbase * s.H2 + by) * s.W2 + bx];
   }
-  auto lds_add = [](float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto lds_add = [](double* p, float v) { __hip_atomic_fetch_add(p, static_cast<double>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
 #pragma unroll 1
   for (int c = 0; c < GRP; ++c) {
@@ -1747,9 +1748,16 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
       const int which = i / (TR * s.Wq);                  // 0: gL, 1: gR
       const int rj = i - which * TR * s.Wq;
       const int r = rj / s.Wq, j = rj - r * s.Wq;
-      float* acc = (which ? accR : accL) + r * Wl + 4 * j;
-      const float4 v = *reinterpret_cast<const float4*>(acc);
-      *reinterpret_cast<float4*>(acc) = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v;
+      if (which) {
+        double* acc = accR + r * Wl + 4 * j;
+        v = make_float4(static_cast<float>(acc[0]), static_cast<float>(acc[1]), static_cast<float>(acc[2]), static_cast<float>(acc[3]));
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+      } else {
+        float* acc = accL + r * Wl + 4 * j;
+        v = *reinterpret_cast<const float4*>(acc);
+        *reinterpret_cast<float4*>(acc) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       float* dst = which ? gR : gL;
       const int y = y0 + r;
       if (dst != nullptr && y < H) st4<VEC>(dst + goff + c * HW + static_cast<size_t>(y) * W, 4 * j, W, v);
@@ -1769,6 +1777,147 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
   }
 }
 
+// Backward of the sampled path with one lane per ROW of a 4x4 block and the candidates as the OUTER loop (round 5; the forward
+// counterpart is block_cost_corr_rows).  block_cost_bwd_tile gives a lane one (candidate, block) and all four rows: the block means
+// need all rows before any gradient can be formed, so it evaluates every difference twice (two passes over the rows per channel),
+// sums gL over the candidate lanes with four shuffles per pixel and stages it through LDS.  Here the four rows of a block are the four
+// lanes of a quad: e is evaluated ONCE, the 2x2 / 4x4 sums are two quad permutes, gL accumulates over the candidates in registers
+// and leaves as plain stores, the tap position is one division per (candidate, pixel) instead of one per channel.  What stays is the
+// scatter of gR: LDS float atomics into one row tile per channel (all eight resident: the candidate loop is outside).
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256)
+block_cost_bwd_rows(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
+                    const float* __restrict__ dout, const float* __restrict__ dP1, const float* __restrict__ dP2,
+                    float* __restrict__ gL, float* __restrict__ gR, float* __restrict__ gD, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int by = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int y0 = by * TR;
+  const int H = s.H, W = s.W, D = s.D, C = s.C;
+  const size_t HW = static_cast<size_t>(H) * W;
+  const size_t goff = (static_cast<size_t>(b) * C + g * GRP) * HW;
+  const float* Lg = L + goff;
+  const int Wl = 4 * s.Wq;
+  // gR accumulates in DOUBLE: on gfx950 an LDS float atomic add costs 192 cycles per wave instruction (three per lane, serialised),
+  // ds_add_f64 8.6 (tools/exp/lds_atomic_rate.hip: ds_add_u32 6.5, ds_add_u64 8.1, a plain write 7.2).  Four channels at a time so
+  // that two workgroups still share a CU; the candidate loop runs once per half.
+  constexpr int CH = GRP / 2;
+  double* accR = reinterpret_cast<double*>(lds + static_cast<size_t>(GRP) * TR * 4 * s.Wqp);       // [CH][TR][Wl]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  stage_right_rows<true>(lds, R + goff, y0, H, W, HW, s.Wq, s.Wqp);   // ends with a barrier
+
+  const int r = tid & 3, bx = tid >> 2;
+  const int y = y0 + r, x4 = bx * 4;
+  const bool live = bx < s.nbx && y < H;
+  const float m = live ? 1.f : 0.f;
+  const size_t rowoff = static_cast<size_t>(min(y, H - 1)) * W + (bx < s.nbx ? x4 : 0);
+  const float Wm1 = static_cast<float>(W - 1);
+  const size_t cstride = static_cast<size_t>(D) * HW;
+
+  auto lds_add = [](double* p, float v) {
+    __hip_atomic_fetch_add(p, static_cast<double>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  const int py = 2 * by + (r >> 1);
+
+#pragma unroll 1
+ for (int c0 = 0; c0 < GRP; c0 += CH) {
+  for (int i = tid; i < CH * TR * Wl; i += nthr) accR[i] = 0.0;
+  float lv[CH][4], gl[CH][4];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    unpack(*reinterpret_cast<const float4*>(Lg + (c0 + c) * HW + rowoff), lv[c]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gl[c][k] = 0.f;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int d = 0; d < D; ++d) {
+    const float* dplane = dout + (static_cast<size_t>(b) * s.Ctot * D + d) * HW + rowoff;
+    const size_t pbase = (static_cast<size_t>(b) * s.G + g) * D + d;
+    float dv[4], dg0[4];
+    unpack(*reinterpret_cast<const float4*>(disp + (static_cast<size_t>(b) * D + d) * HW + rowoff), dv);
+    unpack(*reinterpret_cast<const float4*>(dplane + static_cast<size_t>(s.mainC + g) * cstride), dg0);
+    float dp1a = 0.f, dp1b = 0.f, dp2 = 0.f;                 // this row pair's two 2x2 cells, the block's 4x4 cell
+    if (live && s.scales > 1 && py < s.H1) {
+      if (2 * bx < s.W1) dp1a = dP1[(pbase * s.H1 + py) * s.W1 + 2 * bx];
+      if (2 * bx + 1 < s.W1) dp1b = dP1[(pbase * s.H1 + py) * s.W1 + 2 * bx + 1];
+    }
+    if (live && s.scales > 2 && by < s.H2 && bx < s.W2) dp2 = dP2[(pbase * s.H2 + by) * s.W2 + bx];
+    int a[4];
+    float f[4], w0[4], w1[4], gd[4] = {0.f, 0.f, 0.f, 0.f};
+    int o0[4], o1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      column_of<true>(x4 + k, d, source_position(x4 + k, dv[k], W, Wm1), a[k], f[k]);
+      const int i0 = min(max(a[k], 0), W - 1), i1 = min(max(a[k] + 1, 0), W - 1);
+      o0[k] = (i0 & 3) * s.Wqp + (i0 >> 2);
+      o1[k] = (i1 & 3) * s.Wqp + (i1 >> 2);
+      w0[k] = (a[k] >= 0 && a[k] < W) ? 1.f : 0.f;            // masks by multiplication (a select becomes a load behind a branch)
+      w1[k] = (a[k] + 1 >= 0 && a[k] + 1 < W) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float* src = lds + static_cast<size_t>((c0 + c) * TR + r) * 4 * s.Wqp;
+      float e[4], slope[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float r0 = src[o0[k]] * w0[k], r1 = src[o1[k]] * w1[k];
+        slope[k] = r1 - r0;
+        e[k] = (lv[c][k] - ((1.f - f[k]) * r0 + f[k] * r1)) * m;
+      }
+      const float sa = e[0] + e[1], sb = e[2] + e[3];
+      const float pa = sa + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(sa), 0xB1, 0xF, 0xF, true));
+      const float pb = sb + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(sb), 0xB1, 0xF, 0xF, true));
+      const float q = pa + pb;
+      const float m2 = (q + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(q), 0x4E, 0xF, 0xF, true))) * 0.0625f;
+      const size_t chan = static_cast<size_t>(g * GRP + c0 + c);
+      float dmain[4] = {0.f, 0.f, 0.f, 0.f}, dwarp[4];
+      if (!s.omit_ref) unpack(*reinterpret_cast<const float4*>(dplane + chan * cstride), dmain);
+      unpack(*reinterpret_cast<const float4*>(dplane + (chan + s.tch) * cstride), dwarp);
+      double* acc = accR + static_cast<size_t>(c * TR + r) * Wl;
+      int pend_a = -1;
+      float pend_v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float ge = -2.f * e[k] * dg0[k];
+        ge -= 0.125f * (k < 2 ? pa * dp1a : pb * dp1b);         // 2 * (sum/4) / 4
+        ge -= 0.125f * m2 * dp2;                                 // 2 * mean / 16
+        gl[c][k] += live ? ge + dmain[k] : 0.f;
+        const float gt = dwarp[k] - ge;
+        // gR: two taps per pixel; the +1 tap is carried to the next pixel and merged into its tap when they share a column
+        const bool t0 = live && a[k] >= 0 && a[k] < W, t1 = live && a[k] + 1 >= 0 && a[k] + 1 < W;
+        const bool merge = t0 && pend_a == a[k];
+        if (pend_a >= 0 && !merge) lds_add(acc + pend_a, pend_v);
+        if (t0) lds_add(acc + a[k], (1.f - f[k]) * gt + (merge ? pend_v : 0.f));
+        pend_a = t1 ? a[k] + 1 : -1;
+        pend_v = f[k] * gt;
+        gd[k] -= live ? gt * slope[k] : 0.f;
+      }
+      if (pend_a >= 0) lds_add(acc + pend_a, pend_v);
+    }
+    if (gD && live) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(gD + (static_cast<size_t>(b) * D + d) * HW + rowoff + k, gd[k]);
+    }
+  }
+  if (gL != nullptr && live) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) st4<true>(gL + goff + (c0 + c) * HW + static_cast<size_t>(y) * W, x4, W, pack(gl[c]));
+  }
+  __syncthreads();
+  if (gR != nullptr) {
+    for (int i = tid; i < CH * TR * s.Wq; i += nthr) {
+      const int j = i % s.Wq, cr = i / s.Wq;
+      const int rr = cr & (TR - 1), c = cr >> 2;
+      const double* a4 = accR + static_cast<size_t>(cr) * Wl + 4 * j;
+      if (y0 + rr < H)
+        st4<true>(gR + goff + (c0 + c) * HW + static_cast<size_t>(y0 + rr) * W, 4 * j, W,
+                  make_float4(static_cast<float>(a4[0]), static_cast<float>(a4[1]), static_cast<float>(a4[2]), static_cast<float>(a4[3])));
+    }
+  }
+  __syncthreads();
+ }
+}
+
 template <bool SAMPLED>
 int launch_bwd(const float* left, const float* right, const float* disp, const float* grad_out,
                float* grad_left, float* grad_right, float* grad_disp, void* workspace,
@@ -1781,7 +1930,7 @@ int launch_bwd(const float* left, const float* right, const float* disp, const f
   hipStream_t st = ts::as_stream(stream);
   const size_t nfeat = static_cast<size_t>(B) * C * H * W * sizeof(float);
   // tile path: the workgroup that owns a row tile writes every element of it (no zero fill, no global atomics)
-  const size_t tile_lds = (static_cast<size_t>(GRP) * TR * 4 * s.Wqp + 2 * TR * 4 * s.Wq + 4) * sizeof(float);
+  const size_t tile_lds = (static_cast<size_t>(GRP) * TR * 4 * s.Wqp + 3 * TR * 4 * s.Wq + 4) * sizeof(float);   // R rows, gL tile (float), gR tile (double)
   const int tile_threads = D <= 16 ? ((s.nbx + 64 / D - 1) / (64 / D)) * 64 : 1 << 30;   // 64 / D blocks per wave
   const bool tile = tile_lds <= 64 * 1024 && tile_threads <= 512;
   if (!tile) {
@@ -1811,6 +1960,17 @@ int launch_bwd(const float* left, const float* right, const float* disp, const f
   int threads = static_cast<int>(ts::round_up(static_cast<size_t>((nitems + passes - 1) / passes), ts::kWave));
   if (threads > 256) threads = 256;
   const dim3 grid(s.nby, s.G, B);
+  {   // sampled path on aligned maps of up to 256 columns: one lane per block row, candidates outside (block_cost_bwd_rows)
+    static const bool rows = [] { const char* e = getenv("TS_K1_BWD_ROWS"); return !e || atoi(e) != 0; }();
+    const int rthreads = static_cast<int>(ts::round_up(static_cast<size_t>(s.nbx) * 4, ts::kWave));
+    const size_t rlds = (static_cast<size_t>(GRP) * TR * 4 * s.Wqp + static_cast<size_t>(GRP) * TR * 4 * s.Wq) * sizeof(float);   // R rows + [GRP/2][TR][Wl] doubles
+    if (SAMPLED && rows && vec && rthreads <= 256 && rlds <= 64 * 1024 && (!grad_left || ts::aligned16(grad_left)) &&
+        (!grad_right || ts::aligned16(grad_right))) {
+      hipLaunchKernelGGL((block_cost_bwd_rows<0>), grid, dim3(rthreads), rlds, st, left, right, disp, grad_out, dP1, dP2, grad_left,
+                         grad_right, grad_disp, s);
+      return ts::launched("block_cost_bwd_rows");
+    }
+  }
   if (tile) {
     const int tthreads = tile_threads;
     if (vec) hipLaunchKernelGGL((block_cost_bwd_tile<SAMPLED, true>), grid, dim3(tthreads), tile_lds, st, left, right, disp,

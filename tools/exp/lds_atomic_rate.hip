@@ -1,89 +1,61 @@
-// LDS atomic rate on gfx950: cycles per wave instruction of ds_add_f32 / ds_add_u32 / plain ds_write / read-add-write,
-// conflict-free and with 2-way / 16-way same-address collisions.  hipcc --offload-arch=gfx950 -O3 lds_atomic_rate.hip -o lds_atomic_rate
+// LDS atomic throughput on gfx950: cycles per wave-instruction of ds_add_f32 / ds_add_u32 / ds_add_u64 / plain read-modify-write,
+// conflict-free addresses (lane i -> word i + 64 * step), one workgroup of 256 threads per CU.  Build: hipcc --offload-arch=gfx950
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <vector>
+#include <cstdlib>
 
-template <int KIND, int PATTERN>
-__global__ void __launch_bounds__(256) k(float* out, int iters) {
-  __shared__ float buf[4096];
-  for (int i = threadIdx.x; i < 4096; i += 256) buf[i] = 0.f;
+template <int MODE>
+__global__ void __launch_bounds__(256) k(unsigned long long* out, int iters, float v) {
+  __shared__ float ldsf[8192];
+  unsigned* ldsu = reinterpret_cast<unsigned*>(ldsf);
+  unsigned long long* ldsq = reinterpret_cast<unsigned long long*>(ldsf);
+  double* ldsd = reinterpret_cast<double*>(ldsf);
+  for (int i = threadIdx.x; i < 8192; i += 256) ldsf[i] = 0.f;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int idx;
-  if (PATTERN == 0) idx = lane;                 // conflict-free, distinct banks
-  else if (PATTERN == 1) idx = lane >> 1;       // pairs of lanes on one address
-  else if (PATTERN == 2) idx = lane >> 4;       // 16 lanes on one address
-  else if (PATTERN == 3) idx = (lane * 4) & 63 | (lane >> 4);   // distinct addresses, 4 apart: bank conflicts (2-way on 32 banks... stride 4 -> 8 banks)
-  else idx = (lane * 5) & 63;                   // permuted distinct banks
-  float* p = buf + wave * 1024 + idx;
-  unsigned* pu = reinterpret_cast<unsigned*>(p);
-  const float v = 1.0f + lane * 1e-3f;
-  long long t0 = clock64();
-  for (int i = 0; i < iters; ++i) {
+  const int lane = threadIdx.x;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      float* q = p + u * 64;
-      if (KIND == 0) __hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      else if (KIND == 1) __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(q), 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      else if (KIND == 2) *reinterpret_cast<volatile float*>(q) = v;
-      else if (KIND == 3) { volatile float* vq = q; *vq = *vq + v; }
-      else if (KIND == 4) {               // float add as an integer compare-and-swap loop
-        unsigned* qu = reinterpret_cast<unsigned*>(q);
-        unsigned old = *reinterpret_cast<volatile unsigned*>(qu), assumed;
-        do {
-          assumed = old;
-          old = atomicCAS(qu, assumed, __float_as_uint(__uint_as_float(assumed) + v));
-        } while (old != assumed);
-      } else {                            // 64-bit fixed point (two floats' worth of LDS per value)
-        unsigned long long* q8 = reinterpret_cast<unsigned long long*>(buf + wave * 1024) + idx + u * 32;
-        __hip_atomic_fetch_add(q8, static_cast<unsigned long long>(static_cast<long long>(v * 4294967296.f)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+    for (int s = 0; s < 16; ++s) {
+      const int idx = (lane + 256 * s + it * 7) & 4095;
+      if (MODE == 0) __hip_atomic_fetch_add(ldsf + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (MODE == 1) __hip_atomic_fetch_add(ldsu + idx, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (MODE == 2) __hip_atomic_fetch_add(ldsq + idx, 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (MODE == 3) { ldsf[idx] = ldsf[idx] + v; }
+      else if (MODE == 4) { ldsf[idx] = v + s; }
+      else if (MODE == 5) __hip_atomic_fetch_add(ldsd + idx, static_cast<double>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (MODE == 6) { const float old = __hip_atomic_fetch_add(ldsf + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); v += old * 1e-30f; }
+      else if (MODE == 7) __hip_atomic_fetch_max(reinterpret_cast<int*>(ldsu) + idx, static_cast<int>(v) + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  long long t1 = clock64();
   __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = static_cast<float>(t1 - t0) / (iters * 8.0f) + buf[5] * 0.f;
-}
-
-template <int KIND, int PATTERN>
-void run(const char* name, int blocks_per_cu) {
-  const int nb = 256 * blocks_per_cu, iters = 2000;
-  float* d;
-  hipMalloc(&d, nb * sizeof(float));
-  hipEvent_t a, b;
-  hipEventCreate(&a); hipEventCreate(&b);
-  hipLaunchKernelGGL((k<KIND, PATTERN>), dim3(nb), dim3(256), 0, 0, d, 10);
-  hipEventRecord(a);
-  hipLaunchKernelGGL((k<KIND, PATTERN>), dim3(nb), dim3(256), 0, 0, d, iters);
-  hipEventRecord(b);
-  hipEventSynchronize(b);
-  float ms;
-  hipEventElapsedTime(&ms, a, b);
-  std::vector<float> h(nb);
-  hipMemcpy(h.data(), d, nb * sizeof(float), hipMemcpyDeviceToHost);
-  // wave instructions per CU: blocks_per_cu * 4 waves * iters * 8
-  const double per_cu = double(blocks_per_cu) * 4 * iters * 8;
-  printf("%-34s wg/CU %d: %7.1f clk/instr seen by a wave, %6.2f ns per wave-instr per CU (%.3f ms)\n", name, blocks_per_cu, h[0], ms * 1e6 / per_cu, ms);
-  hipFree(d);
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (ldsf[lane] == 12345.f) out[0] = 0;
 }
 
 int main() {
-  for (int bpc : {1, 4}) {
-    run<0, 0>("ds_add_f32 conflict-free", bpc);
-    run<0, 4>("ds_add_f32 permuted banks", bpc);
-    run<0, 1>("ds_add_f32 2 lanes/address", bpc);
-    run<0, 2>("ds_add_f32 16 lanes/address", bpc);
-    run<0, 3>("ds_add_f32 stride-4 banks", bpc);
-    run<1, 0>("ds_add_u32 conflict-free", bpc);
-    run<1, 1>("ds_add_u32 2 lanes/address", bpc);
-    run<2, 0>("ds_write_b32 conflict-free", bpc);
-    run<3, 0>("read+add+write conflict-free", bpc);
-    run<4, 0>("CAS-loop f32 add conflict-free", bpc);
-    run<4, 1>("CAS-loop f32 add 2 lanes/address", bpc);
-    run<4, 2>("CAS-loop f32 add 16 lanes/address", bpc);
-    run<5, 0>("ds_add_u64 conflict-free", bpc);
-    run<5, 1>("ds_add_u64 2 lanes/address", bpc);
+  unsigned long long* d; hipMalloc(&d, 256 * 8);
+  unsigned long long h[256];
+  const int iters = 200;
+  const char* names[] = {"ds_add_f32", "ds_add_u32", "ds_add_u64", "read+add+write f32", "ds_write_b32", "ds_add_f64", "ds_add_rtn_f32", "ds_max_i32"};
+  for (int mode = 0; mode < 8; ++mode) {
+    for (int rep = 0; rep < 2; ++rep) {
+      if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, d, iters, 1.5f);
+      if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, d, iters, 1.5f);
+      if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, d, iters, 1.5f);
+      if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(256), 0, 0, d, iters, 1.5f);
+      if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(256), 0, 0, d, iters, 1.5f);
+      if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(256), 0, 0, d, iters, 1.5f);
+      if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(256), dim3(256), 0, 0, d, iters, 1.5f);
+      if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(256), dim3(256), 0, 0, d, iters, 1.5f);
+      hipDeviceSynchronize();
+    }
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    double c = 0; for (int i = 0; i < 256; ++i) c += h[i];
+    c /= 256;
+    // 4 waves x iters x 16 instructions per workgroup share one LDS
+    printf("%-22s %8.1f cycles per wave-instruction (4 waves issuing: %8.1f per instruction per CU)\n", names[mode], c / (iters * 16.0), c / (iters * 16.0 * 4));
   }
   return 0;
 }

@@ -1918,6 +1918,81 @@ block_cost_bwd_rows(const float* __restrict__ L, const float* __restrict__ R, co
  }
 }
 
+// The same adjoint as a SCATTER over coalesced fine rows (round 5): a workgroup owns R2 rows of the 1/4-pooled map and the 2 R2 rows of
+// the 1/2-pooled map over them, of one (b, g, d) plane; it reads the fine rows that can reach them (lanes along x), and every fine
+// value goes to its (up to) four cells per level by ds_add_f64 (8.6 cycles per wave instruction: tools/exp/lds_atomic_rate.hip) --
+// cells of other owners are dropped, so nothing is shared between workgroups.  block_cost_upsample_adjoint gathers instead: one lane
+// per pooled cell walking a 6 x 6 ... 10 x 10 window of strided loads (48 us for 21 MB at the 1/4 level).
+constexpr int ADJ_R2 = 2;
+__global__ void __launch_bounds__(256)
+block_cost_upsample_adjoint_rows(const float* __restrict__ dout, float* __restrict__ dP1, float* __restrict__ dP2, const Shape s) {
+  extern __shared__ __attribute__((aligned(16))) double adj_lds[];
+  const int band = blockIdx.x, plane = blockIdx.y;                 // plane = (b * G + g) * D + d
+  const int d = plane % s.D, bg = plane / s.D;
+  const int g = bg % s.G, b = bg / s.G;
+  const size_t HW = static_cast<size_t>(s.H) * s.W;
+  double* acc1 = adj_lds;                                           // [2 ADJ_R2][W1]
+  double* acc2 = adj_lds + 2 * ADJ_R2 * s.W1;                       // [ADJ_R2][W2]
+  const int n1 = 2 * ADJ_R2 * s.W1, n2 = (s.scales > 2) ? ADJ_R2 * s.W2 : 0;
+  for (int i = threadIdx.x; i < n1 + n2; i += blockDim.x) adj_lds[i] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int lvl = 1; lvl <= 2; ++lvl) {
+    if (lvl >= s.scales) break;
+    const int Hs = (lvl == 1) ? s.H1 : s.H2, Ws = (lvl == 1) ? s.W1 : s.W2;
+    const float rh = (lvl == 1) ? s.rh1 : s.rh2, rw = (lvl == 1) ? s.rw1 : s.rw2;
+    const int r0 = (lvl == 1) ? 2 * ADJ_R2 * band : ADJ_R2 * band;                 // first owned pooled row
+    const int nr = min((lvl == 1) ? 2 * ADJ_R2 : ADJ_R2, Hs - r0);
+    if (nr <= 0) continue;
+    double* acc = (lvl == 1) ? acc1 : acc2;
+    // fine rows that can touch rows [r0, r0 + nr): the same bounds the gather form uses, per edge
+    int ylo = 0, yhi = s.H - 1;
+    if (rh > 0.f) {
+      ylo = max(0, static_cast<int>(floorf((r0 - 1) / rh)) - 1);
+      yhi = min(s.H - 1, static_cast<int>(ceilf((r0 + nr) / rh)) + 1);
+    }
+    const float* src = dout + ((static_cast<size_t>(b) * s.Ctot + s.mainC + lvl * s.G + g) * s.D + d) * HW;
+    const int nrows = yhi - ylo + 1;
+    for (int i = threadIdx.x; i < nrows * s.W; i += blockDim.x) {
+      const int yy = i / s.W, x = i - yy * s.W;
+      const int y = ylo + yy;
+      const float hr = rh * static_cast<float>(y);
+      const int h1 = static_cast<int>(hr);
+      const int hp = (h1 < Hs - 1) ? 1 : 0;
+      const float hl = hr - static_cast<float>(h1);
+      const int ra = h1 - r0, rb = h1 + hp - r0;
+      const bool oa = ra >= 0 && ra < nr, ob = rb >= 0 && rb < nr;
+      if (!oa && !ob) continue;
+      const float v = src[static_cast<size_t>(y) * s.W + x];
+      const float wr = rw * static_cast<float>(x);
+      const int w1 = static_cast<int>(wr);
+      const int wp = (w1 < Ws - 1) ? 1 : 0;
+      const float wl = wr - static_cast<float>(w1);
+      auto add = [](double* p, float t) { __hip_atomic_fetch_add(p, static_cast<double>(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+      if (oa) {
+        add(acc + ra * Ws + w1, (1.f - hl) * (1.f - wl) * v);
+        add(acc + ra * Ws + w1 + wp, (1.f - hl) * wl * v);
+      }
+      if (ob) {
+        add(acc + rb * Ws + w1, hl * (1.f - wl) * v);
+        add(acc + rb * Ws + w1 + wp, hl * wl * v);
+      }
+    }
+  }
+  __syncthreads();
+  const size_t pbase = static_cast<size_t>(plane);
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) {
+    const int rr = i / s.W1, c = i - rr * s.W1;
+    const int row = 2 * ADJ_R2 * band + rr;
+    if (row < s.H1) dP1[(pbase * s.H1 + row) * s.W1 + c] = static_cast<float>(acc1[i]);
+  }
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+    const int rr = i / s.W2, c = i - rr * s.W2;
+    const int row = ADJ_R2 * band + rr;
+    if (row < s.H2) dP2[(pbase * s.H2 + row) * s.W2 + c] = static_cast<float>(acc2[i]);
+  }
+}
+
 template <bool SAMPLED>
 int launch_bwd(const float* left, const float* right, const float* disp, const float* grad_out,
                float* grad_left, float* grad_right, float* grad_disp, void* workspace,
@@ -1947,9 +2022,21 @@ int launch_bwd(const float* left, const float* right, const float* disp, const f
     const long long total = static_cast<long long>(B) * s.G * D * (static_cast<long long>(s.H1) * s.W1 + (scales > 2 ? s.H2 * s.W2 : 0));
     long long blocks = (total + 255) / 256;
     if (blocks > ts::kNumCU * 16) blocks = ts::kNumCU * 16;
-    hipLaunchKernelGGL(block_cost_upsample_adjoint, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
-                       grad_out, dP1, dP2, s);
-    if (int rc = ts::launched("block_cost_upsample_adjoint")) return rc;
+    static const bool adj_rows = [] { const char* e = getenv("TS_K1_ADJOINT_ROWS"); return !e || atoi(e) != 0; }();
+    const long long planes = static_cast<long long>(B) * s.G * D;
+    const int bands = scales > 2 ? (s.H2 + ADJ_R2 - 1) / ADJ_R2 : (s.H1 + 2 * ADJ_R2 - 1) / (2 * ADJ_R2);
+    const size_t alds = (static_cast<size_t>(2) * ADJ_R2 * s.W1 + ADJ_R2 * s.W2) * sizeof(double);
+    // (with three scales H1 >= 2 H2: the 1/2-pooled rows beyond 2 R2 bands of the 1/4 map, if any, need one more band)
+    const int bands1 = (s.H1 + 2 * ADJ_R2 - 1) / (2 * ADJ_R2);
+    if (adj_rows && planes <= 65535 && alds <= 64 * 1024) {
+      hipLaunchKernelGGL(block_cost_upsample_adjoint_rows, dim3(static_cast<unsigned>(bands > bands1 ? bands : bands1), static_cast<unsigned>(planes)),
+                         dim3(256), alds, st, grad_out, dP1, dP2, s);
+      if (int rc = ts::launched("block_cost_upsample_adjoint_rows")) return rc;
+    } else {
+      hipLaunchKernelGGL(block_cost_upsample_adjoint, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
+                         grad_out, dP1, dP2, s);
+      if (int rc = ts::launched("block_cost_upsample_adjoint")) return rc;
+    }
   }
   const bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(grad_out) &&
                    (!SAMPLED || ts::aligned16(disp));

@@ -514,30 +514,69 @@ pool5_max_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gmax
   const float* xp = x + static_cast<size_t>(b) * p.x_bstride + static_cast<size_t>(c) * p.x_cstride;
   const float* gp = gmax + static_cast<size_t>(b) * p.max_bstride + static_cast<size_t>(c) * p.max_cstride;
   float* op = gx + static_cast<size_t>(b) * p.avg_bstride + static_cast<size_t>(c) * p.avg_cstride;
+  // the haloed plane tile as in pool5_avgmax_kernel: this thread's (up to two) elements, their clamped source offsets and padding
+  // flags computed once, the NEXT plane's values in flight under the 25 taps (round 5: the loads of a plane used to be issued
+  // after the barrier that waits for them, one exposed round trip per depth plane: 66-73 us per call against the forward's 14)
+  constexpr int TW = PT_X + 4, TN = (PT_Y + 4) * TW;
+  int soff[2], lidx[2];
+  bool pad[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = min(static_cast<int>(threadIdx.x) + 256 * e, TN - 1);
+    const int cx = i % TW, cy = i / TW;
+    const int gy = ty0 + cy - 2, gx = tx0 + cx - 2;
+    pad[e] = !(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W);
+    soff[e] = min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1);
+    lidx[e] = cy * (TW + 1) + cx;
+  }
+  float* tl = &tile[0][0];
+  float nxt[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) nxt[e] = xp[soff[e]];
+  // Neighbouring windows share their maximum (a local maximum wins up to 125 of them): one global atomic per OUTPUT piled them onto
+  // a few addresses.  The gradient is gathered in LDS first -- one double accumulator per element of the haloed tile and plane of the
+  // five-plane ring, ds_add_f64 (tools/exp/lds_atomic_rate.hip) -- and a plane leaves with one global atomic per touched element once
+  // no later output plane can reach it.
+  __shared__ double acc[5][TN];
+  for (int i = threadIdx.x; i < 5 * TN; i += 256) (&acc[0][0])[i] = 0.0;
   float rm[5];
-  int ri[5];
+  int ri[5];                  // winner of the plane as a position in the haloed tile (row * TW + column), -1 = none
 #pragma unroll
   for (int i = 0; i < 5; ++i) { rm[i] = -INFINITY; ri[i] = -1; }
+  auto flush = [&](int plane) {                                  // plane >= 0: its accumulators are final
+    double* a = acc[plane % 5];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = static_cast<int>(threadIdx.x) + 256 * e;
+      if (i < TN) {
+        const double v = a[i];
+        if (v != 0.0) {                                          // (padding never wins: its accumulators stay zero)
+          atomicAdd(op + static_cast<size_t>(plane) * HW + soff[e], static_cast<float>(v));
+          a[i] = 0.0;
+        }
+      }
+    }
+  };
   for (int d = 0; d < p.D + 2; ++d) {
     float m2 = -INFINITY;
     int i2 = -1;
     if (d < p.D) {
       __syncthreads();
-      for (int i = threadIdx.x; i < (PT_Y + 4) * (PT_X + 4); i += blockDim.x) {
-        const int cx = i % (PT_X + 4), cy = i / (PT_X + 4);
-        const int gy = min(max(ty0 + cy - 2, 0), p.H - 1), gxx = min(max(tx0 + cx - 2, 0), p.W - 1);
-        const bool pad = (ty0 + cy - 2 != gy) || (tx0 + cx - 2 != gxx);
-        const float v = xp[d * HW + static_cast<size_t>(gy) * p.W + gxx];
-        tile[cy][cx] = pad ? NAN : v;
-      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) tl[lidx[e]] = pad[e] ? NAN : nxt[e];
       __syncthreads();
+      const int dn = min(d + 1, p.D - 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) nxt[e] = xp[dn * HW + soff[e]];
+      int best = -1;                                               // tap number ky * 5 + kx of the plane's maximum
 #pragma unroll
       for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
           const float v = tile[ty + ky][tx + kx];
-          if (v > m2) { m2 = v; i2 = (d * p.H + (y + ky - 2)) * p.W + (xx + kx - 2); }     // NaN (padding) never wins
+          if (v > m2) { m2 = v; best = ky * 5 + kx; }            // NaN (padding) never wins; the first of equals stays
         }
+      if (best >= 0) i2 = (ty + best / 5) * TW + (tx + best % 5);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { rm[i] = rm[i + 1]; ri[i] = ri[i + 1]; }
@@ -545,13 +584,21 @@ pool5_max_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gmax
     const int od = d - 2;
     if (od >= 0 && y < p.H && xx < p.W) {
       float m = rm[0];
-      int mi = ri[0];
+      int mi = ri[0], mp = 0;                                     // ring slot i holds plane od - 2 + i
 #pragma unroll
       for (int i = 1; i < 5; ++i)
-        if (rm[i] > m) { m = rm[i]; mi = ri[i]; }
-      if (mi >= 0) atomicAdd(op + mi, gp[od * HW + static_cast<size_t>(y) * p.W + xx]);
+        if (rm[i] > m) { m = rm[i]; mi = ri[i]; mp = i; }
+      if (mi >= 0)
+        __hip_atomic_fetch_add(&acc[(od - 2 + mp + 5) % 5][mi], static_cast<double>(gp[od * HW + static_cast<size_t>(y) * p.W + xx]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (od >= 2) {                // plane od - 2 is out of reach of every later output plane
+      __syncthreads();
+      flush(od - 2);
     }
   }
+  __syncthreads();
+  for (int plane = max(p.D - 2, 0); plane < p.D; ++plane) flush(plane);
 }
 
 // sort + gather backward (coarse.py:103-105 / fine.py:120-122 under autograd): rank of candidate j among its

@@ -359,6 +359,10 @@ int ts_conv3d_hw_x6_supported(int Cin, int Cout, int W, int stride, int dilation
 size_t ts_conv3d_hw_x6_weight_bytes(int Cin, int Cout);
 size_t ts_conv3d_hw_x6_workspace_bytes(int B, int Cin, int Cout, int D, int H, int W);
 int ts_conv3d_hw_x6_weight_split(const float* w_t, void* w6, int Cin, int Cout, void* stream);
+/* ... the same from the FRAMEWORK's weight in one launch (ABI 9; training re-splits per call): element (ci, co, tap) of the
+ * convolution being run = w[ci*stride_ci + co*stride_co + tap*stride_t], taps reversed when flip (input gradient of a stride-1 layer) */
+int ts_conv3d_hw_x6_weight_split_from(const float* w, void* w6, int Cin, int Cout, long long stride_ci, long long stride_co,
+                                      long long stride_t, int flip, void* stream);
 int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* scale, const float* shift, float* y,
                         int B, int Cin, int Cout, int D, int H, int W, int dilation, int act, float act_param,
                         long long in_bstride, long long in_cstride, long long out_bstride, long long out_cstride,

@@ -104,6 +104,7 @@ SIGNATURES = {
     "ts_conv3d_hw_x6_supported": (c_int, [c_int] * 6),
     "ts_conv3d_hw_x6_weight_bytes": (ctypes.c_size_t, [c_int] * 2),
     "ts_conv3d_hw_x6_weight_split": (c_int, [c_f32p, c_ptr, c_int, c_int, c_ptr]),
+    "ts_conv3d_hw_x6_weight_split_from": (c_int, [c_f32p, c_ptr, c_int, c_int] + [ctypes.c_longlong] * 3 + [c_int, c_ptr]),
     "ts_conv3d_hw_x6_workspace_bytes": (c_size, [c_int] * 6),
     "ts_conv3d_hw_x6s_supported": (c_int, [c_int] * 5),
     "ts_conv3d_hw_x6s_weight_bytes": (c_size, [c_int] * 3),

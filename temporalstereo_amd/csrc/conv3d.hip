@@ -538,7 +538,10 @@ constexpr int X6_NC = 16, X6_SLOTS = 10;
 
 // w_t fp32 [Cin][9][coutp] -> w6 [chunk][part 3][slot 10][group 2][coutp][8] bf16 (slot 9 and channels past Cin: zero)
 __global__ void __launch_bounds__(256)
-weight_split6_kernel(const float* __restrict__ w_t, u32x4* __restrict__ w6, int Cin, int coutp, int nchunk) {
+weight_split6_kernel(const float* __restrict__ w_t, u32x4* __restrict__ w6, int Cin, int coutp, int nchunk, int Cout, long long sci,
+                     long long sco, long long st, int flip) {
+  // Cout > 0: `w_t` is the FRAMEWORK's weight, element (ci, co, tap) at ci * sci + co * sco + tap * st (taps reversed when flip):
+  // layout and split in one launch (ts_conv3d_hw_x6_weight_split_from)
   const int n = nchunk * X6_SLOTS * 2 * coutp;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int co = i % coutp;
@@ -549,7 +552,8 @@ weight_split6_kernel(const float* __restrict__ w_t, u32x4* __restrict__ w6, int 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int ci = chunk * X6_NC + g * 8 + e;
-      v[e] = (slot < 9 && ci < Cin) ? w_t[(static_cast<size_t>(ci) * 9 + slot) * coutp + co] : 0.f;
+      if (Cout > 0) v[e] = (slot < 9 && ci < Cin && co < Cout) ? w_t[ci * sci + co * sco + (flip ? 8 - slot : slot) * st] : 0.f;
+      else v[e] = (slot < 9 && ci < Cin) ? w_t[(static_cast<size_t>(ci) * 9 + slot) * coutp + co] : 0.f;
     }
     unsigned part[3][4];
 #pragma unroll
@@ -1621,7 +1625,21 @@ extern "C" int ts_conv3d_hw_x6_weight_split(const float* w_t, void* w6, int Cin,
   const int bucket = cout_bucket(Cout), nchunk = (Cin + X6_NC - 1) / X6_NC;
   const int n = nchunk * X6_SLOTS * 2 * bucket;
   hipLaunchKernelGGL(weight_split6_kernel, dim3((n + 255) / 256), dim3(256), 0, ts::as_stream(stream), w_t,
-                     static_cast<u32x4*>(w6), Cin, bucket, nchunk);
+                     static_cast<u32x4*>(w6), Cin, bucket, nchunk, 0, 0ll, 0ll, 0ll, 0);
+  return ts::launched("weight_split6_kernel");
+}
+
+// Layout + split in one launch, straight from the framework's weight (training: the parameters move every step, so both would be
+// launched per call): element (ci, co, tap) of the CONVOLUTION being run is w[ci * stride_ci + co * stride_co + tap * stride_t], taps
+// reversed when `flip` (the input gradient of a stride-1 layer is the convolution of dy with the flipped taps and ci / co exchanged).
+extern "C" int ts_conv3d_hw_x6_weight_split_from(const float* w, void* w6, int Cin, int Cout, long long stride_ci, long long stride_co,
+                                                 long long stride_t, int flip, void* stream) {
+  TS_REQUIRE(Cin > 0 && Cout > 0 && Cout <= 512, TS_ERR_SHAPE, "conv3d_hw_x6_weight_split_from: bad channel counts");
+  TS_REQUIRE_PTR(w); TS_REQUIRE_PTR(w6);
+  const int bucket = cout_bucket(Cout), nchunk = (Cin + X6_NC - 1) / X6_NC;
+  const int n = nchunk * X6_SLOTS * 2 * bucket;
+  hipLaunchKernelGGL(weight_split6_kernel, dim3((n + 255) / 256), dim3(256), 0, ts::as_stream(stream), w,
+                     static_cast<u32x4*>(w6), Cin, bucket, nchunk, Cout, stride_ci, stride_co, stride_t, flip);
   return ts::launched("weight_split6_kernel");
 }
 

@@ -84,7 +84,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_bn_act_bwd_reduce),        TS_PLAN_OP(ts_bn_act_bwd_apply),
     TS_PLAN_OP(ts_convex_upsample_bwd),      TS_PLAN_OP(ts_unet_upsample_bwd),
     TS_PLAN_OP(ts_conv_weight_layout),      TS_PLAN_OP(ts_conv_weight_layout_many),
-    TS_PLAN_OP(ts_conv3d_hw_x6_fwd),        TS_PLAN_OP(ts_conv3d_hw_x6_weight_split),
+    TS_PLAN_OP(ts_conv3d_hw_x6_fwd),        TS_PLAN_OP(ts_conv3d_hw_x6_weight_split), TS_PLAN_OP(ts_conv3d_hw_x6_weight_split_from),
     TS_PLAN_OP(ts_conv3d_hw_x6s_fwd),       TS_PLAN_OP(ts_conv3d_hw_x6s_weight_split),
     TS_PLAN_OP(ts_peer_all_gather),         TS_PLAN_OP(ts_peer_all_reduce_sum),
     TS_PLAN_OP(ts_bn_train_fwd),            TS_PLAN_OP(ts_bn_train_bwd),

@@ -416,9 +416,11 @@ _TRAIN_X6 = __import__("os").environ.get("TS_TRAIN_X6", "1") != "0"
 _TRAIN_X6_MIN_GRID = int(__import__("os").environ.get("TS_TRAIN_X6_MIN_GRID", "256"))
 
 
-def _x6_conv(x, w_t, y, B, Cin, Cout, D, H, W, dilation, shift=None, scale=None, act=0, addend=None):
-    """y = act(scale * conv(x) + shift) through ts_conv3d_hw_x6_fwd when the shape qualifies; False when it does not."""
-    if not _TRAIN_X6 or Cin < 32:
+def _x6_conv(x, weight, wspec, y, B, Cin, Cout, D, H, W, dilation, shift=None, scale=None, act=0, addend=None):
+    """y = act(scale * conv(x) + shift) through ts_conv3d_hw_x6_fwd when the shape qualifies; False when it does not.
+    `weight`: the framework's (contiguous) parameter; wspec = (stride_ci, stride_co, stride_tap, flip) of the convolution being run
+    inside it -- layout and bf16 split are ONE launch (ts_conv3d_hw_x6_weight_split_from)."""
+    if not _TRAIN_X6 or Cin < 32 or not weight.is_contiguous():
         return False
     L = _lib.lib()
     if not L.ts_conv3d_hw_x6_supported(Cin, Cout, W, 1, dilation, 0):
@@ -428,7 +430,8 @@ def _x6_conv(x, w_t, y, B, Cin, Cout, D, H, W, dilation, shift=None, scale=None,
     if grid < _TRAIN_X6_MIN_GRID and not wsb:
         return False
     w6 = torch.empty(_q("ts_conv3d_hw_x6_weight_bytes", Cin, Cout), device=x.device, dtype=torch.uint8)
-    _lib.check(L.ts_conv3d_hw_x6_weight_split(_lib.ptr(w_t), _lib.ptr(w6), Cin, Cout, _stream()), "ts_conv3d_hw_x6_weight_split")
+    _lib.check(L.ts_conv3d_hw_x6_weight_split_from(_lib.ptr(weight.detach()), _lib.ptr(w6), Cin, Cout, wspec[0], wspec[1], wspec[2], wspec[3],
+                                                   _stream()), "ts_conv3d_hw_x6_weight_split_from")
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
     Ho, Wo = H, W
     rc = L.ts_conv3d_hw_x6_fwd(_lib.ptr(x), _lib.ptr(w6), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), B, Cin, Cout, D, H, W, dilation,
@@ -446,23 +449,23 @@ def _hw_forward(x, weight, stride, dilation, transposed, bias=None, fold=None, a
     B, Cin, D, H, W = x.shape
     if transposed:                                   # weight [Cin, Cout, 1, 3, 3]
         Cout = weight.shape[1]
-        w_t = _layout(weight, 0, 1)                                              # [ci][t][co]
         Ho, Wo = 2 * H, 2 * W
     else:                                            # weight [Cout, Cin, 1, 3, 3]
         Cout = weight.shape[0]
-        w_t = _layout(weight, 1, 0)
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((B, Cout, D, Ho, Wo), device=x.device, dtype=torch.float32)
-    L = _lib.lib()
-    wsb = _q("ts_conv3d_hw_workspace_bytes", B, Cin, Cout, D, H, W, stride, int(transposed))
-    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
     sc, sh = fold if fold is not None else (None, _shift_vec(bias, _cpad(Cout)))
     if addend is not None:          # [B, Cout, 1, Ho, Wo] (or [B, Cout, Ho, Wo]): added to every depth plane's raw sum
         addend = _lib.contiguous(addend)
         if addend.numel() != B * Cout * Ho * Wo or transposed:
             raise ValueError("conv addend: one [B, Cout, Ho, Wo] plane per batch item (stride-1 / stride-2 forms only)")
-    if stride == 1 and not transposed and _x6_conv(x, w_t, y, B, Cin, Cout, D, H, W, dilation, sh, sc, act, addend):
+    # (element (ci, co, tap) of [Cout, Cin, 1, 3, 3]: ci * 9 + co * Cin * 9 + tap)
+    if stride == 1 and not transposed and _x6_conv(x, weight, (9, Cin * 9, 1, 0), y, B, Cin, Cout, D, H, W, dilation, sh, sc, act, addend):
         return x, y, (B, Cin, Cout, D, H, W, stride, dilation, transposed)
+    w_t = _layout(weight, 0, 1) if transposed else _layout(weight, 1, 0)          # [ci][t][co]
+    L = _lib.lib()
+    wsb = _q("ts_conv3d_hw_workspace_bytes", B, Cin, Cout, D, H, W, stride, int(transposed))
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
     rc = L.ts_conv3d_hw_fwd(_lib.ptr(x), _lib.ptr(w_t), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(y), B, Cin, Cout, D, H, W, stride, dilation,
                             int(transposed), int(act), 0.0, x.stride(0), x.stride(1), y.stride(0), y.stride(1),
                             _lib.ptr(addend), (Cout * Ho * Wo) if addend is not None else 0, _lib.ptr(ws), wsb, _stream())
@@ -561,15 +564,16 @@ def _hw_backward(x, weight, dy, geom, need_x, need_w):
     L = _lib.lib()
     dx = dw = None
     if need_x:
-        if transposed:
-            w_b = _layout(weight, 1, 0)                                          # [co][t][ci] = W_T[ci][co][t]
-        elif stride == 2:
-            w_b = _layout(weight, 0, 1)                                          # [co][t][ci], taps as they are
-        else:
-            w_b = _layout(weight, 0, 1, flip=True)                               # taps flipped
         dx = torch.empty_like(x)
         # stride 1: the input gradient is the same convolution of dy with the flipped taps, Cout -> Cin channels
-        if not (stride == 1 and not transposed and _x6_conv(dy, w_b, dx, B, Cout, Cin, D, H, W, dilation)):
+        # (element (ci' = co, co' = ci, tap) of [Cout, Cin, 1, 3, 3]: ci' * Cin * 9 + co' * 9 + (8 - tap))
+        if not (stride == 1 and not transposed and _x6_conv(dy, weight, (Cin * 9, 9, 1, 1), dx, B, Cout, Cin, D, H, W, dilation)):
+            if transposed:
+                w_b = _layout(weight, 1, 0)                                      # [co][t][ci] = W_T[ci][co][t]
+            elif stride == 2:
+                w_b = _layout(weight, 0, 1)                                      # [co][t][ci], taps as they are
+            else:
+                w_b = _layout(weight, 0, 1, flip=True)                           # taps flipped
             rc = L.ts_conv3d_hw_bwd_data(_lib.ptr(dy), _lib.ptr(w_b), _lib.ptr(dx), B, Cin, Cout, D, H, W, stride, dilation,
                                          int(transposed), dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), _stream())
             _lib.check(rc, "ts_conv3d_hw_bwd_data")

@@ -225,7 +225,8 @@ class TrainStep:
         # them (so that the layouts are still in the Infinity Cache when read) 14.2 / 14.1 / 14.1.  The ~270 small launches are not what
         # the replay waits for, and with kept layouts the convolution kernels themselves run ~7 % slower (rocprof: 4.42 vs 4.12 ms per
         # step) -- the per-call buffers are one recycled block of the graph's pool, hot in every cache level.  TS_TRAIN_GRAPH_LAYOUTS=1
-        # selects the one-launch form for the A/B.
+        # selects the one-launch form for the A/B (with TS_SPLIT_FIRST_LAYER=0: the split first layer's weight halves are new tensors
+        # every step, which the kept table cannot register inside a capture).
         self.layouts = TF.WeightLayouts() if (not self.graph or os.environ.get("TS_TRAIN_GRAPH_LAYOUTS", "0") != "0") else None
         # the previous frames run in eval() / no_grad: their conv -> BatchNorm -> activation wrappers become one convolution launch
         # each, the BatchNorm folded into its epilogue; all folds of the step are recomputed by one launch (functional.BNFolds)

@@ -645,8 +645,8 @@ block_cost_fast(const float* __restrict__ L, const float* __restrict__ R,
 // lanes of a quad: the 2x2 / 4x4 block means (block_cost.py:66-73) are two quad permutes (DPP, VALU rate) instead of registers
 // carried over rows.  Sums are formed in the order block_cost_fast forms them (a pair of rows, then the two pairs).
 // NRP: right-row staging items per lane (2 * TR * Wq float4-quads over the workgroup), all requested before the first is written.
-template <int NRP>
-__global__ void __launch_bounds__(256)
+template <int NRP, int NT = 256>      // NT: workgroup size bound (512: maps of 260-512 columns, e.g. KITTI's 1/4 level)
+__global__ void __launch_bounds__(NT)
 block_cost_corr_rows(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
                      float* __restrict__ out, float* __restrict__ P1, float* __restrict__ P2, const Shape s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1258,6 +1258,10 @@ int launch_fwd(const float* left, const float* right, const float* disp, float* 
       if (nrp == 1) hipLaunchKernelGGL((block_cost_corr_rows<1>), grid, dim3(cthreads), clds, st, left, right, disp, out, P1, P2, s);
       else hipLaunchKernelGGL((block_cost_corr_rows<2>), grid, dim3(cthreads), clds, st, left, right, disp, out, P1, P2, s);
       done = true;
+    } else if (cthreads <= 512 && nrp <= 2 && clds <= 64 * 1024) {
+      if (nrp == 1) hipLaunchKernelGGL((block_cost_corr_rows<1, 512>), grid, dim3(cthreads), clds, st, left, right, disp, out, P1, P2, s);
+      else hipLaunchKernelGGL((block_cost_corr_rows<2, 512>), grid, dim3(cthreads), clds, st, left, right, disp, out, P1, P2, s);
+      done = true;
     }
   }
   if (done) {
@@ -1784,8 +1788,8 @@ block_cost_bwd_tile(const float* __restrict__ L, const float* __restrict__ R, co
 // lanes of a quad: e is evaluated ONCE, the 2x2 / 4x4 sums are two quad permutes, gL accumulates over the candidates in registers
 // and leaves as plain stores, the tap position is one division per (candidate, pixel) instead of one per channel.  What stays is the
 // scatter of gR: LDS float atomics into one row tile per channel (all eight resident: the candidate loop is outside).
-template <int UNUSED = 0>
-__global__ void __launch_bounds__(256)
+template <int NT = 256>               // NT: workgroup size bound (512: maps of 260-512 columns)
+__global__ void __launch_bounds__(NT)
 block_cost_bwd_rows(const float* __restrict__ L, const float* __restrict__ R, const float* __restrict__ disp,
                     const float* __restrict__ dout, const float* __restrict__ dP1, const float* __restrict__ dP2,
                     float* __restrict__ gL, float* __restrict__ gR, float* __restrict__ gD, const Shape s) {
@@ -2051,10 +2055,19 @@ int launch_bwd(const float* left, const float* right, const float* disp, const f
     static const bool rows = [] { const char* e = getenv("TS_K1_BWD_ROWS"); return !e || atoi(e) != 0; }();
     const int rthreads = static_cast<int>(ts::round_up(static_cast<size_t>(s.nbx) * 4, ts::kWave));
     const size_t rlds = (static_cast<size_t>(GRP) * TR * 4 * s.Wqp + static_cast<size_t>(GRP) * TR * 4 * s.Wq) * sizeof(float);   // R rows + [GRP/2][TR][Wl] doubles
-    if (SAMPLED && rows && vec && rthreads <= 256 && rlds <= 64 * 1024 && (!grad_left || ts::aligned16(grad_left)) &&
+    if (SAMPLED && rows && vec && rthreads <= 512 && rlds <= 80 * 1024 && (!grad_left || ts::aligned16(grad_left)) &&
         (!grad_right || ts::aligned16(grad_right))) {
-      hipLaunchKernelGGL((block_cost_bwd_rows<0>), grid, dim3(rthreads), rlds, st, left, right, disp, grad_out, dP1, dP2, grad_left,
-                         grad_right, grad_disp, s);
+      if (rthreads <= 256) {
+        auto kern = &block_cost_bwd_rows<256>;
+        if (rlds > 64 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(rlds));
+        hipLaunchKernelGGL(kern, grid, dim3(rthreads), rlds, st, left, right, disp, grad_out, dP1, dP2, grad_left, grad_right, grad_disp, s);
+      } else {
+        auto kern = &block_cost_bwd_rows<512>;
+        if (rlds > 64 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(rlds));
+        hipLaunchKernelGGL(kern, grid, dim3(rthreads), rlds, st, left, right, disp, grad_out, dP1, dP2, grad_left, grad_right, grad_disp, s);
+      }
       return ts::launched("block_cost_bwd_rows");
     }
   }

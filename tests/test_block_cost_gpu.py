@@ -137,7 +137,8 @@ def test_full_size_precise_level_properties():
 
 @pytest.mark.parametrize("sampled", [False, True])
 @pytest.mark.parametrize("shape", [(2, 16, 10, 14, 3), (1, 8, 9, 13, 4), (1, 16, 12, 20, 5), (2, 24, 21, 130, 3), (1, 8, 7, 258, 2),
-                                   (1, 16, 34, 60, 8), (1, 8, 8, 520, 2)])     # the last one: more items than the tile kernel takes
+                                   (1, 16, 34, 60, 8), (1, 8, 8, 520, 2),     # more items than the tile kernel takes
+                                   (1, 16, 9, 312, 5), (2, 8, 6, 512, 3)])     # the 512-lane form of the row kernels (KITTI's 1/4 level is 312 wide)
 def test_backward_vs_oracle_autograd(shape, sampled):
     """Gradients through the C ABI backward vs autograd of the oracle (same torch ops as the
     reference).  fp32 atomics -> 1e-4 relative to the gradient scale."""
@@ -168,7 +169,7 @@ def test_backward_vs_oracle_autograd(shape, sampled):
 
 
 @pytest.mark.parametrize("shape", [(1, 16, 20, 36, 5), (2, 32, 34, 60, 7), (1, 128, 68, 120, 5), (1, 64, 135, 240, 5),
-                                   (3, 8, 9, 256, 3), (1, 16, 12, 260, 5), (1, 16, 12, 38, 5), (1, 8, 4, 4, 2)])
+                                   (3, 8, 9, 256, 3), (1, 16, 12, 260, 5), (1, 16, 12, 38, 5), (1, 8, 4, 4, 2), (1, 16, 9, 312, 5), (1, 8, 6, 512, 3)])
 @pytest.mark.parametrize("scales", [3, 2])
 def test_correlation_blocks_alone_equal_the_full_op(shape, scales):
     """ts_block_cost_sampled_corr_fwd (what the pipeline launches: block_cost_corr_rows on aligned maps of up to 256 columns,

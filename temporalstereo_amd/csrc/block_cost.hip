@@ -854,7 +854,8 @@ block_cost_upsample(const float* __restrict__ P1, const float* __restrict__ P2,
 // 8-channel group in the channel-packed R4 layout, the left rows beside them -- but a workgroup walks the
 // (candidate, 4-pixel block) items of its rows in strides of the block size instead of owning one each, and
 // there is no pooling.  MODE 0: cat (left repeat | warped right);  1: max |left - warped| only (first pass of
-// dif_fms: the fill value is the maximum over the WHOLE tensor, dif_fms.py:38);  2: dif with the fill applied.
+// dif_fms: the fill value is the maximum over the WHOLE tensor, dif_fms.py:38);  2: dif with the fill applied;
+// 3: the warp alone, sampled at x + disp (inverse_warp_3d itself, layers/inverse_warp_3d.py:4-58: its callers pass -disp).
 // ------------------------------------------------------------------------------------------------
 constexpr int TRD = 2;
 
@@ -885,6 +886,7 @@ dense_warp_kernel(const float* __restrict__ L, const float* __restrict__ R, cons
       ldsR4[(hr * 4 + k) * Wqp + jx] = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
   }
   if (tid < 2 * TRD) ldsR4[(tid * 4) * Wqp + Wq] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero slot of each row
+  if constexpr (MODE != 3)
   for (int i = tid; i < GRP * TRD * Wq; i += nthr) {
     const int jx = i % Wq, cr = i / Wq;           // cr = c*TRD + r
     const int y = min(y0 + cr % TRD, H - 1);
@@ -903,6 +905,10 @@ dense_warp_kernel(const float* __restrict__ L, const float* __restrict__ R, cons
   auto do_item = [&](int r, int d, int x4, unsigned loff, const float4 dq) {
     float dv[4];
     unpack(dq, dv);
+    if constexpr (MODE == 3) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dv[k] = -dv[k];      // tap4 samples at x - disp (what block_cost / cat_fms / dif_fms ask of the warp)
+    }
     unsigned op[4];
     float fr[4];
 #pragma unroll
@@ -916,7 +922,7 @@ dense_warp_kernel(const float* __restrict__ L, const float* __restrict__ R, cons
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int c = h * 4 + cc;
-        const float4 lv4 = *reinterpret_cast<const float4*>(ldsL + (c * TRD + r) * Wl + x4);
+        const float4 lv4 = MODE == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(ldsL + (c * TRD + r) * Wl + x4);
         float lv[4], tv[4];
         unpack(lv4, lv);
 #pragma unroll
@@ -925,6 +931,8 @@ dense_warp_kernel(const float* __restrict__ L, const float* __restrict__ R, cons
         if constexpr (MODE == 0) {
           bst4<VEC>(orsrc, loff, plane, x4, W, lv4);
           bst4<VEC>(orsrc, loff, plane + static_cast<unsigned>(C) * dHW, x4, W, pack(tv));
+        } else if constexpr (MODE == 3) {
+          bst4<VEC>(orsrc, loff, plane, x4, W, pack(tv));
         } else if constexpr (MODE == 1) {
 #pragma unroll
           for (int k = 0; k < 4; ++k)
@@ -2130,7 +2138,7 @@ int launch_dense(const float* left, const float* right, const float* disp, float
   if (int rc = make_shape(s, true, B, C, H, W, D, 1, 0, 1)) return rc;       // no pooling here: any H, W
   TS_REQUIRE_PTR(left); TS_REQUIRE_PTR(right); TS_REQUIRE_PTR(disp);
   if (MODE != 1) TS_REQUIRE_PTR(out);
-  if (MODE != 0) TS_REQUIRE_PTR(maxbits);
+  if (MODE == 1 || MODE == 2) TS_REQUIRE_PTR(maxbits);
   bool vec = (W % 4 == 0) && ts::aligned16(left) && ts::aligned16(right) && ts::aligned16(disp) && (MODE == 1 || ts::aligned16(out));
   const size_t base_bytes = (static_cast<size_t>(2) * TRD * 4 * s.Wqp * 4 + static_cast<size_t>(GRP) * TRD * 4 * s.Wq) * sizeof(float);
   // the run-order (16-byte) form keeps 16 KB of candidates in LDS on top of the row staging: where that no longer fits (aligned maps
@@ -2153,6 +2161,13 @@ int launch_dense(const float* left, const float* right, const float* disp, float
 extern "C" int ts_cat_fms_fwd(const float* left, const float* right, const float* disp, float* out, int B, int C, int H,
                               int W, int D, void* stream) {
   return launch_dense<0>(left, right, disp, out, nullptr, B, C, H, W, D, stream);
+}
+
+// inverse_warp_3d (layers/inverse_warp_3d.py:4-58) for a 4-D image, padding_mode 'zeros', no disp_Y:
+// out [B,C,D,H,W][b,c,d,y,x] = lerp(img[b,c,y,:], x + disp[b,d,y,x]) with zeros outside [0, W-1] (grid_sample, align_corners=True)
+extern "C" int ts_inverse_warp_3d_fwd(const float* img, const float* disp, float* out, int B, int C, int H, int W, int D,
+                                      void* stream) {
+  return launch_dense<3>(img, img, disp, out, nullptr, B, C, H, W, D, stream);
 }
 
 extern "C" size_t ts_dif_fms_workspace_bytes(void) { return 256; }

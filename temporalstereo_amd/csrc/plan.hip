@@ -55,7 +55,7 @@ const Entry kTable[] = {
     TS_PLAN_OP(ts_block_cost_int_fwd),      TS_PLAN_OP(ts_block_cost_sampled_fwd),
     TS_PLAN_OP(ts_block_cost_sampled_warped_fwd),
     TS_PLAN_OP(ts_block_cost_sampled_corr_fwd), TS_PLAN_OP(ts_conv3d_hw_warp_fwd),
-    TS_PLAN_OP(ts_cat_fms_fwd),             TS_PLAN_OP(ts_dif_fms_fwd),
+    TS_PLAN_OP(ts_cat_fms_fwd),             TS_PLAN_OP(ts_dif_fms_fwd),             TS_PLAN_OP(ts_inverse_warp_3d_fwd),
     TS_PLAN_OP(ts_block_cost_int_bwd),      TS_PLAN_OP(ts_block_cost_sampled_bwd),
     TS_PLAN_OP(ts_topk_softargmax_fwd),     TS_PLAN_OP(ts_topk_softargmax_bwd),
     TS_PLAN_OP(ts_softargmin_fwd),          TS_PLAN_OP(ts_softargmin_bwd),

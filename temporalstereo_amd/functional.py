@@ -212,6 +212,66 @@ def dif_fms(reference_fm, target_fm, disp_sample):
     return _DifFms.apply(reference_fm, target_fm, disp_sample)
 
 
+class _InverseWarp3d(torch.autograd.Function):
+    """img [B,C,H,W] (C % 8 == 0), disp [B,D,H,W] -> [B,C,D,H,W] sampled at x + disp (ts_inverse_warp_3d_fwd).  Backward: the warped
+    half of ts_block_cost_sampled_bwd at scales = 1 (that op warps by -disp: the candidates go in negated, their gradient comes
+    back negated)."""
+
+    @staticmethod
+    def forward(ctx, img, disp):
+        B, C, H, W = img.shape
+        D = disp.shape[1]
+        out = torch.empty((B, C, D, H, W), device=img.device, dtype=torch.float32)
+        rc = _lib.lib().ts_inverse_warp_3d_fwd(_lib.ptr(img), _lib.ptr(disp), _lib.ptr(out), B, C, H, W, D, _stream())
+        _lib.check(rc, "ts_inverse_warp_3d_fwd")
+        ctx.save_for_backward(img, disp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        img, disp = ctx.saved_tensors
+        _, gi, gd = _fms_backward(img, img, -disp, None, _lib.contiguous(g), (False, ctx.needs_input_grad[0], ctx.needs_input_grad[1]))
+        return gi, (-gd if gd is not None else None)
+
+
+def inverse_warp_3d(img, disp, padding_mode='zeros', disp_Y=None):
+    """layers/inverse_warp_3d.py:4 (same arguments): img [B,C,H,W] or [B,C,D,H,W], disp [B,D,H,W] -> img sampled at x + disp,
+    [B,C,D,H,W], zeros outside the row.  Differentiable in img and disp.  `padding_mode` other than 'zeros' and a `disp_Y` are not
+    what any caller in the reference asks for (block_cost.py:56, cat_fms.py:31, dif_fms.py:31) and are refused; wrong ranks raise the
+    reference's own ValueError (inverse_warp_3d.py:31-33)."""
+    if img.dim() not in (4, 5):
+        raise ValueError('image is only allowed with 4 or 5 dimensions, but got {} dimensions!'.format(img.dim()))
+    if disp.dim() != 4:
+        raise ValueError("disp must be [B, D, H, W]")
+    if padding_mode != 'zeros' or disp_Y is not None:
+        raise RuntimeError("inverse_warp_3d: padding_mode=%r / disp_Y are not supported by the HIP kernel (TS_ERR_UNSUPPORTED): the reference "
+                           "only ever calls it with 'zeros' and no disp_Y" % (padding_mode,))
+    _require_gpu(img, disp)
+    B, D, H, W = disp.shape
+    if img.dim() == 5:
+        if img.shape[2] != D:
+            raise AssertionError('The disparity number should be same between image and disparity map!')
+        if img.stride(2) == 0 or D == 1:
+            img = img[:, :, 0]                       # an expanded view (cat_fms.py:28-31): every plane is the same image
+        else:
+            # plane d is warped by candidate d: B * D images with one candidate each (the kernel wants two: the row is doubled)
+            C = img.shape[1]
+            flat = img.permute(0, 2, 1, 3, 4).reshape(B * D, C, img.shape[3], img.shape[4])
+            dd = disp.reshape(B * D, 1, H, W).expand(B * D, 2, H, W)
+            return inverse_warp_3d(flat, dd)[:, :, 0].reshape(B, D, C, H, W).permute(0, 2, 1, 3, 4)
+    if img.shape[0] != B or img.shape[2:] != disp.shape[2:]:
+        raise ValueError("img [B,C,H,W] and disp [B,D,H,W] must agree in B, H, W")
+    C = img.shape[1]
+    if D == 1:
+        return inverse_warp_3d(img, disp.expand(B, 2, H, W))[:, :, :1]
+    pad = (-C) % 8
+    x = _lib.contiguous(img.float())
+    if pad:
+        x = torch.cat([x, x.new_zeros(B, pad, H, W)], 1)
+    out = _InverseWarp3d.apply(x, _lib.contiguous(disp.float()))
+    return out[:, :C] if pad else out
+
+
 class _Correlation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, left, right, ph, pw, keep):
@@ -392,7 +452,9 @@ def _layout_now(weight, a_dim, b_dim, flip):
 def _layout(weight, a_dim, b_dim, flip=False):
     """[A][taps][pad(B)] kernel layout of a conv weight [d0, d1, taps...] (ts_conv_weight_layout): A / B are which of the first two
     dimensions goes outermost / innermost.  Inside a `WeightLayouts` context the layouts are kept and refreshed together."""
-    if _LAYOUTS is not None and weight.is_contiguous():
+    # only LEAVES (parameters) are registered: a temporary made per step -- the two halves of first_layer_split's weight -- would add a
+    # fresh entry every step, each pinning its tensor, its layout and a table rebuild (+ pageable upload) until the 4096-entry clear
+    if _LAYOUTS is not None and weight.is_contiguous() and weight.is_leaf:
         return _LAYOUTS.get(weight, a_dim, b_dim, flip)
     return _layout_now(weight, a_dim, b_dim, flip)[0]
 
@@ -506,19 +568,37 @@ class WgradDefer:
         global _WGRAD_DEFER
         self._outer, _WGRAD_DEFER = _WGRAD_DEFER, self
         self.uses = {}
+        self.discard()             # nothing of an earlier, aborted step may reach this step's finish launch
         return self
 
     def __exit__(self, *exc):
         global _WGRAD_DEFER
         _WGRAD_DEFER = self._outer
+        # flush() has run in a completed step; after an exception between the first deferred call and the flush (an OOM-skip loop, an
+        # interrupt) the descriptors still name workspaces and dw tensors that are about to be freed: drop them WITHOUT launching
+        self.discard()
         return False
+
+    def discard(self):
+        """Drops every pending deferred finish (the library's descriptor list and the workspaces kept for it) without launching."""
+        import ctypes
+        L = _lib.lib()
+        if int(L.ts_conv_wgrad_pending()) != 0:
+            scratch = (ctypes.c_char * self.cap)()
+            n, blocks = ctypes.c_int(0), ctypes.c_int(0)
+            L.ts_conv_wgrad_take(ctypes.cast(scratch, ctypes.c_void_p), self.cap, ctypes.byref(n), ctypes.byref(blocks))
+        self.keep = []
 
     def used(self, weight):
         k = weight.data_ptr()
         self.uses[k] = self.uses.get(k, 0) + 1
 
     def single_use(self, weight):
-        return self.uses.get(weight.data_ptr(), 0) == 1
+        # a deferred dw is handed to autograd UNWRITTEN and filled by flush(): only sound when AccumulateGrad takes the tensor itself
+        # (no gradient accumulated yet, no hook that would read or clone it first)
+        # (a non-leaf -- a slice made inside the step -- hands its gradient to another backward node, which reads it at once)
+        return (self.uses.get(weight.data_ptr(), 0) == 1 and weight.is_leaf and weight.grad is None
+                and not getattr(weight, "_backward_hooks", None) and not getattr(weight, "_post_accumulate_grad_hooks", None))
 
     def flush(self):
         import ctypes

@@ -166,6 +166,7 @@ class PeerGroup:
         if dist.is_initialized():
             dist.barrier(group=self.group)    # nobody unmaps while a peer may still write
         self._release()
+        self.closed = True
         if installed() is self:
             install(None)
 

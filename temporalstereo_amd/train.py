@@ -194,14 +194,17 @@ class TrainStep:
         self.sync_bn = bool(sync_bn) and self.world > 1
         self.peer = None
         from . import peer as _peer
-        if _peer.installed() is not None:
-            # a PeerGroup left installed by an earlier TrainStep of this process is not this step's: exchanges of a step that
-            # did not ask for the mailboxes go through torch.distributed
+        stale = _peer.installed()
+        if stale is not None and (getattr(stale, "closed", False) or getattr(stale, "owner", lambda: None)() is None):
+            # a PeerGroup left installed by a TrainStep that is gone (or closed) is not this step's: its exchanges would go through
+            # dead mailboxes.  The group of a LIVE step (a validation step built beside a training one) stays installed.
             _peer.install(None)
         if self.sync_bn:
             net = tsd.sync_batchnorm(net)
             if sync_bn == "peer":
                 self.peer = _peer.PeerGroup()
+                import weakref
+                self.peer.owner = weakref.ref(self)
                 _peer.install(self.peer)
         self.net = net
         tsd.broadcast_parameters(net)
@@ -242,6 +245,7 @@ class TrainStep:
         self.wgrad_defer = TF.WgradDefer() if (on_gpu and self.buckets is None and os.environ.get("TS_TRAIN_WGRAD_DEFER", "1") != "0") else None
         self._native_prev = None
         self._use_native_prev = on_gpu and os.environ.get("TS_TRAIN_NATIVE_PREV", "1") != "0"
+        self._native_prev_ran = False
         # (Tried and dropped in round 3: the weight-gradient launches on a forked side stream inside the capture -- they depend only on
         # dy, 15 % of the step's device time, small grids.  The replayed graph got SLOWER, 15.0 vs 13.4 ms: forked captures replay
         # badly on ROCm 7.2, as the inference graph already showed)
@@ -284,6 +288,9 @@ class TrainStep:
                     agg = eng.net
                 if agg.tape.unsupported:
                     raise NotImplementedError("; ".join(agg.tape.unsupported))
+                if agg.tape._tables is None and not agg.tape.unsupported:
+                    # the re-fold tables go up NOW (a numpy table + a pageable upload): never inside a capture, whatever the warm-up count
+                    agg.tape._upload(next(self.net.parameters()).device)
                 self._native_prev = (agg, eng)
                 return eng if eng is not None else agg   # just built from the current values
             except NotImplementedError:                  # a model the inference form does not cover: the module path serves it
@@ -317,7 +324,19 @@ class TrainStep:
             for t, fr in enumerate(frames[:-1]):
                 self._set_training(False)
                 with torch.no_grad():
-                    info = (prev_net if prev_net is not None else net)(fr[0], fr[1], fr[2], fr[3], dict(info))[5]
+                    if prev_net is not None and not self._native_prev_ran:
+                        # the first CALL can still refuse (a geometry or stride the inference form rejects): the module path serves it
+                        try:
+                            out = prev_net(fr[0], fr[1], fr[2], fr[3], dict(info))
+                            self._native_prev_ran = True
+                        except (NotImplementedError, RuntimeError, ValueError):
+                            if torch.cuda.is_current_stream_capturing():
+                                raise
+                            self._use_native_prev, self._native_prev, prev_net = False, None, None
+                            out = net(fr[0], fr[1], fr[2], fr[3], dict(info))
+                        info = out[5]
+                    else:
+                        info = (prev_net if prev_net is not None else net)(fr[0], fr[1], fr[2], fr[3], dict(info))[5]
                     H, W = fr[2].shape[-2:]
                     info = temporal.update_map(dict(info), K, poses[t + 1][0], poses[t + 1][1], self.baseline, H, W,
                                                use_past_cost=True, local_map_size=self.local_map_size)
@@ -416,7 +435,10 @@ class TrainStep:
                     raise RuntimeError("TrainStep(graph=True): this call's inputs do not have the structure / shapes / dtypes the graph was "
                                        "captured with (%d tensors); build a new TrainStep for a new geometry" % len(dsts))
                 for dst, src in zip(dsts, srcs):
-                    if dst.data_ptr() != src.data_ptr():         # (a caller that fills `bound_inputs()` in place copies nothing)
+                    # (a caller that fills `bound_inputs()` in place copies nothing; a VIEW of the bound buffer with other strides or
+                    # offset -- flipped, transposed -- shares its data_ptr but not its contents and is copied)
+                    if not (dst is src or (dst.data_ptr() == src.data_ptr() and dst.stride() == src.stride()
+                                           and dst.storage_offset() == src.storage_offset())):
                         dst.detach().copy_(src, non_blocking=True)
             self._g.replay()
             loss = self._loss.clone()                                # the graph's own buffer is overwritten by the next replay

@@ -286,3 +286,53 @@ def test_batchnorm_one_launch_form_for_small_layers(shape):
     want = [yd.detach(), xd.grad, ref[0].weight.grad, ref[1].weight.grad, ref[1].bias.grad]
     for a, b in zip(res[old][:5], want):
         assert rel(a, b) < 2e-5
+
+
+def test_wgrad_defer_survives_an_aborted_step():
+    """functional.WgradDefer: a step that raises between the first deferred weight-gradient call and flush() must not
+    leave descriptors behind -- the next step's finish launch would write old partial sums through pointers to freed memory.  An
+    aborted step, then a clean one: the clean one's gradient equals torch's; and a weight that already has a .grad (autograd would
+    ACCUMULATE into the still-unwritten tensor) is not deferred."""
+    import temporalstereo_amd.functional as TF
+    from temporalstereo_amd import _lib
+    dev = _dev()
+    x = t(synth.normal(5, "x", (1, 16, 2, 12, 32)), dev)
+    w = t(synth.normal(6, "w", (16, 16, 1, 3, 3), 0.1), dev).requires_grad_(True)
+    s, p, d = (1, 1, 1), (0, 1, 1), (1, 1, 1)
+    defer = TF.WgradDefer()
+
+    class Boom(RuntimeError):
+        pass
+
+    class _Raise(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a):
+            return a.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise Boom("mid-backward")
+
+    L = _lib.lib()
+    with pytest.raises(Boom):
+        with defer:
+            xin = x.clone().requires_grad_(True)
+            y = TF.conv3d(_Raise.apply(xin), w, None, s, p, d)       # the conv's weight gradient is deferred, then the input's path raises
+            y.sum().backward()
+    assert int(L.ts_conv_wgrad_pending()) == 0 and defer.keep == [], "an aborted step left deferred finishes behind"
+    w.grad = None
+    with defer:
+        y = TF.conv3d(x, w, None, s, p, d)
+        y.sum().backward()
+        defer.flush()
+    w2 = w.detach().clone().requires_grad_(True)
+    F.conv3d(x, w2, None, s, p, d).sum().backward()
+    _close(w.grad, w2.grad, "weight gradient of the clean step")
+    # a second backward into the SAME .grad: accumulated by autograd, so it must take the immediate finish
+    with defer:
+        y = TF.conv3d(x, w, None, s, p, d)
+        y.sum().backward()
+        assert int(L.ts_conv_wgrad_pending()) == 0, "a weight with a gradient already in place was deferred"
+        defer.flush()
+    torch.cuda.synchronize()
+    _close(w.grad, 2 * w2.grad, "accumulated weight gradient")

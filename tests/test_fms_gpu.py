@@ -92,3 +92,58 @@ def test_fms_backward_vs_oracle_autograd(shape):
             scale = float(want.abs().max()) + 1e-6
             err = float((got.cpu() - want).abs().max())
             assert err <= 3e-4 * scale + 1e-5, "%s grad %s: max err %g (scale %g)" % (name, what, err, scale)
+
+
+def test_inverse_warp_3d_value_test_and_oracle():
+    """temporalstereo_amd.inverse_warp_3d(img, disp): the function-level seam of layers/inverse_warp_3d.py:4.
+    (1) the reference's own output on the 3x4 value-test grid (golden/value_test_warp.npz: inverse_warp_3d(right, -disp) as
+    recorded from the imported reference); (2) the oracle's warp on a config geometry (fine level of configs[1]: 68 x 120, five
+    candidates, a channel count that is not a multiple of 8); (3) both gradients against fp64 autograd of the oracle's form;
+    (4) the 5-D forms (an expanded view, as cat_fms.py:28-31 builds it, and a genuinely per-plane image); (5) what is refused."""
+    import temporalstereo_amd as ts
+    from oracle import cost_volume as O
+    dev = _dev()
+    g = load("value_test_warp")
+    r, d = t(g["right"], dev), t(g["disp"], dev)
+    np.testing.assert_allclose(ts.inverse_warp_3d(r, -d).cpu().numpy(), g["warped"], atol=1e-5)
+
+    B, C, D, H, W = 2, 12, 5, 68, 120
+    img = t(synth.normal(11, "img", (B, C, H, W)), dev)
+    disp = t(synth.uniform(12, "disp", (B, D, H, W), -9.0, 40.0), dev)
+    ref = O.warp_candidates(img.cpu(), (-disp).cpu())                 # the oracle warps by -disp like the reference's callers
+    out = ts.inverse_warp_3d(img, disp)
+    assert out.shape == (B, C, D, H, W)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-5)
+
+    # gradients: fp64 autograd through the oracle's form of the same warp
+    B, C, D, H, W = 1, 8, 3, 9, 16
+    img = t(synth.normal(13, "img", (B, C, H, W)), dev).requires_grad_(True)
+    disp = t(synth.uniform(14, "disp", (B, D, H, W), -3.0, 6.0), dev).requires_grad_(True)
+    gout = t(synth.normal(15, "g", (B, C, D, H, W)), dev)
+    ts.inverse_warp_3d(img, disp).backward(gout)
+    i64 = img.detach().double().cpu().requires_grad_(True)
+    d64 = disp.detach().double().cpu().requires_grad_(True)
+    O.warp_candidates(i64, -d64).backward(gout.double().cpu())
+    np.testing.assert_allclose(img.grad.cpu().numpy(), i64.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # the disparity gradient of a linear interpolation is the local slope: where a sample sits within 1e-4 of a pixel centre the fp32
+    # and fp64 positions can fall on different sides of it -- those elements are left out (they are the warp's own kinks)
+    pos = (torch.arange(W).view(1, 1, 1, W) + d64.detach())
+    smooth = ((pos - pos.round()).abs() > 1e-3).numpy()
+    np.testing.assert_allclose(disp.grad.cpu().numpy()[smooth], d64.grad.numpy()[smooth], rtol=1e-4, atol=1e-4)
+
+    # 5-D images
+    img = t(synth.normal(16, "img", (2, 8, 7, 12)), dev)
+    disp = t(synth.uniform(17, "disp", (2, 4, 7, 12), -2.0, 5.0), dev)
+    a = ts.inverse_warp_3d(img.unsqueeze(2).expand(2, 8, 4, 7, 12), disp)
+    np.testing.assert_allclose(a.cpu().numpy(), ts.inverse_warp_3d(img, disp).cpu().numpy(), atol=0)
+    vol = t(synth.normal(18, "vol", (2, 8, 4, 7, 12)), dev)
+    b5 = ts.inverse_warp_3d(vol, disp)
+    for k in range(4):
+        np.testing.assert_allclose(b5[:, :, k].cpu().numpy(), ts.inverse_warp_3d(vol[:, :, k].contiguous(), disp)[:, :, k].cpu().numpy(), atol=1e-6)
+
+    with pytest.raises(ValueError):
+        ts.inverse_warp_3d(img[0], disp)                                # 3-D image: the reference's own ValueError (inverse_warp_3d.py:31-33)
+    with pytest.raises(RuntimeError):
+        ts.inverse_warp_3d(img, disp, padding_mode='border')
+    with pytest.raises(RuntimeError):
+        ts.inverse_warp_3d(img, disp, disp_Y=disp)

@@ -375,6 +375,7 @@ def test_stress_random_weights_end_to_end_bulk(name):
     c = PT.CONFIGS[name]
     rep = PT.Report()
     single, floor_single, temporal, floor_temporal = [], [], [], []
+    dev_hip, dev_oracle = [], []          # per frame: mean |disparity - fp64 oracle| of the HIP path and of the fp32 oracle (px)
     try:
         for k in range(_STRESS_SEEDS[name]):
             seed = synth.SEED0 + 100 + 7 * k
@@ -395,6 +396,7 @@ def test_stress_random_weights_end_to_end_bulk(name):
                         oracle_fp32_vs_fp64_delta_epe=f, oracle_fp32_vs_fp64_mean_abs=fmad, vs_fp64_delta_epe=d64, vs_fp64_mean_abs=mad64)
                 (single if t == 0 else temporal).append(min(d, d64))
                 (floor_single if t == 0 else floor_temporal).append(f)
+                dev_hip.append((seed, t, mad64, d64)); dev_oracle.append((seed, t, fmad, f))
     finally:
         rep.dump("parity_end_to_end_stress.json")
     if SOFT:
@@ -403,6 +405,23 @@ def test_stress_random_weights_end_to_end_bulk(name):
     if temporal:
         assert max(temporal) < max(3 * max(floor_temporal), 0.05), \
             "%s: temporal frames |dEPE| %.3g px vs the oracle's own fp32-vs-fp64 %.3g" % (name, max(temporal), max(floor_temporal))
+    # "Within the reference's own fp32 noise" as a test, under SURVEY section 8(d)'s own protocol (reference
+    # initialiser, random BatchNorm statistics: a network that is NOT contractive).  The fp64 oracle is the truth; the fp32 oracle --
+    # the reference's arithmetic -- misses it by its own rounding noise, a different amount at every seed (5.9e-4 ... 6.6e-3 px mean
+    # |difference| over three seeds).  The HIP path must not miss it by more than 1.5x that: per frame against the LARGER of that frame's
+    # own oracle noise and the median of the oracle's noise over the frames of its kind (one frame's noise is one draw of a
+    # heavy-tailed quantity; the HIP path's deviation is another draw, so the same-frame value alone is not a bound).
+    import statistics
+    for kind, sel in (("single", lambda t: t == 0), ("temporal", lambda t: t > 0)):
+        noise = [m for (_, t, m, _) in dev_oracle if sel(t)]
+        if not noise:
+            continue
+        med = statistics.median(noise)
+        for (seed, t, m_hip, e_hip), (_, _, m_or, e_or) in zip(dev_hip, dev_oracle):
+            if sel(t):
+                assert m_hip <= 1.5 * max(m_or, med), \
+                    "%s seed %d frame %d: mean |HIP - fp64 oracle| %.3g px exceeds 1.5 x the fp32 oracle's own %.3g (median over %s frames %.3g)" % (
+                        name, seed, t, m_hip, m_or, kind, med)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

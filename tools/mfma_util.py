@@ -40,14 +40,16 @@ def main(path, pattern="%ig_conv%"):
             continue
         util = busy / (gui / 8.0 * 1024.0)
         flops = busy / 32.0 * 2048.0
-        if "x6" in name:
+        if "x6p" in name:       # v_mfma_f32_32x32x16_bf16, six products per fp32 product, nine taps in nine steps
+            flops = busy / 32.0 * 32768.0 / 6.0
+        elif "x6" in name:      # v_mfma_f32_16x16x32_bf16, ten tap slots for nine taps
             flops = busy / 16.0 * 16384.0 / 6.0 * 0.9
-        out.append((busy * n, name, grid, n, dur / 1e3, util, flops / dur / 1e3, gui / 8.0 / dur * 1e3, mops))
+        out.append((busy * n, name, grid, n, dur / 1e3, util, flops / dur / 1e3, mops))
     out.sort(reverse=True)
     tot_busy = sum(o[0] for o in out)
-    print("%-34s %-14s %5s %9s %8s %8s %8s" % ("kernel", "grid", "calls", "avg_us", "MfmaUtil", "TF/s", "clk_MHz"))
-    for _, name, grid, n, us, util, tfs, mhz, mops in out[:40]:
-        print("%-34s %-14s %5d %9.1f %7.1f%% %8.1f %8.0f" % (name[:34], "%dx%dx%d" % grid, n, us, 100 * util, tfs, mhz))
+    print("%-34s %-14s %5s %9s %8s %8s" % ("kernel", "grid", "calls", "avg_us", "MfmaUtil", "TF/s"))
+    for _, name, grid, n, us, util, tfs, mops in out[:40]:
+        print("%-34s %-14s %5d %9.1f %7.1f%% %8.1f" % (name[:34], "%dx%dx%d" % grid, n, us, 100 * util, tfs))
     wsum = sum(o[5] * o[4] * o[3] for o in out)
     tsum = sum(o[4] * o[3] for o in out)
     print("time-weighted MfmaUtil over %d dispatches of %d kernels: %.1f%%  (f32 MFMA peak 157.3 TF/s)" %

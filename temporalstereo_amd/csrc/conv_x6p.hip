@@ -57,9 +57,18 @@ struct XPG {
   static constexpr int SLOTS = in_rows * QPR;           // (row, quad) staging slots; threads [0, SLOTS) stage channels 0-7, [SLOTS, 2 SLOTS) 8-15
   static constexpr int NPB = HR / 4;                    // 32-pixel blocks (= rows) per wave
   static constexpr int HALF_U = 3 * 2 * NPIX;           // 16-byte units of a half's input tile
+  // HR = 4 has the LDS for a third weight buffer and needs it: its matrix phase is half as long, and with all 27 LDS-DMA instructions
+  // of a step in half 1's stage phase (100-185 cycles of issue each) that phase was the longer one.  Three buffers let BOTH halves issue
+  // their share in their own stage phase (the buffer being filled was last read two steps ago).  HR = 8: two buffers, half 1 issues.
+  static constexpr int NWB = HR == 4 ? 3 : 2;
+  // staging threads per (row, quad): HR = 8: two (8 channels each, 16-byte LDS stores); HR = 4: four (4 channels each, 8-byte
+  // stores by lane PAIRS of one pixel unit) -- 240 of 256 threads stage instead of 120
+  static constexpr int SPC = HR == 4 ? 4 : 2;
+  static constexpr int NCH = 16 / SPC;
   // weights, the two halves' tiles, 8 waves x 8 channels of output staging, scale + shift
-  static constexpr size_t lds_bytes = (static_cast<size_t>(2) * XP_WBUF + 2 * HALF_U) * 16 + (8 * 8 * (NPB * 32 + 4) + 2 * XP_MAXC) * 4;
-  static_assert(2 * SLOTS <= 256, "staging slots");
+  static constexpr int TILE0 = NWB * XP_WBUF;           // first 16-byte unit of the halves' tiles
+  static constexpr size_t lds_bytes = (static_cast<size_t>(TILE0) + 2 * HALF_U) * 16 + (8 * 8 * (NPB * 32 + 4) + 2 * XP_MAXC) * 4;
+  static_assert(SPC * SLOTS <= 256, "staging slots");
 };
 
 // one tile of the work list: (batch element, depth plane, output-channel group, 2 HR x 32 pixel tile)
@@ -78,7 +87,7 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   const int wave = tid >> 6, lane = tid & 63;
   const int px = lane & 31, grp = lane >> 5;
   u32x4* wls = ldsp;                                          // [buffer][row][32]
-  u32x4* in6 = ldsp + 2 * XP_WBUF + half * G::HALF_U;         // [part][group][NPIX]
+  u32x4* in6 = ldsp + G::TILE0 + half * G::HALF_U;         // [part][group][NPIX]
 
   // ---- the work list.  The launch is PERSISTENT: min(tiles, 256) workgroups, each walking its share of the
   // (batch, plane, channel group, tile) order, so that a workgroup's prologue (first fetch, first weights: ~8 k of ~96 k cycles) is
@@ -111,9 +120,12 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   const int nchunk = (p.Cin + XP_NC - 1) / XP_NC;
 
   // ---- staging deal: thread -> (channel group, row, aligned quad) of the half's (HR + 2) x 40 input tile
-  const bool stager = tid < 2 * G::SLOTS;
-  const int sg = tid / G::SLOTS;
-  const int sslot = tid - sg * G::SLOTS;
+  constexpr int SPC = G::SPC, NCH = G::NCH;
+  const bool stager = tid < SPC * G::SLOTS;
+  // HR = 8: thread -> (group sg, slot); HR = 4: lanes 2j, 2j + 1 are the two 4-channel halves (shalf) of one (group, slot)
+  const int sg = SPC == 2 ? tid / G::SLOTS : tid / (2 * G::SLOTS);
+  const int shalf = SPC == 2 ? 0 : (tid & 1);
+  const int sslot = SPC == 2 ? tid - sg * G::SLOTS : (tid - sg * 2 * G::SLOTS) >> 1;
   const int srow = sslot / G::QPR, squad = sslot - srow * G::QPR;
   // LDS pixel units are stored with the pixel-in-quad index XORed by bit 1 of the quad index (swz below): the eight lanes of a
   // ds_write_b128 bank group are eight consecutive quads, 64 bytes apart -- four of them on each half of the 32 write banks (4-way
@@ -146,24 +158,25 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
     goff = (stager && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
         ? (static_cast<unsigned>(t.od) * HW + static_cast<unsigned>(gy) * p.W + gx) * 4u : kOOB;
   };
-  v4f rin[8];
+  v4f rin[NCH];
   auto fetch = [&](int c) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < NCH; ++e) {
       // channels past Cin re-read the last real one; their weights are zero
-      const unsigned co = static_cast<unsigned>(min(c * XP_NC + sg * 8 + e, p.Cin - 1)) * cstride_b;
+      const unsigned co = static_cast<unsigned>(min(c * XP_NC + sg * 8 + shalf * 4 + e, p.Cin - 1)) * cstride_b;
       rin[e] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, (goff == kOOB || (p.dbg & 1)) ? kOOB : goff + co, 0, 0));
     }
   };
   // weight DMA: instruction i (0..26) = (part, tap) = (i / 9, i % 9), its 64 lanes = (group, co); wave w of half 1 issues i = w, w + 4, ...
-  auto dma_weights = [&](int c, int co0, int buf) {
+  // share: -1 = all 27 instructions by this half's four waves; 0 | 1 = the even | odd ones (both halves take part, NWB == 3)
+  auto dma_weights = [&](int c, int co0, int buf, int share) {
     u32x4* dst = wls + buf * XP_WBUF;
     const unsigned cbase = static_cast<unsigned>(c) * wchunk_b;
     const bool lane_ok = co0 + px < p.coutp && !(p.dbg & 16);
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
-      const int i = wave + 4 * q;
-      if (i < 27) {
+      const int i = share < 0 ? wave + 4 * q : 2 * (wave + 4 * q) + share;
+      if (i < 27 && (share < 0 || q < 4)) {
         const int pt = i / 9, tap = i - pt * 9;
         const unsigned row = static_cast<unsigned>((pt * XP_GSLOTS + tap) * 2 + grp);
         const unsigned off = lane_ok ? (row * p.coutp + co0 + px) * 16u + cbase : kOOB;
@@ -175,11 +188,14 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
     if (stager && !(p.dbg & 4)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        unsigned part[3][4];
+        unsigned part[3][NCH / 2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split6(rin[2 * e][i], rin[2 * e + 1][i], part[0][e], part[1][e], part[2][e]);
+        for (int e = 0; e < NCH / 2; ++e) split6(rin[2 * e][i], rin[2 * e + 1][i], part[0][e], part[1][e], part[2][e]);
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt) in6[pt * 2 * NPIX + lpix + (i ^ wsw)] = u32x4{part[pt][0], part[pt][1], part[pt][2], part[pt][3]};
+        for (int pt = 0; pt < 3; ++pt) {
+          if constexpr (SPC == 2) in6[pt * 2 * NPIX + lpix + (i ^ wsw)] = u32x4{part[pt][0], part[pt][1], part[pt][2], part[pt][3]};
+          else reinterpret_cast<u32x2*>(in6 + pt * 2 * NPIX + lpix + (i ^ wsw))[shalf] = u32x2{part[pt][0], part[pt][1]};
+        }
       }
     }
   };
@@ -205,8 +221,8 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   // (tools/exp/x6p_trace.py).  Wave-private: no barrier of its own -- it simply lengthens this half's next stage phase while the
   // other half multiplies.  scale / shift were copied to LDS when the workgroup started.
   constexpr int EPITCH = NPB * 32 + 4;
-  float* scr = reinterpret_cast<float*>(ldsp + 2 * XP_WBUF + 2 * G::HALF_U) + (threadIdx.x >> 6) * (8 * EPITCH);
-  const float* ss = reinterpret_cast<const float*>(ldsp + 2 * XP_WBUF + 2 * G::HALF_U) + 8 * 8 * EPITCH;
+  float* scr = reinterpret_cast<float*>(ldsp + G::TILE0 + 2 * G::HALF_U) + (threadIdx.x >> 6) * (8 * EPITCH);
+  const float* ss = reinterpret_cast<const float*>(ldsp + G::TILE0 + 2 * G::HALF_U) + 8 * 8 * EPITCH;
   auto epilogue = [&](const XPTile& t) {
     const __amdgpu_buffer_rsrc_t yr = ig_rsrc(y + static_cast<long long>(t.b) * p.out_bstride, p.out_bytes);
     const unsigned ocs = static_cast<unsigned>(p.out_cstride) * 4u;
@@ -271,7 +287,7 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   // (a step = one chunk of one tile; steps run through the workgroup's tiles without a seam)
   if (first >= band1) return;
   {
-    float* ssw = reinterpret_cast<float*>(ldsp + 2 * XP_WBUF + 2 * G::HALF_U) + 8 * 8 * EPITCH;
+    float* ssw = reinterpret_cast<float*>(ldsp + G::TILE0 + 2 * G::HALF_U) + 8 * 8 * EPITCH;
     for (int i = threadIdx.x; i < p.coutp; i += 512) {
       ssw[i] = scale ? scale[i] : 1.f;
       ssw[XP_MAXC + i] = shift ? shift[i] : 0.f;
@@ -280,13 +296,15 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   XPTile cur = tile_at(first);
   aim(cur);
   fetch(0);
+  constexpr int NWB = G::NWB;
+  if (NWB == 3) dma_weights(0, cur.co0, 0, half);
+  else if (half == 1) dma_weights(0, cur.co0, 0, -1);
   if (half == 1) {
-    dma_weights(0, cur.co0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     phase_barrier();                                    // half 1 runs one phase behind
   }
   stamp();
-  int gs = 0;                                           // steps done: weight buffer parity
+  int wcur = 0, wnext = 1;                              // weight buffers of this step and the next (rotating through NWB)
   for (int L = first; L < band1; L += step) {
     const bool more = L + step < band1;
     const XPTile nxt = more ? tile_at(L + step) : cur;
@@ -294,12 +312,13 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
     for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
-    for (int c = 0; c < nchunk; ++c, ++gs) {
+    for (int c = 0; c < nchunk; ++c, wcur = wnext, wnext = (wnext + 1 == NWB ? 0 : wnext + 1)) {
       const bool last = c + 1 == nchunk;
       // ---- stage: the fetched registers have landed; split and commit
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stamp();
-      if (half == 1 && (!last || more)) dma_weights(last ? 0 : c + 1, last ? nxt.co0 : cur.co0, (gs + 1) & 1);
+      if ((NWB == 3 || half == 1) && (!last || more))
+        dma_weights(last ? 0 : c + 1, last ? nxt.co0 : cur.co0, wnext, NWB == 3 ? half : -1);
       commit();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       stamp();
@@ -308,7 +327,7 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
       // ---- compute
       if (!last) fetch(c + 1);
       else if (more) { aim(nxt); fetch(0); }
-      const u32x4* wb = wls + (gs & 1) * XP_WBUF;
+      const u32x4* wb = wls + wcur * XP_WBUF;
       f32x16 part[NACC];
 #pragma unroll
       for (int a = 0; a < NACC; ++a)
@@ -330,7 +349,7 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
         __builtin_amdgcn_sched_group_barrier(0x100, 3 + 3 * NPB, 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          if (tap + 1 < 9 && !(p.dbg & 32)) load_frag(tap + 1, (tap + 1) & 1);
+          if (tap + 1 < 9) load_frag(tap + 1, (tap + 1) & 1);
           constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first
 #pragma unroll
           for (int t = 0; t < 6; ++t)
@@ -348,7 +367,7 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NPB - (3 + 3 * NPB), 0);
+            if constexpr (6 * NPB > 3 + 3 * NPB) __builtin_amdgcn_sched_group_barrier(0x008, 6 * NPB - (3 + 3 * NPB), 0);       // (a group of size 0 undoes the pinning: HR = 4 ran read bursts and exposed waits)
           } else {
             __builtin_amdgcn_sched_group_barrier(0x008, 6 * NPB, 0);
           }
@@ -367,7 +386,8 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
         }
       if (trc) asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[NPB - 1][15]));
       stamp();
-      if (half == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the next step's weights are in LDS
+      // the next step's weights (this half's share of them) are in LDS: everything but the fetches issued after them has landed
+      if (NWB == 3 || half == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCH) : "memory");
       phase_barrier();
       stamp();
     }

@@ -1701,15 +1701,41 @@ extern "C" int ts_conv3d_hw_x6_fwd(const float* x, const void* w6, const float* 
   // TS_X6P_MIN_WGS 8 x 32 tiles;
   // TS_X6P=0 keeps every layer on ig_conv_x6_kernel.
   static const bool x6p_on = env_not_zero("TS_X6P");
-  static const long long x6p_min = env_ll("TS_X6P_MIN_WGS", 128);        // of its 8 x 32 tiles: 136 (128 -> 32 on 136 x 240) 29.3 vs 37.5 us, 72 (128 -> 64 on 68 x 120) 27.0 vs 24.7
-  if (x6p_on && !split && dilation == 1 && Cout > 16 && act <= ACT_RELU) {
+  static const long long x6p_min = env_ll("TS_X6P_MIN_WGS", 128);        // of its 8 x 32 work items: 136 (128 -> 32 on 136 x 240) 29.3 vs 37.5 us, 72 (128 -> 64 on 68 x 120) 27.0 vs 24.7
+  static const bool x6p_split_on = env_not_zero("TS_X6P_KSPLIT");
+  if (x6p_on && dilation == 1 && Cout > 16 && act <= ACT_RELU) {
     ts::X6P q;
     q.Cin = Cin; q.Cout = Cout; q.coutp = p.coutp; q.B = B; q.D = D; q.H = H; q.W = W; q.act = act; q.act_param = act_param;
     q.in_bstride = in_bstride; q.in_cstride = in_cstride; q.out_bstride = out_bstride; q.out_cstride = out_cstride;
     q.in_bytes = p.in_bytes; q.w_bytes = p.w_bytes; q.out_bytes = p.out_bytes;
     q.addend = addend; q.add_bstride = addend_bstride; q.add_cstride = p.add_cstride; q.xcd = p.xcd; q.tiles_x = 0; q.co_groups = 0;
-    if (ts::x6p_grid(q) >= x6p_min && D <= 65535 && static_cast<long long>(B) * ((Cout + 31) / 32) <= 65535)
-      return ts::x6p_launch(x, w6, scale, shift, y, q, stream);
+    const int nchunk = (Cin + X6_NC - 1) / X6_NC;
+    q.ksplit = 1; q.kspan = nchunk; q.partial = nullptr; q.part_bytes = 0;
+    // its own split-K: long reductions (16+ chunks) on grids under a round of its one-per-CU workgroups are cut into 2 | 4 | 8 slices of two
+    // chunks at least while the items still fit the round (352 -> 32 on 12 x 34 x 60: 120 items x 2; 256 -> 64 on 34 x 60: 20 x 8),
+    // within the workspace the caller sized by ts_conv3d_hw_x6_workspace_bytes
+    int xks = 1;
+    const long long t8 = ts::x6p_grid(q);
+    const unsigned long long slice_b = static_cast<unsigned long long>(B) * Cout * plane * sizeof(float);
+    if (x6p_split_on && nchunk >= 16 && workspace != nullptr && static_cast<unsigned long long>(Cout) * plane * 4ull < 0x7fffffffull &&
+        static_cast<long long>(B) * Cout <= 65535)
+      while (xks < 8 && t8 * xks * 2 <= ts::kNumCU + ts::kNumCU / 8 && nchunk >= xks * 4 && slice_b * (xks * 2) <= workspace_bytes) xks *= 2;
+    while (xks > 1 && ((nchunk + xks - 1) / xks) * (xks - 1) >= nchunk) xks /= 2;         // every slice owns a chunk
+    if (t8 * xks >= x6p_min && D <= 65535 && static_cast<long long>(B) * ((Cout + 31) / 32) <= 65535) {
+      if (xks > 1) {
+        q.ksplit = xks; q.kspan = (nchunk + xks - 1) / xks;
+        q.partial = reinterpret_cast<float*>(workspace);
+        q.part_bytes = static_cast<unsigned>(static_cast<unsigned long long>(Cout) * plane * 4ull);
+      }
+      const int rc6 = ts::x6p_launch(x, w6, scale, shift, y, q, stream);
+      if (rc6 || xks == 1) return rc6;
+      long long blocks = (plane + 255) / 256;
+      const long long cap = (4096 + static_cast<long long>(B) * Cout - 1) / (static_cast<long long>(B) * Cout);
+      if (blocks > cap) blocks = cap;
+      hipLaunchKernelGGL(conv_splitk_finish, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(B * Cout)), dim3(256), 0, st, q.partial, scale, shift,
+                         y, B, Cout, plane, xks, act, act_param, out_bstride, out_cstride, addend, addend_bstride, static_cast<long long>(H) * W);
+      return ts::launched("conv_splitk_finish");
+    }
   }
   // grids under 3/4 of a round of 8-row workgroups (2 per CU): 4-row tiles (ig_conv_x6_kernel, TR); TS_X6_TR=8 | 4 forces one form
   static const long long tr_env = env_ll("TS_X6_TR", 0);

@@ -74,6 +74,8 @@ struct XPG {
 // one tile of the work list: (batch element, depth plane, output-channel group, 2 HR x 32 pixel tile)
 struct XPTile {
   int b, od, co0, ty0, tx0;
+  int c0, c1;       // chunk range of the work item (split-K: a slice of the input channels, raw sums to the workspace)
+  int ks;
 };
 
 template <int HR>
@@ -104,12 +106,15 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   } else {
     band0 = 0; band1 = total; first = g; step = nwg;
   }
+  const int nchunk = (p.Cin + XP_NC - 1) / XP_NC;
   auto tile_at = [&](int L) {
     XPTile t;
     const int tile = L % p.tiles_pp;
     int r = L / p.tiles_pp;
     const int cog = r % p.co_groups; r /= p.co_groups;
-    t.od = r % p.D; t.b = r / p.D;
+    t.od = r % p.D; r /= p.D;
+    t.b = r % p.B; t.ks = r / p.B;
+    t.c0 = t.ks * p.kspan; t.c1 = min(nchunk, t.c0 + p.kspan);
     t.co0 = cog * 32;
     t.ty0 = (tile / p.tiles_x) * (2 * HR) + half * HR;
     t.tx0 = (tile % p.tiles_x) * 32;
@@ -117,7 +122,6 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   };
   const unsigned HW = static_cast<unsigned>(p.H) * p.W;
   const unsigned cstride_b = static_cast<unsigned>(p.in_cstride) * 4u;
-  const int nchunk = (p.Cin + XP_NC - 1) / XP_NC;
 
   // ---- staging deal: thread -> (channel group, row, aligned quad) of the half's (HR + 2) x 40 input tile
   constexpr int SPC = G::SPC, NCH = G::NCH;
@@ -224,9 +228,14 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   float* scr = reinterpret_cast<float*>(ldsp + G::TILE0 + 2 * G::HALF_U) + (threadIdx.x >> 6) * (8 * EPITCH);
   const float* ss = reinterpret_cast<const float*>(ldsp + G::TILE0 + 2 * G::HALF_U) + 8 * 8 * EPITCH;
   auto epilogue = [&](const XPTile& t) {
-    const __amdgpu_buffer_rsrc_t yr = ig_rsrc(y + static_cast<long long>(t.b) * p.out_bstride, p.out_bytes);
-    const unsigned ocs = static_cast<unsigned>(p.out_cstride) * 4u;
-    const float* ab = p.addend ? p.addend + static_cast<size_t>(t.b) * p.add_bstride : nullptr;
+    // split-K (p.ksplit > 1): the slice's RAW sums go to the workspace, [slice][batch][channel][plane]; conv_splitk_finish (conv3d.hip)
+    // adds the slices in a fixed order and applies addend / scale / shift / activation
+    const bool split = p.ksplit > 1;
+    const __amdgpu_buffer_rsrc_t yr = split
+        ? ig_rsrc(p.partial + (static_cast<size_t>(t.ks) * p.B + t.b) * p.Cout * (static_cast<size_t>(p.D) * HW), p.part_bytes)
+        : ig_rsrc(y + static_cast<long long>(t.b) * p.out_bstride, p.out_bytes);
+    const unsigned ocs = split ? static_cast<unsigned>(p.D) * HW * 4u : static_cast<unsigned>(p.out_cstride) * 4u;
+    const float* ab = (p.addend && !split) ? p.addend + static_cast<size_t>(t.b) * p.add_bstride : nullptr;
     const unsigned obase = static_cast<unsigned>(t.od) * HW;
     // (uniform conditions outside the element loops: inside, hipcc put a branch and an s_waitcnt vmcnt(0) -- which also waits for the
     // previous round's STORES -- in front of every element)
@@ -243,11 +252,12 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) {                       // accumulator register r holds channel (r & 3) + 8 (r >> 2) + 4 grp (32 x 32 C/D map)
       const int cc = min(t.co0 + (r & 3) + 8 * (r >> 2) + 4 * grp, p.coutp - 1);
-      const float sc = ss[cc], sh = ss[XP_MAXC + cc];
+      const float sc = split ? 1.f : ss[cc], sh = split ? 0.f : ss[XP_MAXC + cc];
 #pragma unroll
       for (int pb = 0; pb < NPB; ++pb) acc[pb][r] = acc[pb][r] * sc + sh;
     }
-    if (p.act == ACT_SILU) {
+    if (split) {
+    } else if (p.act == ACT_SILU) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -295,10 +305,10 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
   }                           // (the whole workgroup: an XCD's band can be shorter than its workgroup count)
   XPTile cur = tile_at(first);
   aim(cur);
-  fetch(0);
+  fetch(cur.c0);
   constexpr int NWB = G::NWB;
-  if (NWB == 3) dma_weights(0, cur.co0, 0, half);
-  else if (half == 1) dma_weights(0, cur.co0, 0, -1);
+  if (NWB == 3) dma_weights(cur.c0, cur.co0, 0, half);
+  else if (half == 1) dma_weights(cur.c0, cur.co0, 0, -1);
   if (half == 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     phase_barrier();                                    // half 1 runs one phase behind
@@ -312,13 +322,13 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
     for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
-    for (int c = 0; c < nchunk; ++c, wcur = wnext, wnext = (wnext + 1 == NWB ? 0 : wnext + 1)) {
-      const bool last = c + 1 == nchunk;
+    for (int c = cur.c0; c < cur.c1; ++c, wcur = wnext, wnext = (wnext + 1 == NWB ? 0 : wnext + 1)) {
+      const bool last = c + 1 == cur.c1;
       // ---- stage: the fetched registers have landed; split and commit
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stamp();
       if ((NWB == 3 || half == 1) && (!last || more))
-        dma_weights(last ? 0 : c + 1, last ? nxt.co0 : cur.co0, wnext, NWB == 3 ? half : -1);
+        dma_weights(last ? nxt.c0 : c + 1, last ? nxt.co0 : cur.co0, wnext, NWB == 3 ? half : -1);
       commit();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       stamp();
@@ -326,7 +336,7 @@ ig_conv_x6p_kernel(const float* __restrict__ x, const u32x4* __restrict__ w6, co
       stamp();
       // ---- compute
       if (!last) fetch(c + 1);
-      else if (more) { aim(nxt); fetch(0); }
+      else if (more) { aim(nxt); fetch(nxt.c0); }
       const u32x4* wb = wls + wcur * XP_WBUF;
       f32x16 part[NACC];
 #pragma unroll
@@ -418,7 +428,7 @@ static unsigned long long* trace_buf = nullptr;
 constexpr size_t kTraceBytes = 4096 + 8000 * 32;
 
 static long long tiles_of(const X6P& p, int hr) {
-  return static_cast<long long>((p.H + 2 * hr - 1) / (2 * hr)) * ((p.W + 31) / 32) * p.D * p.B * ((p.Cout + 31) / 32);
+  return static_cast<long long>((p.H + 2 * hr - 1) / (2 * hr)) * ((p.W + 31) / 32) * p.D * p.B * ((p.Cout + 31) / 32) * (p.ksplit > 1 ? p.ksplit : 1);
 }
 
 int x6p_rows(const X6P& p) {
@@ -432,7 +442,7 @@ int x6p_rows(const X6P& p) {
   return 100 * r8 <= 58 * r4 ? 8 : 4;
 }
 
-// 8 x 32 tiles of the layer (the caller's threshold between this kernel and ig_conv_x6_kernel)
+// 8 x 32 work items of the layer, slices included (the caller's threshold between this kernel and ig_conv_x6_kernel)
 long long x6p_grid(const X6P& p) { return tiles_of(p, 4); }
 
 int x6p_launch(const float* x, const void* w6, const float* scale, const float* shift, float* y, X6P p, void* stream) {
@@ -445,7 +455,8 @@ int x6p_launch(const float* x, const void* w6, const float* scale, const float* 
   p.tiles_x = (p.W + 31) / 32;
   p.co_groups = (p.Cout + 31) / 32;
   p.tiles_pp = ((p.H + 2 * hr - 1) / (2 * hr)) * p.tiles_x;
-  const long long total = static_cast<long long>(p.tiles_pp) * p.co_groups * p.D * p.B;
+  if (p.ksplit < 1) p.ksplit = 1;
+  const long long total = static_cast<long long>(p.tiles_pp) * p.co_groups * p.D * p.B * p.ksplit;
   if (total > 0x3fffffff) return fail(TS_ERR_UNSUPPORTED, "conv3d_hw_x6: too many tiles");
   p.total_tiles = static_cast<int>(total);
   // persistent: one workgroup per CU (its 132 KB of LDS fill one), fewer when there are fewer tiles

@@ -13,6 +13,9 @@ struct X6P {
   const float* addend;          // [B][Cout][H*W] added to every depth plane's sum before scale/shift (or null)
   long long add_bstride, add_cstride;
   int xcd;                      // XCD-banded workgroup order
+  int ksplit, kspan;            // split-K: this many slices of `kspan` 16-channel chunks each (1: unsplit)
+  float* partial;               // [ksplit][B][Cout][D*H*W] raw sums when ksplit > 1
+  unsigned part_bytes;          // extent of one (slice, batch) block of the partials
   int tiles_x, co_groups, tiles_pp, total_tiles;       // filled by x6p_launch (tiles per row / per plane / in all)
   int dbg;                      // experiment switches (TS_X6P_DBG; 0 in production)
   unsigned long long* trace;    // experiment: cycle stamps of workgroup trace_wg (TS_X6P_TRACE), else null

@@ -10,11 +10,14 @@ ACC = [  # B, Cin, Cout, D, H, W, addend
     (1, 16, 32, 2, 24, 64, False), (2, 32, 32, 3, 37, 44, False), (1, 176, 24, 5, 34, 60, True), (1, 20, 24, 2, 16, 36, False),
     (1, 64, 64, 1, 40, 72, False), (1, 128, 32, 1, 68, 120, False), (1, 32, 144, 1, 24, 40, False), (1, 512, 17, 1, 32, 64, False),
     (3, 40, 33, 2, 1, 4, False), (1, 31, 80, 1, 5, 8, True), (2, 100, 48, 1, 19, 76, False), (1, 64, 32, 1, 272, 480, False),
+    # 9..16 output channels: the row-paired form
+    (1, 64, 16, 7, 68, 120, False), (2, 48, 12, 3, 37, 44, True), (1, 128, 16, 1, 68, 120, False), (1, 176, 9, 2, 33, 36, False), (1, 32, 16, 1, 272, 480, False),
 ]
 TIME = [  # name, Cin, Cout, D, H, W
     ("unet 32->32 272x480", 32, 32, 1, 272, 480), ("unet 64->64 136x240", 64, 64, 1, 136, 240), ("unet 128->32 272x480", 128, 32, 1, 272, 480),
     ("unet 64->32 272x480", 64, 32, 1, 272, 480), ("unet 128->32 136x240", 128, 32, 1, 136, 240), ("unet 32->32 136x240", 32, 32, 1, 136, 240),
     ("coarse 128->32 D14 34x60", 128, 32, 14, 34, 60), ("coarse 32->32 D12 34x60", 32, 32, 12, 34, 60), ("conv 128->64 68x120", 128, 64, 1, 68, 120),
+    ("fine 64->16 D7 68x120", 64, 16, 7, 68, 120), ("conv 128->16 68x120", 128, 16, 1, 68, 120), ("fine 48->16 D5 68x120", 48, 16, 5, 68, 120),
 ]
 
 

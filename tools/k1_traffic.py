@@ -46,7 +46,7 @@ def main(fetch_db, write_db):
     for name, sub, grid in (("main (reference half + warped half + scale-0 correlation + pooled maps)", "block_cost_fast<true, true, 3, true, true>", (34, 16, 1)),
                             ("expansion of the pooled maps", "block_cost_upsample_rows<true, 4>", (8, 80, 1)),
                             ("round 1-3 pipeline: main without the reference half", "block_cost_fast<true, true, 3, false, true>", (34, 16, 1)),
-                            ("round 4-5 pipeline: the correlation planes alone", "block_cost_corr_rows<2>", (34, 16, 1))):
+                            ("round 4-5 pipeline: the correlation planes alone", "block_cost_corr_rows<2", (34, 16, 1))):
         f, w = find(F, sub, grid) * kib, find(W, sub, grid) * kib
         rows[name] = dict(fetch_size_bytes_raw=f, write_size_bytes_raw=w, hbm_bytes=f * fx + w * wx)
     main_b = rows["main (reference half + warped half + scale-0 correlation + pooled maps)"]["hbm_bytes"]

@@ -459,9 +459,19 @@ int x6p_launch(const float* x, const void* w6, const float* scale, const float* 
   const long long total = static_cast<long long>(p.tiles_pp) * p.co_groups * p.D * p.B * p.ksplit;
   if (total > 0x3fffffff) return fail(TS_ERR_UNSUPPORTED, "conv3d_hw_x6: too many tiles");
   p.total_tiles = static_cast<int>(total);
-  // persistent: one workgroup per CU (its 132 KB of LDS fill one), fewer when there are fewer tiles
-  static const long long max_wgs = env_ll("TS_X6P_WGS", kNumCU);
-  const int nwg = static_cast<int>(total < max_wgs ? total : max_wgs);
+  // persistent: one workgroup per CU (its 140-154 KB of LDS fill one), at most TS_X6P_WGS of them, and no more than the rounds need
+  // (510 tiles under a cap of 224 are three rounds: 170 workgroups take three tiles each, the other CUs stay free for the launches of
+  // the pass's other streams -- which cannot share a CU with this kernel's LDS footprint)
+  // Cap 208 of 256: measured 256 / 232 / 224 / 208 / 192 / 176 / 160 / 128 -> 1318 / 1335 / 1322 / 1333 / 1330 / 1313 / 1305 / 1266 pairs/s with
+  // three passes in flight, batch 4 1763 / 1804 / 1802 / 1798 / 1810 / 1771 / 1767 / 1742, one pass at a time 961-965 throughout (>= 160): what a
+  // pass's throughput follows is CU-time, not this launch's latency, and a workgroup that walks more tiles pays its prologue once.
+  static const long long max_wgs = env_ll("TS_X6P_WGS", 208);
+  int nwg = static_cast<int>(total < max_wgs ? total : max_wgs);
+  {
+    const long long rounds = (total + nwg - 1) / nwg;
+    const long long even = (total + rounds - 1) / rounds;
+    nwg = static_cast<int>(((even + 7) / 8 * 8 <= nwg) ? (even + 7) / 8 * 8 : even);
+  }
   hipStream_t st = as_stream(stream);
   return hr == 8 ? launch_x6p<8>(x, w6, scale, shift, y, p, nwg, st) : launch_x6p<4>(x, w6, scale, shift, y, p, nwg, st);
 }

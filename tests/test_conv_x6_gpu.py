@@ -156,3 +156,24 @@ def test_x6_split_k_equals_the_unsplit_form(shape):
         assert torch.isfinite(out).all()
         assert float((out.double() - ref).abs().max()) <= 1e-6 * scale
     assert float((outs[0] - outs[1]).abs().max()) <= 5e-7 * scale
+
+
+@pytest.mark.parametrize("rows", ["8", "4"])
+def test_ping_pong_form_forced_on_every_grid(rows):
+    """ig_conv_x6p_kernel (csrc/conv_x6p.hip) is chosen by grid size, so the small shapes above mostly run the older kernel.  Its
+    switches are read once per process: a child process with the form forced on every grid (TS_X6P_MIN_WGS=1) and the half-tile height
+    pinned runs the accuracy sweep of tools/exp/x6p_check.py -- ragged tiles, ragged channel counts on both sides, 5 channel groups,
+    an addend, one-row / four-column images, 272 x 480 (several tiles per persistent workgroup) -- against fp64 convolutions with the
+    bound of this file (1e-6 of the output's magnitude)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TS_X6P_MIN_WGS="1", TS_X6P_HR=rows)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "x6p_check.py"), "--child", "acc"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("acc ")]
+    assert len(lines) >= 30 and not any("FAIL" in l for l in lines), "\n".join(l for l in lines if "FAIL" in l)
+    worst = float([l for l in r.stdout.splitlines() if l.startswith("worst")][0].split()[1])
+    assert worst <= 1e-6

@@ -86,9 +86,9 @@ def parse_args():
                     help="also launch the known-size read / fill / copy streams of csrc/calib.hip (1 GiB each) once, "
                          "so that a PMC pass of this command carries its own FETCH_SIZE / WRITE_SIZE calibration "
                          "(tools/k1_traffic.py)")
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3),
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3, 4),
                     help="native mode: N > 1 = the engine keeps N independent passes in flight on N sets of "
-                         "launch-plan buffers, each pass a three-stage pipeline over the engine's streams; 1 = one "
+                         "launch-plan buffers, each pass a four-stage pipeline over the engine's streams; 1 = one "
                          "pass at a time")
     ap.add_argument("--inflight", type=int, default=0,
                     help="extra measurement (does not change `value`): pairs/s with this many independent pairs in "

@@ -107,9 +107,9 @@ class InferenceEngine:
                           copied; a call with different storage records a new plan for it.
         private_streams: the native backend's two helper streams are shared by every engine of a device;
                 True gives this engine its own pair (several passes in flight on one GPU).
-        pipeline: N = 2 or 3 keeps N passes in flight (replay='plan', inputs='bind' only).  The pass is recorded N times,
-                on N sets of buffers used in turn, as a three-stage pipeline over the engine's streams (coarse level |
-                fine level | wide UNet half + 1/4-level tail on the caller's stream); none of the engine's streams waits
+        pipeline: N = 2, 3 or 4 keeps N passes in flight (replay='plan', inputs='bind' only).  The pass is recorded N times,
+                on N sets of buffers used in turn, as a four-stage pipeline over the engine's streams (coarse level |
+                fine level | wide UNet half | 1/4-level tail on the caller's stream); none of the engine's streams waits
                 for the caller's stream, where the tail of the previous call is still running on other buffers:
                 consecutive, independent frames overlap (single-frame mode; a temporal sequence has a true dependency
                 from frame to frame and should use pipeline=1).  Contract: the bound input tensors are complete on
@@ -140,7 +140,7 @@ class InferenceEngine:
         self.backend, self.use_graph, self.replay = backend, graph, replay
         self.warmup = warmup
         self._graphs = {}
-        if pipeline not in (1, 2, 3) or (pipeline > 1 and not (replay == "plan" and self.bind)):
+        if pipeline not in (1, 2, 3, 4) or (pipeline > 1 and not (replay == "plan" and self.bind)):
             raise ValueError("pipeline>1 needs replay='plan' and inputs='bind'")
         self.pipeline = pipeline
         self._slot_of = {}          # one named event per recorded plan: "the pass that last used these buffers is done"

@@ -996,6 +996,9 @@ class NativeAggregator:
             # simply completes here.
             torch.cuda.synchronize(dev)
         self.fast, self.aux = qualified_streams(dev, 2, private=private_streams)
+        # round 6: a stream of its own for the disparity-independent UNet half when several passes are in flight (_staged_pass): on the
+        # caller's stream it queued behind the previous pass's 1/4-level tail.  TS_STAGE4=0: the three-stage form of rounds 2-5.
+        self.wide = qualified_streams(dev, 1, private=True)[0] if os.environ.get("TS_STAGE4", "1") != "0" else None
         self.pipeline_slot = None            # set by the engine while it records one of its double-buffered plans
         self.overlap = True
 
@@ -1032,9 +1035,9 @@ class NativeAggregator:
         return ds
 
     def _staged_pass(self, l4, l8, l16, r4, r8, r16, left_image, right_image, prev_info, out):
-        """Several passes in flight (engine.py, pipeline >= 2): the pass as a three-stage pipeline, one stage per
-        stream -- `fast`: upsampling logits + coarse level, `aux`: fine level, caller's stream: wide UNet half, then the
-        1/4-level tail -- with exactly two cross-stream edges (coarse -> fine, fine -> tail) and no branches inside a
+        """Several passes in flight (engine.py, pipeline >= 2): the pass as a pipeline of stages, one per stream -- `fast`:
+        upsampling logits + coarse level, `aux`: fine level, `wide` (round 6): the UNet half that needs no disparity, caller's
+        stream: the 1/4-level tail -- with three cross-stream edges (coarse -> fine, fine -> tail, wide -> tail) and no branches inside a
         stage: every edge towards a stream that is still busy with the previous pass's stage would stall this pass
         behind it (measured: 773 pairs/s with the latency-mode branches kept, 882 without, depth 2).  None of the
         engine's streams waits for the caller's stream, where the tail of the previous pass is still running on other
@@ -1051,11 +1054,21 @@ class NativeAggregator:
                 mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
                 ltf = self.fine.feature_terms(_lib.contiguous(l8), _lib.contiguous(r8))
                 ds = self._coarse_level(l16, r16, prev_info, out, lambda: mc)
-            both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
+            if self.wide is not None:
+                # the disparity-independent UNet half as a FOURTH stage on a stream of its own: it overlaps the previous pass's 1/4-level
+                # tail (both sat on the caller's stream: 1337 -> 1344-1349 pairs/s at batch 1, 1843 -> 1951-1955 at batch 4).  Like `fast`
+                # and `aux` it waits for the pass that last used these buffers, not for the caller's stream.
+                _lib.check(L.ts_event_wait(slot, P(self.wide)), "ts_event_wait")
+                with torch.cuda.stream(self.wide):
+                    both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
+            else:
+                both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
             _edge(self.fast, self.aux)
             with torch.cuda.stream(self.aux):
                 ds = self._fine_level(l8, r8, ds, prev_info, out, lambda: mf, lambda: ltf)
             _edge(self.aux, main)
+            if self.wide is not None:
+                _edge(self.wide, main)
             res = self.precise(both, mask, ds, prev_info)
             _lib.check(L.ts_event_record(slot, P(main)), "ts_event_record")
         finally:

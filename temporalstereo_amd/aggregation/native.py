@@ -867,13 +867,18 @@ class NativeFine(_MergingLevel):
         super().__init__(mod)
         self.split_reference_half()
 
-    def __call__(self, left, right, ds, prev_info, mask=None, terms=None, next_range=None):
-        """terms: feature_terms(left, right), or a callable returning it (produced on another stream: the callable joins it)."""
+    def early(self, left, right, ds, terms=None):
+        """Cost volume + first layer + init3d of the level (fine.py:96-103): everything before the temporal merge."""
         lt, rt = terms() if callable(terms) else (terms if terms is not None else self.feature_terms(left, right))
         if rt is not None:
-            vol = self.init3d_from(self.first_layer_fused(left, right, ds, lt, rt))
-        else:
-            vol = self.init3d(TF.block_cost_warped(left, right, ds, self.scales), lt)
+            return self.init3d_from(self.first_layer_fused(left, right, ds, lt, rt))
+        return self.init3d(TF.block_cost_warped(left, right, ds, self.scales), lt)
+
+    def __call__(self, left, right, ds, prev_info, mask=None, terms=None, next_range=None, vol=None):
+        """terms: feature_terms(left, right), or a callable returning it (produced on another stream: the callable joins it).
+        vol: early(...) made beforehand (a pipelined pass runs it as a stage of its own)."""
+        if vol is None:
+            vol = self.early(left, right, ds, terms)
         return self.merge_fuse_predict(vol, ds, prev_info, left, resize_memory=False, mask=mask, next_range=next_range)
 
 
@@ -937,6 +942,12 @@ class NativePrecise(_LevelBase):
         (module.py:459-466), the [feature | spx4] concatenation both views feed to block_cost, and the
         decoder down to the 9-tap upsampling mask (module.py:484-491).  Independent of the pyramid, so
         the aggregator runs it concurrently with the coarse and fine levels."""
+        both, lterm, st = self.unet_encode(left, right, left_image, right_image)
+        return both, (self.unet_decode(st), lterm)
+
+    def unet_encode(self, left, right, left_image, right_image):
+        """First part of unet_features: the image encoder of both views, the [feature | spx4] concatenation and the first layer's
+        per-pixel terms -- what the 1/4 level's cost volume needs.  Returns (both, lterm, state for unet_decode)."""
         B, Cf, H, W = left.shape
         both = torch.empty((2 * B, 2 * Cf, H, W), device=left.device, dtype=torch.float32)   # [left | right] x [feat | spx4]
         lcat, rcat = both[:B], both[B:]
@@ -945,23 +956,34 @@ class NativePrecise(_LevelBase):
         cat2 = torch.empty((B, C32 + C2, 2 * H, 2 * W), device=left.device, dtype=torch.float32)      # [deconv4 | s2 of the left view]
         self.encode(left_image, right_image, both, cat2[:, C32:].unsqueeze(2))
         lterm = self.feature_terms(lcat, rcat)
+        return both, lterm, (lcat, cat2, B, H, W)
+
+    def unet_decode(self, st):
+        """Second part: the decoder down to the 9-tap upsampling mask (module.py:484-491), needed by the last launch of a pass only."""
+        lcat, cat2, B, H, W = st
         f = self._c2d(self._c2d(lcat.unsqueeze(2), self.fuse[0], 1), self.fuse[1], 1).squeeze(2)
         self._deconv(_lib.contiguous(f), self.deconv4, cat2, cat2.stride(0))
         g = _lib.contiguous(self._c2d(cat2.unsqueeze(2), self.concat, 1).squeeze(2))
-        mask = torch.empty((B, 9, 4 * H, 4 * W), device=left.device, dtype=torch.float32)
+        mask = torch.empty((B, 9, 4 * H, 4 * W), device=lcat.device, dtype=torch.float32)
         self._deconv(g, self.deconv2, mask, mask.stride(0))
-        return both, (mask, lterm)
+        return mask
 
-    def __call__(self, both, mask_lterm, ds, prev_info):
+    def early(self, both, lterm, ds):
+        """Cost volume + first layer + init3d of the 1/4 level (precise.py:88-93)."""
         B = both.shape[0] // 2
-        H, W = both.shape[-2:]
-        mask, lterm = mask_lterm
         lcat, rcat = both[:B], both[B:]
         lt, rt = lterm
         if rt is not None:
-            vol = self.init3d_from(self.first_layer_fused(lcat, rcat, ds, lt, rt))
-        else:
-            vol = self.init3d(TF.block_cost_warped(lcat, rcat, ds, self.scales), lt)
+            return self.init3d_from(self.first_layer_fused(lcat, rcat, ds, lt, rt))
+        return self.init3d(TF.block_cost_warped(lcat, rcat, ds, self.scales), lt)
+
+    def __call__(self, both, mask_lterm, ds, prev_info, vol=None):
+        B = both.shape[0] // 2
+        H, W = both.shape[-2:]
+        mask, lterm = mask_lterm
+        mask = mask() if callable(mask) else mask
+        if vol is None:
+            vol = self.early(both, lterm, ds)
         cost, off = self.heads(vol)
         disp, mem_s, mem_c = TF.topk_softargmax(cost, ds, off, k=self.topk)
         full = torch.empty((B, 1, 4 * H, 4 * W), device=both.device, dtype=torch.float32)
@@ -996,9 +1018,13 @@ class NativeAggregator:
             # simply completes here.
             torch.cuda.synchronize(dev)
         self.fast, self.aux = qualified_streams(dev, 2, private=private_streams)
-        # round 6: a stream of its own for the disparity-independent UNet half when several passes are in flight (_staged_pass): on the
-        # caller's stream it queued behind the previous pass's 1/4-level tail.  TS_STAGE4=0: the three-stage form of rounds 2-5.
-        self.wide = qualified_streams(dev, 1, private=True)[0] if os.environ.get("TS_STAGE4", "1") != "0" else None
+        # Stage streams of a pipelined pass (_staged_pass).  Rounds 2-5: three (coarse level | fine level | UNet half + 1/4-level tail on the
+        # caller's stream).  Round 6: the pipeline was bound by its longest STAGE, not by the chip -- a fourth stream for the UNet half
+        # (batch 4 1843 -> 1951 pairs/s), the fine level's feature-only work moved from the coarse stage (the longest) to the head of its own
+        # (batch 1 1336 -> 1434-1443), each level cut at its temporal merge (cost volume + init3d | merge, fusion, heads, regression) and
+        # the UNet half at its decoder.  TS_STAGES = 3 | 4 | 5 ... 8: how many streams (default 8); the last stage is always the caller's.
+        self._extra_streams = qualified_streams(dev, 3, private=True)
+        self._stage_sets = {}
         self.pipeline_slot = None            # set by the engine while it records one of its double-buffered plans
         self.overlap = True
 
@@ -1027,12 +1053,32 @@ class NativeAggregator:
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
 
-    def _fine_level(self, l8, r8, ds, prev_info, out, mask=None, terms=None):
+    def _fine_level(self, l8, r8, ds, prev_info, out, mask=None, terms=None, vol=None):
         rng = 4
         disps, costs, offs, samples, ranges = out
-        (d, low, high, ds), c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, mask, terms, (rng, 0))
+        (d, low, high, ds), c, o, s = self.fine(_lib.contiguous(l8), _lib.contiguous(r8), ds, prev_info, mask, terms, (rng, 0), vol=vol)
         disps.append(d); costs.append(c); offs.append(o); samples.append(s); ranges.append({'low': low, 'high': high})
         return ds
+
+    def _stages_for(self, batch):
+        """role -> stream (None: the caller's) of a pipelined pass.  Six streams at batch 1 (more than six share hardware queues and the
+        pipeline collapses: 1512 -> 860 pairs/s at seven), four from batch 2 on (1960 vs 1900 at batch 4: its launches fill the chip, a
+        finer cut only adds edges).  TS_STAGES=3..6 and TS_STAGE_ORDER=unet,coarse2,fine2 override (A/B runs)."""
+        nst = int(os.environ.get("TS_STAGES", "6" if batch == 1 else "4"))
+        key = (nst, os.environ.get("TS_STAGE_ORDER", ""))
+        if key not in self._stage_sets:
+            extra = self._extra_streams[:max(0, min(nst, 6) - 3)]
+            S = {"coarse": self.fast, "fine": self.aux}
+            order = [r for r in os.environ.get("TS_STAGE_ORDER", "unet,coarse2,fine2").split(",") if r]
+            order += [r for r in ("unet", "coarse2", "fine2", "tail", "unet2") if r not in order]
+            parent = {"unet": None, "coarse2": "coarse", "fine2": "fine", "tail": None, "unet2": "unet"}
+            for i, role in enumerate(order):
+                S[role] = extra[i] if i < len(extra) else None
+            for role in order:                       # roles without a stream of their own: their predecessor's (or the caller's)
+                if S[role] is None and parent[role]:
+                    S[role] = S[parent[role]]
+            self._stage_sets[key] = S
+        return self._stage_sets[key]
 
     def _staged_pass(self, l4, l8, l16, r4, r8, r16, left_image, right_image, prev_info, out):
         """Several passes in flight (engine.py, pipeline >= 2): the pass as a pipeline of stages, one per stream -- `fast`:
@@ -1046,30 +1092,43 @@ class NativeAggregator:
         main = torch.cuda.current_stream()
         slot = self.pipeline_slot
         P = lambda st: _lib.ctypes.c_void_p(st.cuda_stream)
-        _lib.check(L.ts_event_wait(slot, P(self.fast)), "ts_event_wait")
-        _lib.check(L.ts_event_wait(slot, P(self.aux)), "ts_event_wait")
+        # by role; a role without a stream of its own shares its predecessor's, or runs on the caller's stream
+        S = {k: (v if v is not None else main) for k, v in self._stages_for(l4.shape[0]).items()}
+        for st in {id(v): v for v in S.values() if v is not main}.values():
+            _lib.check(L.ts_event_wait(slot, P(st)), "ts_event_wait")          # the pass that last used THESE buffers is done
+        on = torch.cuda.stream
+
+        def edge(a, b):
+            if a is not b:
+                _edge(a, b)
         try:
             _chunk_cap(8)
-            with torch.cuda.stream(self.fast):
-                mc, mf = self.coarse.up.mask(_lib.contiguous(l16)), self.fine.up.mask(_lib.contiguous(l8))
-                ltf = self.fine.feature_terms(_lib.contiguous(l8), _lib.contiguous(r8))
-                ds = self._coarse_level(l16, r16, prev_info, out, lambda: mc)
-            if self.wide is not None:
-                # the disparity-independent UNet half as a FOURTH stage on a stream of its own: it overlaps the previous pass's 1/4-level
-                # tail (both sat on the caller's stream: 1337 -> 1344-1349 pairs/s at batch 1, 1843 -> 1951-1955 at batch 4).  Like `fast`
-                # and `aux` it waits for the pass that last used these buffers, not for the caller's stream.
-                _lib.check(L.ts_event_wait(slot, P(self.wide)), "ts_event_wait")
-                with torch.cuda.stream(self.wide):
-                    both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
-            else:
-                both, mask = self.precise.unet_features(l4, r4, left_image, right_image)
-            _edge(self.fast, self.aux)
-            with torch.cuda.stream(self.aux):
-                ds = self._fine_level(l8, r8, ds, prev_info, out, lambda: mf, lambda: ltf)
-            _edge(self.aux, main)
-            if self.wide is not None:
-                _edge(self.wide, main)
-            res = self.precise(both, mask, ds, prev_info)
+            l16c, r16c, l8c, r8c = _lib.contiguous(l16), _lib.contiguous(r16), _lib.contiguous(l8), _lib.contiguous(r8)
+            with on(S["coarse"]):
+                mc = self.coarse.up.mask(l16c)
+                cvol = self.coarse.early(l16c, r16c)
+            with on(S["fine"]):                        # feature-only work of the fine level at the head of ITS stage
+                mf = self.fine.up.mask(l8c)
+                ltf = self.fine.feature_terms(l8c, r8c)
+            with on(S["unet"]):
+                both, lterm, ust = self.precise.unet_encode(l4, r4, left_image, right_image)
+            edge(S["unet"], S["unet2"])
+            with on(S["unet2"]):
+                mask = self.precise.unet_decode(ust)
+            edge(S["coarse"], S["coarse2"])
+            with on(S["coarse2"]):
+                ds = self._coarse_level(l16, r16, prev_info, out, lambda: mc, vol=cvol)
+            edge(S["coarse2"], S["fine"])
+            with on(S["fine"]):
+                fvol = self.fine.early(l8c, r8c, ds, ltf)
+            edge(S["fine"], S["fine2"])
+            with on(S["fine2"]):
+                ds = self._fine_level(l8, r8, ds, prev_info, out, lambda: mf, None, vol=fvol)
+            edge(S["fine2"], S["tail"]); edge(S["unet"], S["tail"])
+            with on(S["tail"]):
+                pvol = self.precise.early(both, lterm, ds)
+            edge(S["tail"], main); edge(S["unet2"], main)
+            res = self.precise(both, (mask, lterm), ds, prev_info, vol=pvol)
             _lib.check(L.ts_event_record(slot, P(main)), "ts_event_record")
         finally:
             _chunk_cap(32)

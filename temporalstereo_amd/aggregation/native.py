@@ -1061,15 +1061,17 @@ class NativeAggregator:
         return ds
 
     def _stages_for(self, batch):
-        """role -> stream (None: the caller's) of a pipelined pass.  Six streams at batch 1 (more than six share hardware queues and the
-        pipeline collapses: 1512 -> 860 pairs/s at seven), four from batch 2 on (1960 vs 1900 at batch 4: its launches fill the chip, a
-        finer cut only adds edges).  TS_STAGES=3..6 and TS_STAGE_ORDER=unet,coarse2,fine2 override (A/B runs)."""
-        nst = int(os.environ.get("TS_STAGES", "6" if batch == 1 else "4"))
-        key = (nst, os.environ.get("TS_STAGE_ORDER", ""))
+        """role -> stream (None: the caller's) of a pipelined pass.  Batch 1: six streams, the levels cut at their temporal merge (more
+        than six share hardware queues and the pipeline collapses: 1512 -> 860 pairs/s at seven; `tail` on a stream of its own loses in
+        every combination).  From batch 2 on the launches fill the chip and the finer cut of the levels only adds edges (1900 vs 1960 at
+        batch 4): five streams, the UNet half -- the longest stage -- cut at its decoder (1983 -> 1991 at batch 4, 2017 -> 2058 at 8).
+        TS_STAGES=3..6 and TS_STAGE_ORDER=role,role,... override (A/B runs)."""
+        nst = int(os.environ.get("TS_STAGES", "6" if batch == 1 else "5"))
+        key = (nst, os.environ.get("TS_STAGE_ORDER", ""), batch == 1)
         if key not in self._stage_sets:
             extra = self._extra_streams[:max(0, min(nst, 6) - 3)]
             S = {"coarse": self.fast, "fine": self.aux}
-            order = [r for r in os.environ.get("TS_STAGE_ORDER", "unet,coarse2,fine2").split(",") if r]
+            order = [r for r in os.environ.get("TS_STAGE_ORDER", "unet,coarse2,fine2" if batch == 1 else "unet,unet2").split(",") if r]
             order += [r for r in ("unet", "coarse2", "fine2", "tail", "unet2") if r not in order]
             parent = {"unet": None, "coarse2": "coarse", "fine2": "fine", "tail": None, "unet2": "unet"}
             for i, role in enumerate(order):

@@ -88,7 +88,8 @@ def parse_args():
                          "(tools/k1_traffic.py)")
     ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3, 4),
                     help="native mode: N > 1 = the engine keeps N independent passes in flight on N sets of "
-                         "launch-plan buffers, each pass a four-stage pipeline over the engine's streams; 1 = one "
+                         "launch-plan buffers, each pass a pipeline of stages over the engine's streams (six at batch "
+                         "1); 1 = one "
                          "pass at a time")
     ap.add_argument("--inflight", type=int, default=0,
                     help="extra measurement (does not change `value`): pairs/s with this many independent pairs in "
@@ -353,6 +354,16 @@ def main():
                                   input_buffer_sets=depth, weights_and_inputs=weights,
                                   conv_arithmetic=_CONV_ARITHMETIC),
                       roofline=roofline)
+        if mode == "native" and depth > 1:
+            # disclosed with the passes in flight: the streams a pass is cut over (NativeAggregator._stages_for)
+            streams = {id(v) for v in runner.net._stages_for(a.batch).values() if v is not None}
+            result["config"]["pipeline_streams"] = 1 + len(streams)
+        if training is not None:
+            # flat copies: a record that keeps only the top level of nested objects still shows them
+            result["config"]["training_ms_per_step"] = training.get("ms_per_step")
+            result["config"]["training_hipgraph_ms_per_step"] = (training.get("hipgraph") or {}).get("ms_per_step")
+        if one is not None:
+            result["config"]["one_pass_at_a_time_pairs_per_s"] = one.get("value")
         for key, val in (("conditioning", conditioning), ("one_pass_at_a_time", one), ("f32_mfma_only", f32_only),
                          ("concurrent_pairs", concurrent), ("training", training), ("sequence", sequence)):
             if val is not None:

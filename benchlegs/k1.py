@@ -167,7 +167,8 @@ def fused_first_layer(k1, runner, batch):
 def committed_traffic(pkey):
     """HBM bytes per launch from the PMC passes committed under profiles/ (a PMC pass cannot run inside the timed
     process)."""
-    for cand in ("r06_k1_hbm_traffic_pmc.json", "r05_k1_hbm_traffic_pmc.json", "r04_k1_hbm_traffic_pmc.json", "r03_k1_hbm_traffic_pmc.json",
+    for cand in ("r06_k1_hbm_traffic_pmc.json", "r05_k1_hbm_traffic_pmc.json", "r04_k1_hbm_traffic_pmc.json",
+                 "r03_k1_hbm_traffic_pmc.json",
                  "r02_k1_hbm_traffic_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as fh:

@@ -1068,6 +1068,18 @@ class NativeAggregator:
         TS_STAGES=3..6 and TS_STAGE_ORDER=role,role,... override (A/B runs)."""
         nst = int(os.environ.get("TS_STAGES", "6" if batch == 1 else "5"))
         key = (nst, os.environ.get("TS_STAGE_ORDER", ""), batch == 1)
+        smap = os.environ.get("TS_STAGE_MAP", "")
+        if smap:
+            # experiment: explicit role -> stream, e.g. "unet:2,coarse2:3,fine2:4,unet2:4,tail:m" (0 fast, 1 aux, 2-4 extras, m caller's)
+            key = ("map", smap)
+            if key not in self._stage_sets:
+                pool = [self.fast, self.aux] + list(self._extra_streams)
+                S = {"coarse": self.fast, "fine": self.aux, "unet": None, "coarse2": self.fast, "fine2": self.aux, "tail": None, "unet2": None}
+                for item in smap.split(","):
+                    role, idx = item.split(":")
+                    S[role] = None if idx == "m" else pool[int(idx)]
+                self._stage_sets[key] = S
+            return self._stage_sets[key]
         if key not in self._stage_sets:
             extra = self._extra_streams[:max(0, min(nst, 6) - 3)]
             S = {"coarse": self.fast, "fine": self.aux}

@@ -47,9 +47,13 @@ def main(path, pattern="%ig_conv%"):
         out.append((busy * n, name, grid, n, dur / 1e3, util, flops / dur / 1e3, mops))
     out.sort(reverse=True)
     tot_busy = sum(o[0] for o in out)
-    print("%-34s %-14s %5s %9s %8s %8s" % ("kernel", "grid", "calls", "avg_us", "MfmaUtil", "TF/s"))
+    # MfmaUtil is a share of the WHOLE chip's matrix pipes.  A persistent kernel (ig_conv_x6p_kernel: one workgroup per CU, at most 208 of
+    # them, fewer when the rounds divide evenly) leaves CUs to the pass's other streams on purpose: the last column is the same share over
+    # the CUs it occupies (grid <= 256 workgroups of a one-per-CU kernel).
+    print("%-34s %-14s %5s %9s %8s %8s %12s" % ("kernel", "grid", "calls", "avg_us", "MfmaUtil", "TF/s", "of its CUs"))
     for _, name, grid, n, us, util, tfs, mops in out[:40]:
-        print("%-34s %-14s %5d %9.1f %7.1f%% %8.1f" % (name[:34], "%dx%dx%d" % grid, n, us, 100 * util, tfs))
+        own = ("%10.1f%%" % (100 * util * 256.0 / grid[0])) if ("x6p" in name and grid[0] <= 256 and grid[1] == 1 and grid[2] == 1) else ""
+        print("%-34s %-14s %5d %9.1f %7.1f%% %8.1f %12s" % (name[:34], "%dx%dx%d" % grid, n, us, 100 * util, tfs, own))
     wsum = sum(o[5] * o[4] * o[3] for o in out)
     tsum = sum(o[4] * o[3] for o in out)
     print("time-weighted MfmaUtil over %d dispatches of %d kernels: %.1f%%  (f32 MFMA peak 157.3 TF/s)" %

@@ -13,16 +13,20 @@
 //     splits and commits its next chunk (VALU + LDS writes beside the other wave's MFMAs on the same SIMD), and the epilogue of a
 //     half falls into a phase in which the other half still multiplies.  The alternation the two independent workgroups of the old
 //     kernel never found by themselves is forced.
-//   * v_mfma_f32_32x32x16_bf16: K = 16 = ONE tap x 16 input channels, so nine taps are nine steps (no zero slot: -10 % MFMA work),
-//     32 x 32 x 16 has half the LDS bytes per FLOP of 16 x 16 x 32 and the higher issue rate (2382 vs 2075 TF in the guide's table).
-//     A = weights (32 output channels x 16), B = pixels (16 x 32 pixels of one row), D[channel][pixel].
+//   * v_mfma_f32_32x32x16_bf16: K = 16 = ONE tap x 16 input channels, so nine taps are nine steps (no zero slot: -10 % MFMA work) and
+//     half the LDS bytes per FLOP of 16 x 16 x 32.  A = weights (32 output channels x 16), B = pixels (16 x 32 pixels of one row),
+//     D[channel][pixel].  (Measured here: one instruction per 40 cycles, not the 32 of the tables -- tools/exp/x6p_trace.py.)
 //   * the split weights (already [chunk][part][slot][group][co] x 8 bf16 in global memory, ts_conv3d_hw_x6_weight_split) go to LDS by
 //     LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR round trip, no commit pass, double-buffered and SHARED by the two halves (they
 //     multiply the same chunk one phase apart).  The zero slot 9 of the global layout is simply not fetched.
 //   * numerics as ig_conv_x6_kernel: six products per fp32 product (smallest first), a chunk's products summed in accumulators of
 //     their own and added to the running sum with an fp32 add.  tests/test_conv_x6_gpu.py holds both kernels to the same fp64 bounds.
-// LDS (16-byte units): weights [2 buffers][54 rows = (part, tap, group)][32 co] first (inside the first 64 KB: the DMA's M0 base),
-// then per half the input tile [part 3][group 2][(HR + 2) x 40 pixels]: 55,296 + 2 x 38,400 = 132,096 bytes at HR = 8.
+//   * PERSISTENT: at most 208 workgroups walk the (batch, plane, channel group, tile[, K slice]) order, XCD-banded; a tile's epilogue
+//     (scale / shift / activation, wave-private LDS transposition, 16-byte stores) needs no barrier of its own and falls into a phase in
+//     which the other half multiplies.  Split-K as work items (raw sums to the caller's workspace, conv_splitk_finish in conv3d.hip).
+// LDS (16-byte units): weights [2 (HR = 4: 3) buffers][54 rows = (part, tap, group)][32 co] first (inside the first 64 KB: the DMA's
+// M0 base), then per half the input tile [part 3][group 2][(HR + 2) x 40 pixels], the waves' output staging and scale / shift:
+// 55,296 + 2 x 38,400 + 17,408 + 4,096 = 153,600 bytes at HR = 8.  DESIGN.md section 4 (K3x6p) has the measurements.
 #include "conv_common.hpp"
 #include "conv_x6p.hpp"
 
@@ -34,8 +38,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int XP_NC = 16;                 // input channels per chunk (= K of one MFMA)
 constexpr int XP_WROWS = 3 * 9 * 2;       // LDS weight rows per chunk: (part, tap, group), 32 output channels x 16 bytes each
 constexpr int XP_WBUF = XP_WROWS * 32;    // 16-byte units per weight buffer
-constexpr int XP_GSLOTS = 10;
-constexpr int XP_MAXC = 512;               // widest layer (ts_conv3d_hw_x6_supported)             // tap slots of the GLOBAL weight layout (slot 9: zeros, not fetched)
+constexpr int XP_GSLOTS = 10;             // tap slots of the GLOBAL weight layout (slot 9: zeros, not fetched)
+constexpr int XP_MAXC = 512;              // widest layer (ts_conv3d_hw_x6_supported)
 
 __device__ __forceinline__ void phase_barrier() {
   // LDS writes / reads of this wave are done (lgkmcnt), then the workgroup barrier.  NOT __syncthreads(): with an LDS-DMA or the next

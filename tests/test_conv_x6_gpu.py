@@ -177,3 +177,10 @@ def test_ping_pong_form_forced_on_every_grid(rows):
     assert len(lines) >= 30 and not any("FAIL" in l for l in lines), "\n".join(l for l in lines if "FAIL" in l)
     worst = float([l for l in r.stdout.splitlines() if l.startswith("worst")][0].split()[1])
     assert worst <= 1e-6
+    # ... and 60 random geometries against the f32-MFMA kernel (to fp32 rounding: 4e-6 of the output's magnitude), SiLU / ReLU / none,
+    # with and without an addend, split-K where the workspace rule gives one
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "x6p_check.py"), "--child", "fuzz"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("fuzz ")]
+    assert len(lines) == 60 and not any("FAIL" in l for l in lines), "\n".join(l for l in lines if "FAIL" in l)

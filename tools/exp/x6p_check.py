@@ -79,9 +79,45 @@ def child_time():
             print("time B=%d %-28s %7.1f us  %6.1f TF eq." % (B, name, t, fl / t / 1e6), flush=True)
 
 
+def child_fuzz():
+    """Random geometries (one-row / four-column images, ragged tiles and channel counts, several planes and batch elements, 17..144 output
+    channels) with the form forced: ts_conv3d_hw_x6_fwd against the f32-MFMA kernel, to fp32 rounding everywhere."""
+    import numpy as np
+    import torch
+    from temporalstereo_amd.aggregation import native as N
+    N._X6_MIN_GRID = 1
+    N._X6_MIN_GRID_UNSPLIT = 1
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(20260930)
+    worst = 0.0
+    for case in range(60):
+        B = int(rng.randint(1, 4)); Cin = int(rng.choice([32, 33, 40, 48, 64, 100, 128, 272])); Cout = int(rng.choice([17, 20, 32, 33, 48, 64, 80, 144]))
+        D = int(rng.randint(1, 6)); H = int(rng.randint(1, 70)); W = 4 * int(rng.randint(1, 40))
+        g = torch.Generator().manual_seed(3000 + case)
+        x = torch.randn(B, Cin, D, H, W, generator=g).to(dev)
+        w = (torch.randn(Cout, Cin, 1, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(dev)
+        act = [N.ACT_NONE, N.ACT_SILU, N.ACT_RELU][case % 3]
+        f = N.Folded(w, torch.randn(Cout, generator=g).to(dev), None, act, False, "hw")
+        add = torch.randn(B, Cout, 1, H, W, generator=g).to(dev) if case % 4 == 0 else None
+        outs = {}
+        for x6 in (True, False):
+            N.X6 = x6
+            try:
+                outs[x6] = N.conv_hw(x, f, 1, 1, addend=add)
+            finally:
+                N.X6 = True
+        torch.cuda.synchronize()
+        scale = max(float(outs[False].abs().max()), 1.0)
+        err = float((outs[True] - outs[False]).abs().max()) / scale
+        worst = max(worst, err)
+        ok = err <= 4e-6 and bool(torch.isfinite(outs[True]).all())
+        print("fuzz %2d B%d %3d->%3d D%d %2dx%3d act%d add%d  %.3e%s" % (case, B, Cin, Cout, D, H, W, act, add is not None, err, "" if ok else "   <-- FAIL"), flush=True)
+    print("worst %.3e" % worst)
+
+
 if __name__ == "__main__":
     if "--child" in sys.argv:
-        {"acc": child_acc, "time": child_time}[sys.argv[sys.argv.index("--child") + 1]]()
+        {"acc": child_acc, "time": child_time, "fuzz": child_fuzz}[sys.argv[sys.argv.index("--child") + 1]]()
         sys.exit(0)
     runs = [("acc", {"TS_X6P_MIN_WGS": "1", "TS_X6P_HR": "8"}), ("acc", {"TS_X6P_MIN_WGS": "1", "TS_X6P_HR": "4"}),
             ("time", {"TS_X6P": "0"}), ("time", {"TS_X6P_MIN_WGS": "1"}), ("time", {"TS_X6P_MIN_WGS": "1", "TS_X6P_HR": "4"}),

@@ -8,7 +8,7 @@
 
 #include "../../include/ts_hip.h"
 
-#define TS_ABI_VERSION 9   // 9: ts_peer_status_async / set_timeout_ms / reset, layout + bf16 split of a framework-layout weight in one launch (ts_conv3d_hw_x6_weight_split_from), two-table weight layouts (ts_conv_weight_layout_many2); 8: ts_peer_* (SyncBatchNorm exchanges as kernels over peer-mapped memory); 7: ts_conv3d_hw_x6s_* (bf16-split stride-2 / transposed convolutions); 6: ts_block_cost_sampled_corr_fwd, ts_conv3d_hw_warp_fwd (first layer of a sampled level without the warped volume); 5: split-K workspace of ts_conv3d_hw_x6_fwd; 4: train_ops (candidates, offset head, deconv2d training forms, clip+RMSprop); 3: bwd_weight workspace, bn_stats counter, x6 / weight-layout / bn_train
+#define TS_ABI_VERSION 10   // 10: ts_inverse_warp_3d_fwd (the inverse_warp_3d seam); 9: ts_peer_status_async / set_timeout_ms / reset, layout + bf16 split of a framework-layout weight in one launch (ts_conv3d_hw_x6_weight_split_from), two-table weight layouts (ts_conv_weight_layout_many2); 8: ts_peer_* (SyncBatchNorm exchanges as kernels over peer-mapped memory); 7: ts_conv3d_hw_x6s_* (bf16-split stride-2 / transposed convolutions); 6: ts_block_cost_sampled_corr_fwd, ts_conv3d_hw_warp_fwd (first layer of a sampled level without the warped volume); 5: split-K workspace of ts_conv3d_hw_x6_fwd; 4: train_ops (candidates, offset head, deconv2d training forms, clip+RMSprop); 3: bwd_weight workspace, bn_stats counter, x6 / weight-layout / bn_train
 
 namespace ts {
 

@@ -11,10 +11,29 @@ enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_TANH_OFFSET = 3, ACT_HE
 
 // co: output channel (only ACT_HEAD_PAIR looks at it: channel 0 = the cost head, no activation; channel 1 =
 // the offset head -- both prediction heads as one block-diagonal convolution)
+// v / (1 + e^-v) with v_exp_f32 and v_rcp_f32 (1 ulp each) instead of the library's expf and an IEEE division: ~6 instructions per value
+// (+ one Newton step on the reciprocal: 8) instead of ~30.  A convolution lane finishes 16-32 values with nothing left to hide them -- 4.5 k of a 7 k-cycle epilogue in the x6
+// kernels (tools/exp/x6p_trace.py), 1-2 us of every launch-bound layer of the pyramid.  |error| ~1.5 ulp of the result, the class of the exact form (the unrefined reciprocal's extra ulp was enough to move one more near-tie of
+// a temporal sequence in tests/test_fullsize_gpu.py's audit); the e^-v
+// argument's rounding (|v| 2^-24 relative: |v| 6e-8 of e^-v) only meets results that are themselves ~e^-|v|.  Below v = -88.7 e^-v is inf, the
+// reciprocal 0 and the Newton step would be inf * 0: the unrefined 0 is kept there (v * 0 = -0, as the exact form's v / inf; NaN stays NaN)
+// (tests/test_conv_x6_gpu.py::test_silu_epilogue_at_the_ends_of_the_range).
+// TS_EXACT_SILU (compile-time) restores the library form.
+__device__ __forceinline__ float silu_fast(float v) {
+#ifdef TS_EXACT_SILU
+  return v / (1.f + expf(-v));
+#else
+  const float d = 1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float rn = fmaf(fmaf(-d, r, 1.f), r, r);          // one Newton step: the quotient to ~0.5 ulp, as the IEEE division's
+  return v * (d < 3.0e38f ? rn : r);
+#endif
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float p, int co = 0) {
   if (act == ACT_HEAD_PAIR) act = co == 0 ? ACT_NONE : ACT_TANH_OFFSET;
   switch (act) {
-    case ACT_SILU: return v / (1.f + expf(-v));
+    case ACT_SILU: return silu_fast(v);
     case ACT_RELU: return fmaxf(v, 0.f);
     // PredictionHeads.regress_offset (module.py:384-390): tanh(x/100).clamp(-1,1) * delta
     case ACT_TANH_OFFSET: return fminf(fmaxf(tanhf(v / 100.f), -1.f), 1.f) * p;

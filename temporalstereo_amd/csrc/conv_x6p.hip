@@ -47,14 +47,6 @@ __device__ __forceinline__ void phase_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// v / (1 + e^-v) with v_exp_f32 and v_rcp_f32 (1 ulp each) instead of the library's expf and an IEEE division: ~6 instructions per value
-// instead of ~30 -- 32 values per lane sat at the end of every workgroup with nothing left to hide them (4.5 k of a 7 k-cycle epilogue).
-// |error| <= ~2 ulp of the result where it matters; the e^-v argument's rounding (|v| 2^-24 relative) only meets results that are
-// themselves ~e^-|v|.  tests/test_conv_x6_gpu.py bounds the whole layer against fp64.
-__device__ __forceinline__ float silu_fast(float v) {
-  return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
-}
-
 template <int HR>
 struct XPG {
   static constexpr int in_rows = HR + 2, QPR = 10, LCOLS = 40, NPIX = in_rows * LCOLS;

@@ -16,7 +16,13 @@
 
 namespace {
 
-__device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
+// (the inference forms; v_exp_f32 / v_rcp_f32 as conv_common.hpp's silu_fast)
+__device__ __forceinline__ float silu(float v) {
+  const float d = 1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float rn = fmaf(fmaf(-d, r, 1.f), r, r);
+  return v * (d < 3.0e38f ? rn : r);          // d = inf: the Newton step would be inf * 0
+}
 
 unsigned grid_for(long long n, int threads) {
   long long blocks = (n + threads - 1) / threads;

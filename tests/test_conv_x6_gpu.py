@@ -184,3 +184,43 @@ def test_ping_pong_form_forced_on_every_grid(rows):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("fuzz ")]
     assert len(lines) == 60 and not any("FAIL" in l for l in lines), "\n".join(l for l in lines if "FAIL" in l)
+
+
+def test_silu_epilogue_at_the_ends_of_the_range():
+    """The epilogues' SiLU is v * rcp(1 + exp2(-v log2 e)) with one Newton step (csrc/conv_common.hpp silu_fast).  Below -88.7 e^-v is inf,
+    the reciprocal 0 and a Newton step there inf * 0 = NaN (found by tests/test_native_gpu.py loading weights far from the trained scale):
+    every conv kernel and the resize-add-SiLU kernel over sums from -1e30 to 1e30 -- finite everywhere, within 2 ulp of torch's fp64
+    SiLU plus the exponent's rounding (|v| 2^-24 relative, on results that are ~|v| e^-|v| themselves), -0 where fp32's own v e^v is."""
+    from temporalstereo_amd.aggregation import native as N
+    dev = torch.device("cuda:0")
+    ends = [-1e30, -1e8, -1e4, -200.0, -104.0, -100.0, -90.0, -88.8, -88.7, -87.0, -83.2, -83.0, -50.0, -20.0, -5.0, -1.0, -1e-3, -1e-30,
+            0.0, 1e-30, 1e-3, 1.0, 5.0, 20.0, 50.0, 83.2, 88.8, 100.0, 200.0, 1e4, 1e8, 1e30]
+    vals = torch.tensor(ends, dtype=torch.float32).double()
+    ref = F.silu(vals)
+    tol = ref.abs() * (2.5e-7 + 1.2e-7 * (-vals).clamp_min(0.0)) + 1e-35
+
+    def check(got, what, lo=0):
+        got = got.double().cpu()
+        n = min(len(got), len(ends) - lo)
+        got, r, t = got[:n], ref[lo:lo + n], tol[lo:lo + n]
+        assert bool(torch.isfinite(got).all()), (what, got)
+        bad = (got - r).abs() > t
+        assert not bool(bad.any()), (what, [(ends[lo + i], float(got[i]), float(r[i])) for i in torch.nonzero(bad).flatten().tolist()])
+
+    # (1, 32, 4, 64, 256) with 32 output channels: 256 work items, the ping-pong kernel; the small grids stay on ig_conv_x6_kernel / the f32 kernel
+    for shape, cout, x6 in (((1, 32, 4, 64, 256), 32, True), ((1, 32, 2, 16, 32), 32, True), ((1, 32, 2, 16, 32), 16, True), ((1, 32, 2, 16, 32), 32, False)):
+        x = torch.zeros(shape, device=dev)
+        w = torch.zeros(cout, 32, 1, 3, 3, device=dev)
+        for lo in range(0, len(ends), cout):
+            bias = (ends[lo:lo + cout] + [0.0] * cout)[:cout]
+            f = N.Folded(w, torch.tensor(bias, device=dev), None, N.ACT_SILU, False, "hw")
+            N.X6 = x6
+            try:
+                y = N.conv_hw(x, f, 1, 1)
+            finally:
+                N.X6 = True
+            assert bool((y == y[:, :, :1, :1, :1]).all()), (shape, cout, x6)
+            check(y[0, :, 0, 0, 0], (shape, cout, x6), lo)
+    a = torch.tensor(ends, device=dev).view(1, len(ends), 1, 1, 1).expand(1, len(ends), 2, 4, 8).contiguous()
+    check(N.resize_add_act(a, None, (2, 4, 8), N.ACT_SILU)[0, :, 0, 0, 0], "resize_add_act")
+    check(N.resize_add_act(a * 0.5, a * 0.5, (2, 4, 8), N.ACT_SILU)[0, :, 1, 3, 7], "resize_add_act with an addend")

@@ -15,7 +15,7 @@
 //     kernel never found by themselves is forced.
 //   * v_mfma_f32_32x32x16_bf16: K = 16 = ONE tap x 16 input channels, so nine taps are nine steps (no zero slot: -10 % MFMA work) and
 //     half the LDS bytes per FLOP of 16 x 16 x 32.  A = weights (32 output channels x 16), B = pixels (16 x 32 pixels of one row),
-//     D[channel][pixel].  (Measured here: one instruction per 40 cycles, not the 32 of the tables -- tools/exp/x6p_trace.py.)
+//     D[channel][pixel].  (One instruction per 32.3 cycles from one wave per SIMD, tools/exp/mfma_issue_rate.hip; ~35 in this step's form, 40 stamped in the kernel.)
 //   * the split weights (already [chunk][part][slot][group][co] x 8 bf16 in global memory, ts_conv3d_hw_x6_weight_split) go to LDS by
 //     LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR round trip, no commit pass, double-buffered and SHARED by the two halves (they
 //     multiply the same chunk one phase apart).  The zero slot 9 of the global layout is simply not fetched.

@@ -11,6 +11,7 @@
 //
 // The reference has no counterpart (it runs eagerly under PyTorch); the closest notion is a CUDA
 // graph with static input/output buffers, and the contract is the same: pointers are baked in.
+#include <cstdint>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -113,6 +114,18 @@ copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long lo
     const long long r = i / row_elems, c = i - r * row_elems;
     dst[r * dst_pitch + c] = src[r * src_pitch + c];
   }
+}
+
+// rows of whole, 16-byte aligned quads (the engine's feature copies: one row of 2 M floats): a row per blockIdx.y, 16 bytes per
+// lane, no division per element (the scalar form above spends a 64-bit division on every float: 6.4 us for 8 MB where this takes 4.4)
+__global__ void __launch_bounds__(256)
+copy_rows4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long row_quads, long long src_pitch_q,
+                  long long dst_pitch_q) {
+  const float4* s = src + blockIdx.y * src_pitch_q;
+  float4* d = dst + blockIdx.y * dst_pitch_q;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < row_quads;
+       i += static_cast<long long>(gridDim.x) * blockDim.x)
+    d[i] = s[i];
 }
 
 }  // namespace
@@ -244,6 +257,16 @@ extern "C" int ts_copy_rows_fwd(const float* src, float* dst, long long rows, lo
   TS_REQUIRE(rows > 0 && row_elems > 0 && src_pitch >= row_elems && dst_pitch >= row_elems, TS_ERR_SHAPE,
              "copy_rows: bad geometry");
   TS_REQUIRE_PTR(src); TS_REQUIRE_PTR(dst);
+  if (rows <= 65535 && row_elems % 4 == 0 && src_pitch % 4 == 0 && dst_pitch % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0) {
+    const long long rq = row_elems / 4;
+    long long bx = (rq + 255) / 256;
+    const long long cap = (8192 + rows - 1) / rows;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(copy_rows4_kernel, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(rows)), dim3(256), 0, ts::as_stream(stream),
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), rq, src_pitch / 4, dst_pitch / 4);
+    return ts::launched("copy_rows4_kernel");
+  }
   long long blocks = (rows * row_elems + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ts::as_stream(stream), src, dst,

@@ -130,6 +130,19 @@ def test_copy_rows_and_stream_fork():
     src = _rand(21, 3, 4, 4, 5, dev=dev)
     native.copy_rows(src, big[:, 6:])
     assert torch.equal(big[:, 6:], src) and float(big[:, :6].abs().sum()) == 0.0
+    # both forms of the kernel: rows of whole aligned quads (16 bytes per lane) and everything else (ragged rows, pitches that are not
+    # multiples of 4, a destination 4 bytes off a 16-byte boundary), each into a frame that must stay untouched
+    for rows, elems, spitch, dpitch, doff in ((1, 1 << 21, 1 << 21, 1 << 21, 0), (3, 4096, 4096, 8192, 4), (5, 1000, 1004, 1012, 8),
+                                              (2, 999, 1000, 1001, 0), (4, 64, 64, 68, 1), (7, 8, 8, 12, 3), (1, 3, 3, 3, 0)):
+        srcb = _rand(100 + rows, rows * spitch, dev=dev)
+        dstb = torch.full((doff + rows * dpitch + 5,), -7.0, device=dev)
+        L = _lib.lib()
+        _lib.check(L.ts_copy_rows_fwd(_lib.ptr(srcb), _lib.ptr(dstb[doff:]), rows, elems, spitch, dpitch, native._stream()), "ts_copy_rows_fwd")
+        torch.cuda.synchronize()
+        want = torch.full_like(dstb, -7.0)
+        for r in range(rows):
+            want[doff + r * dpitch: doff + r * dpitch + elems] = srcb[r * spitch: r * spitch + elems]
+        assert torch.equal(dstb, want), (rows, elems, spitch, dpitch, doff)
     a, b = torch.cuda.Stream(), torch.cuda.Stream()
     out = torch.empty(1 << 22, device=dev)
     with torch.cuda.stream(a):

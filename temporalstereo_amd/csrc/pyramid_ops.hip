@@ -93,7 +93,11 @@ struct Pool5 {
 
 __global__ void __launch_bounds__(256)
 pool5_avgmax_kernel(const float* __restrict__ x, float* __restrict__ oavg, float* __restrict__ omax, const Pool5 p) {
-  __shared__ float tile[PT_Y + 4][PT_X + 4 + 1];
+  // the haloed plane tile TWICE: padding as 0 for the average (count_include_pad) and as -inf for the maximum, so that a tap is one
+  // add and one max.  (Rounds 2-5 kept ONE tile with padding marked NaN and tested every tap: 5 VALU instructions per tap, 125 per
+  // plane and lane -- the kernel was bound by exactly that: 15.5 us for the coarse level's 14 planes, tools/layer_table.py.)
+  __shared__ float tile_s[PT_Y + 4][PT_X + 4 + 1];
+  __shared__ float tile_m[PT_Y + 4][PT_X + 4 + 1];
   const int tiles_x = (p.W + PT_X - 1) / PT_X;
   const int ty0 = (blockIdx.x / tiles_x) * PT_Y, tx0 = (blockIdx.x % tiles_x) * PT_X;
   const int c = blockIdx.y, b = blockIdx.z;
@@ -116,7 +120,8 @@ pool5_avgmax_kernel(const float* __restrict__ x, float* __restrict__ oavg, float
     soff[e] = min(max(gy, 0), p.H - 1) * p.W + min(max(gx, 0), p.W - 1);
     lidx[e] = cy * (TW + 1) + cx;
   }
-  float* tl = &tile[0][0];
+  float* tls = &tile_s[0][0];
+  float* tlm = &tile_m[0][0];
   float nxt[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) nxt[e] = xp[soff[e]];                            // plane 0
@@ -127,9 +132,11 @@ pool5_avgmax_kernel(const float* __restrict__ x, float* __restrict__ oavg, float
     float s2 = 0.f, m2 = -INFINITY;
     if (d < p.D) {
       __syncthreads();
-      // zero for the average (count_include_pad) and -inf for the max: padding is marked NaN in the tile
 #pragma unroll
-      for (int e = 0; e < 2; ++e) tl[lidx[e]] = pad[e] ? NAN : nxt[e];
+      for (int e = 0; e < 2; ++e) {
+        tls[lidx[e]] = pad[e] ? 0.f : nxt[e];
+        tlm[lidx[e]] = pad[e] ? -INFINITY : nxt[e];
+      }
       __syncthreads();
       const int dn = min(d + 1, p.D - 1);                                      // next plane in flight under the 25 taps
 #pragma unroll
@@ -138,10 +145,8 @@ pool5_avgmax_kernel(const float* __restrict__ x, float* __restrict__ oavg, float
       for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
-          const float v = tile[ty + ky][tx + kx];
-          const bool isp = v != v;             // NaN marks padding
-          s2 += isp ? 0.f : v;
-          m2 = isp ? m2 : fmaxf(m2, v);
+          s2 += tile_s[ty + ky][tx + kx];
+          m2 = fmaxf(m2, tile_m[ty + ky][tx + kx]);
         }
     }
 #pragma unroll

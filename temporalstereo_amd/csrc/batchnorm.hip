@@ -22,15 +22,30 @@ namespace {
 
 enum { BN_ACT_NONE = 0, BN_ACT_SILU = 1, BN_ACT_RELU = 2 };
 
+// 1 / (1 + e^-z) as v_exp_f32 + v_rcp_f32 + one Newton step (conv_common.hpp silu_fast: the inference epilogues' form; ~1.5 ulp).  The
+// library expf + IEEE division are ~40 instructions per element: on a 32 x 272 x 480 layer that alone was 6.7 us of the 13.9 us
+// bn_finish_apply_act_kernel took (and of every backward kernel's, which evaluates it again for the derivative).  e^-z = inf
+// (z < -88.7): the unrefined reciprocal 0 is kept, the Newton step there would be inf * 0.
+__device__ __forceinline__ float sigmoid_fast(float z) {
+#ifdef TS_EXACT_SILU
+  return 1.f / (1.f + expf(-z));
+#else
+  const float d = 1.f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f);
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float rn = fmaf(fmaf(-d, r, 1.f), r, r);
+  return d < 3.0e38f ? rn : r;
+#endif
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == BN_ACT_SILU) return z / (1.f + expf(-z));
+  if (act == BN_ACT_SILU) return z * sigmoid_fast(z);
   if (act == BN_ACT_RELU) return fmaxf(z, 0.f);
   return z;
 }
 
 __device__ __forceinline__ float act_grad(float z, int act) {
   if (act == BN_ACT_SILU) {
-    const float s = 1.f / (1.f + expf(-z));
+    const float s = sigmoid_fast(z);
     return s * (1.f + z * (1.f - s));
   }
   if (act == BN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
@@ -66,12 +81,20 @@ struct BN {
 
 // grid (nchunk, C, B): partial[(c * B + b) * nchunk + k] = (sum x', sum x'^2), x' = x - x[b=0, c, 0]
 __global__ void __launch_bounds__(256)
-bn_stats_partial(const float* __restrict__ x, float2* __restrict__ partial, const BN p) {
+bn_stats_partial(const float* __restrict__ x, float2* __restrict__ partial, const BN p, int vec) {
   const int k = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const float pivot = x[static_cast<size_t>(c) * p.cstride];
   const float* xp = x + static_cast<size_t>(b) * p.bstride + static_cast<size_t>(c) * p.cstride;
   const long long lo = k * p.chunk, hi = min(p.N, lo + p.chunk);
   float s = 0.f, q = 0.f;
+  if (vec) {                  // N, the chunk and the strides are multiples of 4, the base 16-byte aligned: a quad per lane and trip
+    for (long long i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+      const float4 t = *reinterpret_cast<const float4*>(xp + i);
+      const float v0 = t.x - pivot, v1 = t.y - pivot, v2 = t.z - pivot, v3 = t.w - pivot;
+      s += (v0 + v1) + (v2 + v3);
+      q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+    }
+  } else
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const float v = xp[i] - pivot;
     s += v;
@@ -144,7 +167,7 @@ bn_apply_act_kernel(const float* __restrict__ x, const float* __restrict__ mean,
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
                      const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
-                     float2* __restrict__ partial, const BNA p, int nchunk, long long chunk) {
+                     float2* __restrict__ partial, const BNA p, int nchunk, long long chunk, int vec) {
   const int k = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const float m = mean[c], is = rsqrtf(var[c] + p.eps);
   const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
@@ -152,6 +175,23 @@ bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, 
   const float* gp = dy + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
   const long long lo = k * chunk, hi = min(p.N, lo + chunk);
   float s1 = 0.f, s2 = 0.f;
+  if (vec) {
+    for (long long i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+      const float4 xt = *reinterpret_cast<const float4*>(xp + i);
+      const float4 gt = *reinterpret_cast<const float4*>(gp + i);
+      const float xs[4] = {xt.x, xt.y, xt.z, xt.w}, gs[4] = {gt.x, gt.y, gt.z, gt.w};
+      float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xs[e] - m) * is;
+        const float dz = gs[e] * act_grad(xh * g + be, p.act);
+        d1 += dz;
+        d2 += dz * xh;
+      }
+      s1 += d1;
+      s2 += d2;
+    }
+  } else
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const float xh = (xp[i] - m) * is;
     const float dz = gp[i] * act_grad(xh * g + be, p.act);
@@ -227,18 +267,49 @@ __device__ __forceinline__ void channel_partial_sum(const float2* __restrict__ p
 // bn_stats_finish + bn_apply_act in one launch (single-rank training: nothing is exchanged between the two): every workgroup
 // sums its channel's partials itself (a few hundred bytes from L2, the same fixed order, so all of them agree to the bit) and
 // workgroup (0, c, 0) leaves mean / var for the backward pass and updates the running statistics.
+// four consecutive elements of a plane block, requested BEFORE anything that waits (VEC: one 16-byte access; N % 4 == 0 then, so a
+// quad is inside or outside as a whole)
+template <bool VEC>
+__device__ __forceinline__ void ld4n(const float* __restrict__ p, long long i0, long long N, float (&v)[4]) {
+  if constexpr (VEC) {
+    const float4 t = i0 < N ? *reinterpret_cast<const float4*>(p + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i0 + k < N ? p[i0 + k] : 0.f;
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void st4n(float* __restrict__ p, long long i0, long long N, const float (&v)[4]) {
+  if constexpr (VEC) {
+    if (i0 < N) *reinterpret_cast<float4*>(p + i0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i0 + k < N) p[i0 + k] = v[k];
+  }
+}
+
+// (the workgroup's own elements and the pivot are requested first: the partial sums' round trip, the pivot's and the elements' used
+// to follow one another -- three serialized round trips in a workgroup that lives for one)
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 bn_finish_apply_act_kernel(const float* __restrict__ x, const float2* __restrict__ partial, int npart, float* __restrict__ mean,
                            float* __restrict__ var, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                            long long* __restrict__ num_batches_tracked, const float* __restrict__ gamma,
                            const float* __restrict__ beta, float* __restrict__ out, const BNA p) {
   const int c = blockIdx.y, b = blockIdx.z;
+  const long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  float xv[4];
+  ld4n<VEC>(x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc, i0, p.N, xv);
+  const float pivot = x[static_cast<size_t>(c) * p.xc];
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   double s, q;
   channel_partial_sum(partial, c, npart, s, q);
   const double cnt = static_cast<double>(p.B) * static_cast<double>(p.N);
   const double m1 = s / cnt;
   const double v = fmax(q / cnt - m1 * m1, 0.0);
-  const float m = static_cast<float>(m1 + static_cast<double>(x[static_cast<size_t>(c) * p.xc]));
+  const float m = static_cast<float>(m1 + static_cast<double>(pivot));
   const float vf = static_cast<float>(v);
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
     mean[c] = m;
@@ -251,41 +322,40 @@ bn_finish_apply_act_kernel(const float* __restrict__ x, const float2* __restrict
     if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
   }
   const float is = rsqrtf(vf + p.eps);
-  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   const float sc = is * g, sh = be - m * sc;
-  const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
-  float* op = out + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
-  const long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  float ov[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (i0 + k < p.N) op[i0 + k] = act_fwd(xp[i0 + k] * sc + sh, p.act);
+  for (int k = 0; k < 4; ++k) ov[k] = act_fwd(xv[k] * sc + sh, p.act);
+  st4n<VEC>(out + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc, i0, p.N, ov);
 }
 
 // bn_bwd_finish + bn_bwd_apply in one launch, the same way; workgroup (0, c, 0) writes the two sums (grad beta, grad gamma)
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 bn_bwd_finish_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
                            const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
                            const float2* __restrict__ partial, int npart, float* __restrict__ s1o, float* __restrict__ s2o,
                            float* __restrict__ dx, const BNA p) {
   const int c = blockIdx.y, b = blockIdx.z;
+  const long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  float xv[4], gv[4];
+  ld4n<VEC>(x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc, i0, p.N, xv);
+  ld4n<VEC>(dy + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc, i0, p.N, gv);
+  const float m = mean[c], is = rsqrtf(var[c] + p.eps);
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   double sa, sb;
   channel_partial_sum(partial, c, npart, sa, sb);
   const float s1 = static_cast<float>(sa), s2 = static_cast<float>(sb);
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) { s1o[c] = s1; s2o[c] = s2; }
-  const float m = mean[c], is = rsqrtf(var[c] + p.eps);
-  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   const float a1 = s1 * p.inv_n, a2 = s2 * p.inv_n;
-  const float* xp = x + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
-  const float* gp = dy + static_cast<size_t>(b) * p.ob + static_cast<size_t>(c) * p.oc;
-  float* op = dx + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc;
-  const long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  float ov[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (i0 + k < p.N) {
-      const float xh = (xp[i0 + k] - m) * is;
-      const float dz = gp[i0 + k] * act_grad(xh * g + be, p.act);
-      op[i0 + k] = (dz - a1 - xh * a2) * is * g;
-    }
+  for (int k = 0; k < 4; ++k) {
+    const float xh = (xv[k] - m) * is;
+    const float dz = gv[k] * act_grad(xh * g + be, p.act);
+    ov[k] = (dz - a1 - xh * a2) * is * g;
+  }
+  st4n<VEC>(dx + static_cast<size_t>(b) * p.xb + static_cast<size_t>(c) * p.xc, i0, p.N, ov);
 }
 
 // ---- one-launch forms for SMALL layers ------------------------------------------------------------------------------------------
@@ -441,7 +511,7 @@ int chunks_for(long long N, int B, int C, long long& chunk) {
   const long long maxn = (N + 1023) / 1024;
   if (n > maxn) n = static_cast<int>(maxn);
   if (n < 1) n = 1;
-  chunk = (N + n - 1) / n;
+  chunk = ((N + n - 1) / n + 3) & ~3ll;          // a multiple of 4: the quad loops of the reduction kernels start every chunk aligned
   return n;
 }
 
@@ -507,7 +577,8 @@ extern "C" int ts_bn_stats_fwd(const float* x, float* mean, float* var, float* r
   BN p{B, C, N, bstride, cstride, 0, 0};
   p.nchunk = chunks_for(N, B, C, p.chunk);
   float2* partial = reinterpret_cast<float2*>(workspace);
-  hipLaunchKernelGGL(bn_stats_partial, dim3(p.nchunk, C, B), dim3(256), 0, ts::as_stream(stream), x, partial, p);
+  hipLaunchKernelGGL(bn_stats_partial, dim3(p.nchunk, C, B), dim3(256), 0, ts::as_stream(stream), x, partial, p,
+                     bn_vec(x, nullptr, nullptr, N, bstride, cstride, 0, 0) ? 1 : 0);
   if (int rc = ts::launched("bn_stats_partial")) return rc;
   hipLaunchKernelGGL(bn_stats_finish, dim3(C), dim3(64), 0, ts::as_stream(stream), x, partial, mean, var, running_mean, running_var,
                      momentum, num_batches_tracked, p);
@@ -539,7 +610,7 @@ extern "C" int ts_bn_act_bwd_reduce(const float* x, const float* dy, const float
   const int n = chunks_for(N, B, C, chunk);
   float2* partial = reinterpret_cast<float2*>(workspace);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(n, C, B), dim3(256), 0, ts::as_stream(stream), x, dy, mean, var, gamma, beta, partial,
-                     p, n, chunk);
+                     p, n, chunk, bn_vec(x, dy, nullptr, N, x_bstride, x_cstride, dy_bstride, dy_cstride) ? 1 : 0);
   if (int rc = ts::launched("bn_bwd_reduce_kernel")) return rc;
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(64), 0, ts::as_stream(stream), partial, sum_dz, sum_dz_xhat, B * n);
   return ts::launched("bn_bwd_finish_kernel");
@@ -616,12 +687,18 @@ extern "C" int ts_bn_train_fwd(const float* x, float* mean, float* var, float* r
   BN p{B, C, N, x_bstride, x_cstride, 0, 0};
   p.nchunk = chunks_for(N, B, C, p.chunk);
   float2* partial = reinterpret_cast<float2*>(workspace);
-  hipLaunchKernelGGL(bn_stats_partial, dim3(p.nchunk, C, B), dim3(256), 0, ts::as_stream(stream), x, partial, p);
+  hipLaunchKernelGGL(bn_stats_partial, dim3(p.nchunk, C, B), dim3(256), 0, ts::as_stream(stream), x, partial, p,
+                     bn_vec(x, nullptr, nullptr, N, x_bstride, x_cstride, 0, 0) ? 1 : 0);
   if (int rc = ts::launched("bn_stats_partial")) return rc;
   const BNA a{B, C, N, x_bstride, x_cstride, out_bstride, out_cstride, act, 1, eps, 0.f};
-  hipLaunchKernelGGL(bn_finish_apply_act_kernel, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0,
-                     ts::as_stream(stream), x, partial, B * p.nchunk, mean, var, running_mean, running_var, momentum,
-                     num_batches_tracked, gamma, beta, out, a);
+  if (bn_vec(x, out, nullptr, N, x_bstride, x_cstride, out_bstride, out_cstride))
+    hipLaunchKernelGGL(bn_finish_apply_act_kernel<true>, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0,
+                       ts::as_stream(stream), x, partial, B * p.nchunk, mean, var, running_mean, running_var, momentum,
+                       num_batches_tracked, gamma, beta, out, a);
+  else
+    hipLaunchKernelGGL(bn_finish_apply_act_kernel<false>, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0,
+                       ts::as_stream(stream), x, partial, B * p.nchunk, mean, var, running_mean, running_var, momentum,
+                       num_batches_tracked, gamma, beta, out, a);
   return ts::launched("bn_finish_apply_act_kernel");
 }
 
@@ -648,9 +725,13 @@ extern "C" int ts_bn_train_bwd(const float* x, const float* dy, const float* mea
   const int n = chunks_for(N, B, C, chunk);
   float2* partial = reinterpret_cast<float2*>(workspace);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(n, C, B), dim3(256), 0, ts::as_stream(stream), x, dy, mean, var, gamma, beta, partial,
-                     p, n, chunk);
+                     p, n, chunk, bn_vec(x, dy, nullptr, N, x_bstride, x_cstride, dy_bstride, dy_cstride) ? 1 : 0);
   if (int rc = ts::launched("bn_bwd_reduce_kernel")) return rc;
-  hipLaunchKernelGGL(bn_bwd_finish_apply_kernel, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0,
-                     ts::as_stream(stream), x, dy, mean, var, gamma, beta, partial, B * n, sum_dz, sum_dz_xhat, dx, p);
+  if (bn_vec(x, dy, dx, N, x_bstride, x_cstride, dy_bstride, dy_cstride))
+    hipLaunchKernelGGL(bn_bwd_finish_apply_kernel<true>, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0,
+                       ts::as_stream(stream), x, dy, mean, var, gamma, beta, partial, B * n, sum_dz, sum_dz_xhat, dx, p);
+  else
+    hipLaunchKernelGGL(bn_bwd_finish_apply_kernel<false>, dim3(static_cast<unsigned>((N + 1023) / 1024), C, B), dim3(256), 0,
+                       ts::as_stream(stream), x, dy, mean, var, gamma, beta, partial, B * n, sum_dz, sum_dz_xhat, dx, p);
   return ts::launched("bn_bwd_finish_apply_kernel");
 }

@@ -461,7 +461,13 @@ int x6p_launch(const float* x, const void* w6, const float* scale, const float* 
   // Cap 208 of 256: measured 256 / 232 / 224 / 208 / 192 / 176 / 160 / 128 -> 1318 / 1335 / 1322 / 1333 / 1330 / 1313 / 1305 / 1266 pairs/s with
   // three passes in flight, batch 4 1763 / 1804 / 1802 / 1798 / 1810 / 1771 / 1767 / 1742, one pass at a time 961-965 throughout (>= 160): what a
   // pass's throughput follows is CU-time, not this launch's latency, and a workgroup that walks more tiles pays its prologue once.
-  static const long long max_wgs = env_ll("TS_X6P_WGS", 208);
+  static const long long max_wgs0 = env_ll("TS_X6P_WGS", 208);
+  // ... except a split-K launch of <= 256 items, which runs in ONE round: the coarse level's first layer (352 -> 32 on 12 x 34 x 60: 120
+  // tiles x 2 slices) is the longest launch on a pass's critical chain, 66.5 us as 120 workgroups x 2 items, 45.6 as 240 x 1; three
+  // passes in flight do not notice (1540-1546 pairs/s either way), one pass at a time gains 1-1.5 % (982 -> 991-997).  The 255-tile
+  // layers of the UNet stay under the cap: all of the chip for them costs the pass's other streams more than it saves (972 vs 982-990).
+  static const long long splitk_all = env_ll("TS_X6P_SPLITK_ALL", 1);
+  const long long max_wgs = (splitk_all && p.ksplit > 1 && total <= 256) ? 256 : max_wgs0;
   int nwg = static_cast<int>(total < max_wgs ? total : max_wgs);
   {
     const long long rounds = (total + nwg - 1) / nwg;

@@ -952,13 +952,15 @@ int launch_ig(const float* x, const float* w, const float* scale, const float* s
 __global__ void __launch_bounds__(256)
 weight_layout_kernel(const float* __restrict__ w, float* __restrict__ out, int A, int T, int nb, int bpad, long long sa, long long sb,
                      long long st, int flip) {
-  const long long n = static_cast<long long>(A) * T * bpad;
-  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
-       i += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const int b = static_cast<int>(i % bpad);
-    const long long r = i / bpad;
-    const int t = static_cast<int>(r % T), a = static_cast<int>(r / T);
-    out[i] = b < nb ? w[a * sa + b * sb + (flip ? T - 1 - t : t) * st] : 0.f;
+  // (32-bit index arithmetic: the host refuses arrays of 2^31 elements or more; the 64-bit divisions this loop used to do per element
+  // were most of the instructions of a launch that runs ~175 times per training step)
+  const unsigned n = static_cast<unsigned>(A) * static_cast<unsigned>(T) * static_cast<unsigned>(bpad);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / static_cast<unsigned>(bpad);
+    const int b = static_cast<int>(i - r * static_cast<unsigned>(bpad));
+    const unsigned a = r / static_cast<unsigned>(T);
+    const int t = static_cast<int>(r - a * static_cast<unsigned>(T));
+    out[i] = b < nb ? w[static_cast<long long>(a) * sa + b * sb + (flip ? T - 1 - t : t) * st] : 0.f;
   }
 }
 
@@ -2032,6 +2034,7 @@ extern "C" int ts_conv_weight_layout(const float* w, float* out, int A, int T, i
   TS_REQUIRE(A > 0 && T > 0 && nb > 0 && bpad >= nb, TS_ERR_SHAPE, "conv_weight_layout: bad size");
   TS_REQUIRE_PTR(w); TS_REQUIRE_PTR(out);
   const long long n = static_cast<long long>(A) * T * bpad;
+  TS_REQUIRE(n < (1ll << 31), TS_ERR_UNSUPPORTED, "conv_weight_layout: 2^31 elements or more");
   long long blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(weight_layout_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ts::as_stream(stream), w, out, A, T, nb,

@@ -46,6 +46,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
                "-Wall", "-Wno-unused-function", "-ffp-contract=on", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
+        cmd += os.environ.get("TS_HIPCC_FLAGS", "").split()     # e.g. TS_HIPCC_FLAGS=-DTS_EXACT_SILU python -m temporalstereo_amd.build --force
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

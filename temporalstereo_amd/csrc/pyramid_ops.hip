@@ -18,6 +18,9 @@ namespace {
 
 // (the inference forms; v_exp_f32 / v_rcp_f32 as conv_common.hpp's silu_fast)
 __device__ __forceinline__ float silu(float v) {
+#ifdef TS_EXACT_SILU
+  return v / (1.f + expf(-v));
+#endif
   const float d = 1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
   const float r = __builtin_amdgcn_rcpf(d);
   const float rn = fmaf(fmaf(-d, r, 1.f), r, r);

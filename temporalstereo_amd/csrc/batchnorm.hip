@@ -549,10 +549,30 @@ channel_sum_finish(const float2* __restrict__ partial, float* __restrict__ out, 
   if (threadIdx.x == 0) out[c] = static_cast<float>(a);
 }
 
+// the same in ONE launch for small tensors (the bias gradients of the heads: 2 channels x 28,560 elements): a 1024-thread workgroup
+// per channel, per-thread fp32 partials combined in double in a fixed order (as the one-launch BatchNorm forms)
+__global__ void __launch_bounds__(kSmallThreads)
+channel_sum_small_kernel(const float* __restrict__ x, float* __restrict__ out, const BN p) {
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    const float* xp = x + static_cast<size_t>(b) * p.bstride + static_cast<size_t>(c) * p.cstride;
+    for (long long i = threadIdx.x; i < p.N; i += kSmallThreads) s += xp[i];
+  }
+  double a = static_cast<double>(s), z = 0.0;
+  block_sum2_double(a, z);
+  if (threadIdx.x == 0) out[c] = static_cast<float>(a);
+}
+
 extern "C" int ts_channel_sum_fwd(const float* x, float* out, void* workspace, int B, int C, long long N, long long bstride,
                                   long long cstride, void* stream) {
   TS_REQUIRE(B > 0 && C > 0 && N > 0 && C <= 65535 && B <= 65535, TS_ERR_SHAPE, "channel_sum: bad size");
   TS_REQUIRE_PTR(x); TS_REQUIRE_PTR(out); TS_REQUIRE_PTR(workspace);
+  if (static_cast<long long>(B) * N <= 32768) {
+    const BN ps{B, C, N, bstride, cstride, 0, 0};
+    hipLaunchKernelGGL(channel_sum_small_kernel, dim3(C), dim3(kSmallThreads), 0, ts::as_stream(stream), x, out, ps);
+    return ts::launched("channel_sum_small_kernel");
+  }
   BN p{B, C, N, bstride, cstride, 0, 0};
   p.nchunk = chunks_for(N, B, C, p.chunk);
   float2* partial = reinterpret_cast<float2*>(workspace);

@@ -147,3 +147,18 @@ def test_eval_batchnorm_folds_equal_the_unfused_wrappers():
             y = m(xg)                                           # gradients enabled: the ordinary autograd node
         assert y.requires_grad and len(folds.entries) == n_before
     assert len(folds.entries) == len(layers)
+
+
+def test_channel_sum_both_forms():
+    """A convolution's bias gradient (ts_channel_sum_fwd): one launch for small tensors (a 1024-thread workgroup per channel), two
+    deterministic stages otherwise -- both against torch in double, and bit-identical from call to call."""
+    from temporalstereo_amd import functional as TF
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    for shape in ((1, 2, 14, 34, 60), (2, 3, 5, 17, 33), (1, 9, 544, 960), (3, 8, 1, 1, 1), (1, 16, 7, 68, 120), (4, 2, 32768 // 4 + 1)):
+        dy = torch.randn(*shape, generator=g).to(dev)
+        got = TF._channel_sum(dy)
+        want = dy.double().transpose(0, 1).reshape(shape[1], -1).sum(1)
+        scale = float(dy.double().abs().transpose(0, 1).reshape(shape[1], -1).sum(1).max())
+        assert float((got.double() - want).abs().max()) <= 2e-7 * scale, shape
+        assert torch.equal(got, TF._channel_sum(dy))
